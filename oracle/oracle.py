@@ -1,0 +1,184 @@
+"""ctypes binding of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+`load()` returns the C99 restatement (oracle/liboracle.so, prefix ``orc_``); `load_ref()` returns
+the reference's own gainmapmath.cpp behind ref_harness.cpp (oracle/_ref/libuhdr_ref.so, prefix
+``ref_``) or None when it has not been built (it is only buildable where /root/reference exists;
+the prebuilt .so travels to the GPU box).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# enum values (lib/include/ultrahdr/ultrahdr.h:36-120)
+CG_UNSPECIFIED, CG_BT709, CG_P3, CG_BT2100 = -1, 0, 1, 2
+TF_LINEAR, TF_HLG, TF_PQ, TF_SRGB = 0, 1, 2, 3
+OUT_SDR, OUT_HDR_LINEAR, OUT_HDR_PQ, OUT_HDR_HLG, OUT_HDR_LINEAR_RGB_10BIT = 0, 1, 2, 3, 4
+FMT_P010, FMT_YUV420, FMT_MONOCHROME = 0, 1, 2
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_size_t), ("height", C.c_size_t),
+                ("colorGamut", C.c_int32), ("chroma_data", C.c_void_p),
+                ("luma_stride", C.c_size_t), ("chroma_stride", C.c_size_t),
+                ("pixelFormat", C.c_int32)]
+
+
+class Metadata(C.Structure):
+    _fields_ = [("maxContentBoost", C.c_float), ("minContentBoost", C.c_float),
+                ("gamma", C.c_float), ("offsetSdr", C.c_float), ("offsetHdr", C.c_float),
+                ("hdrCapacityMin", C.c_float), ("hdrCapacityMax", C.c_float),
+                ("version_ok", C.c_int32)]
+
+
+class Color(C.Structure):
+    _fields_ = [("r", C.c_float), ("g", C.c_float), ("b", C.c_float)]
+
+    def tup(self):
+        return (self.r, self.g, self.b)
+
+
+def _declare(lib, p):
+    f32, u8, sz, i32 = C.c_float, C.c_uint8, C.c_size_t, C.c_int
+    IP, MP = C.POINTER(Image), C.POINTER(Metadata)
+
+    def d(name, res, *args):
+        fn = getattr(lib, p + name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    for n in ("srgbInvOetf", "hlgOetf", "hlgInvOetf", "pqOetf", "pqInvOetf"):
+        d(n, f32, f32)
+    d("luminance", f32, i32, Color)
+    d("yuvToRgb", Color, i32, Color)
+    d("rgbToYuv", Color, i32, Color)
+    d("gamutConv", Color, i32, i32, Color, C.POINTER(C.c_int))
+    d("yuvToYuv", Color, i32, i32, Color)
+    d("encodeGain", u8, f32, f32, f32, f32, f32, f32)
+    d("encodeGain3", u8, f32, f32, f32, f32)
+    d("applyGain3", Color, Color, f32, f32, f32)
+    d("applyGain4", Color, Color, f32, f32, f32, f32)
+    d("getYuv420Pixel", Color, IP, sz, sz)
+    d("getP010Pixel", Color, IP, sz, sz)
+    d("sampleYuv420", Color, IP, sz, sz, sz)
+    d("sampleP010", Color, IP, sz, sz, sz)
+    d("fillShepardsIDW", None, C.POINTER(f32), i32, i32, i32)
+    d("sampleMapIdw", f32, IP, sz, sz, sz)
+    d("sampleMapFloat", f32, IP, f32, sz, sz)
+    d("colorToRgba1010102", C.c_uint32, Color)
+    d("colorToRgbaF16", C.c_uint64, Color)
+    d("floatToHalf", C.c_uint16, f32)
+    d("transformYuv420", None, IP, sz, sz, i32, i32)
+    d("generateGainMap", i32, IP, IP, i32, MP, C.c_void_p, i32, i32)
+    d("applyGainMap", i32, IP, IP, MP, i32, f32, IP, i32)
+    d("convertYuv", i32, IP, i32, i32)
+    if p == "orc_":
+        d("generateGainMapStats", i32, IP, IP, i32, MP, C.c_void_p, i32, i32, C.POINTER(f32))
+        d("toneMap", i32, IP, IP)
+        d("fill_lcg", None, C.c_void_p, C.c_void_p, sz, sz, C.c_uint32)
+        d("checksum_u8", C.c_uint64, C.c_void_p, sz)
+        d("checksum_u32", C.c_uint64, C.c_void_p, sz)
+    else:
+        for n in ("srgbInvOetfLUT", "hlgOetfLUT", "hlgInvOetfLUT", "pqOetfLUT", "pqInvOetfLUT"):
+            d(n, f32, f32)
+        d("applyGainLUT", Color, Color, f32, f32, f32, f32)
+    return lib
+
+
+def build(ref=True):
+    """Compile the checker (and, where /root/reference exists, oracle/_ref)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if ref and os.path.isdir("/root/reference/lib/src"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+_cache = {}
+
+
+def load():
+    if "orc" not in _cache:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        _cache["orc"] = _declare(C.CDLL(path), "orc_")
+    return _cache["orc"]
+
+
+def load_ref():
+    if "ref" not in _cache:
+        path = os.path.join(_HERE, "_ref", "libuhdr_ref.so")
+        if not os.path.exists(path) and os.path.isdir("/root/reference/lib/src"):
+            build(ref=True)
+        _cache["ref"] = _declare(C.CDLL(path), "ref_") if os.path.exists(path) else None
+    return _cache["ref"]
+
+
+# ------------------------------------------------------------------ numpy-level helpers
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+def yuv420_image(buf, w, h, gamut, luma_stride=None, chroma_stride=None, chroma=None):
+    """buf: uint8 array holding Y (luma_stride*h) then U,V planes unless `chroma` (separate
+    uint8 array: U plane then V plane at chroma_stride*(h/2)) is given."""
+    ls = luma_stride or w
+    cs = chroma_stride or ls // 2
+    cptr = _ptr(chroma) if chroma is not None else buf.ctypes.data + ls * h
+    return Image(buf.ctypes.data, w, h, gamut, cptr, ls, cs, FMT_YUV420)
+
+
+def p010_image(buf, w, h, gamut, luma_stride=None, chroma_stride=None, chroma=None):
+    ls = luma_stride or w
+    cs = chroma_stride or ls
+    cptr = _ptr(chroma) if chroma is not None else buf.ctypes.data + ls * h * 2
+    return Image(buf.ctypes.data, w, h, gamut, cptr, ls, cs, FMT_P010)
+
+
+def map_image(buf, mw, mh):
+    return Image(buf.ctypes.data, mw, mh, CG_UNSPECIFIED, None, mw, 0, FMT_MONOCHROME)
+
+
+def out_bytes_per_image(fmt, w, h):
+    return {OUT_HDR_LINEAR: 8, OUT_HDR_PQ: 4, OUT_HDR_HLG: 4, OUT_HDR_LINEAR_RGB_10BIT: 6}.get(fmt, 0) * w * h
+
+
+def lcg_frame(w, h, seed):
+    """SURVEY.md 8(d) synthetic pair: (p010 uint16[w*h*3/2], yuv uint8[w*h*3/2])."""
+    lib = load()
+    p010 = np.empty(w * h * 3 // 2, np.uint16)
+    yuv = np.empty(w * h * 3 // 2, np.uint8)
+    lib.orc_fill_lcg(p010.ctypes.data, yuv.ctypes.data, w, h, seed)
+    return p010, yuv
+
+
+def generate(lib_prefix, yuv_img, p010_img, tf, sdr_is_601=False, threads=0, stats=False):
+    lib = load() if lib_prefix == "orc_" else load_ref()
+    mw, mh = yuv_img.width // 4, yuv_img.height // 4
+    out = np.zeros(max(mw * mh, 1), np.uint8)
+    md = Metadata()
+    if stats:
+        mm = (C.c_float * 2)()
+        st = lib.orc_generateGainMapStats(C.byref(yuv_img), C.byref(p010_img), tf, C.byref(md),
+                                          out.ctypes.data, int(sdr_is_601), threads, mm)
+        return st, out[:mw * mh].reshape(mh, mw), md, (mm[0], mm[1])
+    st = getattr(lib, lib_prefix + "generateGainMap")(C.byref(yuv_img), C.byref(p010_img), tf,
+                                                      C.byref(md), out.ctypes.data,
+                                                      int(sdr_is_601), threads)
+    return st, out[:mw * mh].reshape(mh, mw), md
+
+
+def apply(lib_prefix, yuv_img, map_arr, md, fmt, max_display_boost, threads=0):
+    lib = load() if lib_prefix == "orc_" else load_ref()
+    mh, mw = map_arr.shape
+    m = map_image(map_arr, mw, mh)
+    w, h = yuv_img.width, yuv_img.height
+    out = np.zeros(max(out_bytes_per_image(fmt, w, h), 8), np.uint8)
+    dest = Image(out.ctypes.data, 0, 0, CG_UNSPECIFIED, None, 0, 0, -1)
+    st = getattr(lib, lib_prefix + "applyGainMap")(C.byref(yuv_img), C.byref(m), C.byref(md), fmt,
+                                                   max_display_boost, C.byref(dest), threads)
+    return st, out[:out_bytes_per_image(fmt, w, h)], dest

@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPixels/sec of gain-map generate + apply on an HBM-resident batch of
+4K P010 + YUV420 pairs (BASELINE.json metric; workload = configs[2], "Batch 64 x 4K P010 frames,
+generate+apply on 1 MI355X"; with N GPUs every rank holds its own 64 frames = configs[3]'s sharding).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over the rank's batch: generateGainMap (HLG, P010 BT.2100 vs
+SDR BT.709) into HBM-resident maps, then applyGainMap (FAST) of those maps -> RGBA1010102 HLG with
+max_display_boost = FLT_MAX.  Inputs are already in HBM when the timed region starts; nothing crosses
+PCIe inside it.  For N > 1 each step also all-reduces (RCCL) the batch's content min/max boost --
+the only exchange the path has.  Rank 0 prints ONE JSON line.
+
+MPix = width*height counted once per (generate+apply) pair.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from libultrahdr_dev_amd import api, synth
+
+W, H = 3840, 2160
+CHUNK = 32                       # images per kernel launch (kMaxChunk in csrc/uhdr_kernels.h)
+# algorithmic HBM bytes per 4K frame: every input byte read once, every output written once
+GEN_BYTES = W * H * 3 + W * H * 3 // 2 + (W // 4) * (H // 4)           # 24 883 200 + 12 441 600 + 518 400
+APP_BYTES = W * H * 3 // 2 + (W // 4) * (H // 4) + W * H * 4           # 12 441 600 + 518 400 + 33 177 600
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="4K frame pairs resident per GPU")
+    ap.add_argument("--apply-format", default="hlg", choices=["hlg", "pq"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same batch timed on the host CPU")
+    return ap.parse_args()
+
+
+class Batch:
+    """`frames` 4K pairs + their maps and 1010102 outputs, all resident in this rank's HBM."""
+
+    def __init__(self, lib, frames, rank):
+        self.lib, self.n = lib, frames
+        self.p010, self.yuv, self.maps, self.outs = [], [], [], []
+        for i in range(frames):
+            p, y = synth.lcg_frame(W, H, 1234 + rank * frames + i)   # seed = 1234 + global image index
+            self.p010.append(p)
+            self.yuv.append(y)
+            self.maps.append(torch.zeros((W // 4) * (H // 4), dtype=torch.uint8, device="cuda"))
+            self.outs.append(torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda"))
+        self.minmax = torch.zeros(2 * frames, dtype=torch.float32, device="cuda")
+        self.yi = api.image_array([api.yuv420_image(y.data_ptr(), W, H, api.CG_BT709) for y in self.yuv])
+        self.pi = api.image_array([api.p010_image(p.data_ptr(), W, H, api.CG_BT2100) for p in self.p010])
+        self.mi = api.image_array([api.out_image(m.data_ptr()) for m in self.maps])
+        self.oi = api.image_array([api.out_image(o.data_ptr()) for o in self.outs])
+        self.md = api.Metadata()
+
+    def _slice(self, arr, lo):
+        return C.cast(C.byref(arr, lo * C.sizeof(api.Image)), C.POINTER(api.Image))
+
+    def generate(self, stream, events=None):
+        for lo in range(0, self.n, CHUNK):
+            m = min(CHUNK, self.n - lo)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = self.lib.uhdr_hip_generate_gainmap_batch(
+                m, self._slice(self.yi, lo), self._slice(self.pi, lo), api.TF_HLG, C.byref(self.md),
+                self._slice(self.mi, lo), 0, C.c_void_p(self.minmax.data_ptr() + 8 * lo), stream)
+            assert rc == 0, rc
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, m))
+
+    def apply(self, stream, fmt, events=None):
+        for lo in range(0, self.n, CHUNK):
+            m = min(CHUNK, self.n - lo)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = self.lib.uhdr_hip_apply_gainmap_batch(
+                m, self._slice(self.yi, lo), self._slice(self.mi, lo), C.byref(self.md), fmt, api.FLT_MAX,
+                self._slice(self.oi, lo), api.APPLY_FAST, stream)
+            assert rc == 0, rc
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, m))
+
+
+def cpu_baseline(batch, fmt, nframes):
+    """The oracle (kind "port": byte-identical to the reference on its golden vectors) timed on this
+    box's host cores on the first `nframes` frames of rank 0's batch, and cross-checked against the GPU
+    outputs of the same frames.  This is the ONLY use of oracle/ in this file."""
+    from oracle import oracle as O
+    ncpu = os.cpu_count() or 1
+    torch.cuda.synchronize()
+    t_gen = t_app = t_gen4 = t_app4 = 0.0
+    worst, ndiff, nch = 0, 0, 0
+    for i in range(nframes):
+        p010 = batch.p010[i].cpu().numpy().view(np.uint16)
+        yuv = batch.yuv[i].cpu().numpy()
+        yi, pi = O.yuv420_image(yuv, W, H, O.CG_BT709), O.p010_image(p010, W, H, O.CG_BT2100)
+        t0 = time.perf_counter()
+        st, omap, omd = O.generate("orc_", yi, pi, O.TF_HLG, threads=ncpu)
+        t1 = time.perf_counter()
+        st2, ref, _ = O.apply("orc_", yi, omap, omd, fmt, api.FLT_MAX, threads=ncpu)
+        t2 = time.perf_counter()
+        assert st == 0 and st2 == 0
+        t_gen += t1 - t0
+        t_app += t2 - t1
+        if i == 0:  # the reference's own threading policy: min(cores, 4) threads (ultrahdr.cpp:304,500)
+            t0 = time.perf_counter()
+            O.generate("orc_", yi, pi, O.TF_HLG, threads=0)
+            t1 = time.perf_counter()
+            O.apply("orc_", yi, omap, omd, fmt, api.FLT_MAX, threads=0)
+            t2 = time.perf_counter()
+            t_gen4, t_app4 = t1 - t0, t2 - t1
+        gmap = batch.maps[i].cpu().numpy().reshape(omap.shape)
+        assert np.array_equal(gmap, omap), "GPU gain map differs from the CPU oracle on frame %d" % i
+        out = batch.outs[i].cpu().numpy().view(np.uint32)
+        ref = ref.view(np.uint32)
+        for sh in (0, 10, 20):
+            d = np.abs(((out >> sh) & 0x3ff).astype(np.int32) - ((ref >> sh) & 0x3ff).astype(np.int32))
+            worst = max(worst, int(d.max()))
+            ndiff += int((d != 0).sum())
+            nch += d.size
+    mpix = W * H / 1e6
+    return {
+        "value": round(nframes * mpix / (t_gen + t_app), 3), "unit": "MPix/s", "cores": ncpu, "kind": "port",
+        "sample": "%d of the batch's 4K frames, generate+apply(%s), oracle/uhdr_oracle.c -O2 -ffp-contract=off, "
+                  "%d row-band threads" % (nframes, "HLG" if fmt == api.OUTPUT_HDR_HLG else "PQ", ncpu),
+        "generate_mpix_s": round(nframes * mpix / t_gen, 3), "apply_mpix_s": round(nframes * mpix / t_app, 3),
+        "ref_policy_4_threads_mpix_s": round(mpix / (t_gen4 + t_app4), 3),
+        "gpu_vs_cpu_parity": {"map_bit_exact": True, "apply_worst_lsb": worst,
+                              "apply_channels_differing": round(ndiff / max(nch, 1), 6)},
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    lib = api.init(local)
+    fmt = api.OUTPUT_HDR_HLG if a.apply_format == "hlg" else api.OUTPUT_HDR_PQ
+
+    batch = Batch(lib, a.frames, rank)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    red = torch.zeros(2, dtype=torch.float32, device="cuda")
+
+    def step(ev_gen=None, ev_app=None):
+        batch.generate(stream, ev_gen)
+        if world > 1:
+            # the path's only exchange: batch-wide content min / max boost (8 bytes, latency-bound)
+            mm = batch.minmax.view(-1, 2)
+            red[0] = mm[:, 0].min()
+            red[1] = -mm[:, 1].max()
+            dist.all_reduce(red, op=dist.ReduceOp.MIN)
+        batch.apply(stream, fmt, ev_app)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev_gen, ev_app = [], []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(ev_gen, ev_app)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    def avg_ms_per_launch(evs):   # every event pair brackets exactly one kernel launch of <= CHUNK frames
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        frames = sum(m for _, _, m in evs)
+        return tot_ms / max(len(evs), 1), tot_ms, frames
+
+    gen_ms, gen_tot, gen_frames = avg_ms_per_launch(ev_gen)
+    app_ms, app_tot, app_frames = avg_ms_per_launch(ev_app)
+
+    if rank == 0:
+        mpix_frame = W * H / 1e6
+        total_frames = a.frames * world * a.steps
+        value = total_frames * mpix_frame / elapsed
+        gen_gbs = GEN_BYTES * gen_frames / (gen_tot * 1e-3) / 1e9
+        app_gbs = APP_BYTES * app_frames / (app_tot * 1e-3) / 1e9
+        dominant = "apply" if app_tot >= gen_tot else "generate"
+        ach = app_gbs if dominant == "apply" else gen_gbs
+        per_launch = (APP_BYTES if dominant == "apply" else GEN_BYTES) * min(CHUNK, a.frames)
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command
+            try:
+                tj = json.load(open(tp))
+                traffic, traffic_src = tj.get(dominant), tj.get("source")
+            except Exception:
+                pass
+        out = {
+            "metric": "MPixels/sec gain-map generate+apply, 4K P010 batch", "value": round(value, 1), "unit": "MPix/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 in, f32+f64 math, u8/u32 out",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: batch %d x 3840x2160 P010(BT.2100,HLG)+YUV420(BT.709) per GPU, "
+                                   "generate + apply(FAST)->RGBA1010102 %s, HBM-resident" % (a.frames, a.apply_format.upper()),
+                       "frames_per_gpu": a.frames, "width": W, "height": H, "images_per_launch": min(CHUNK, a.frames),
+                       "parallelism": "one image batch per GPU, no pixel traffic between GPUs"},
+            "roofline": {"bound": "hbm", "kernel": "k_apply_s4<HLG>" if dominant == "apply" else "k_generate<HLG,aligned>",
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "avg_launch_ms": round(app_ms if dominant == "apply" else gen_ms, 4)},
+            "kernels": {
+                "generate": {"avg_launch_ms": round(gen_ms, 4), "GB/s": round(gen_gbs, 1), "frac_of_8TBs": round(gen_gbs / HBM_PEAK_GBS, 4),
+                             "bytes_per_frame": GEN_BYTES},
+                "apply": {"avg_launch_ms": round(app_ms, 4), "GB/s": round(app_gbs, 1), "frac_of_8TBs": round(app_gbs / HBM_PEAK_GBS, 4),
+                          "bytes_per_frame": APP_BYTES},
+                "generate+apply_GB/s": round((GEN_BYTES + APP_BYTES) * total_frames / world / elapsed / 1e9, 1),
+                "frac_of_8TBs_whole_step_per_gpu": round((GEN_BYTES + APP_BYTES) * total_frames / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, fmt, max(1, min(a.cpu_frames, a.frames)))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

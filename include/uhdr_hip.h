@@ -1,0 +1,188 @@
+/*
+ * uhdr_hip.h -- C-ABI of the MI355X (gfx950) gain-map pixel path.
+ *
+ * This is the drop-in boundary for the per-pixel hot path of libultrahdr_dev.  The reference has
+ * no FFI layer: the path sits behind three protected C++ members of ultrahdr::UltraHdr plus one
+ * private member of JpegR.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference tree); INTEGRATION.md shows the binding a maintainer adds.
+ *
+ *   uhdr_hip_generate_gainmap   <- UltraHdr::generateGainMap   lib/include/ultrahdr/ultrahdr.h:348-350
+ *                                                              lib/src/ultrahdr.cpp:185-358
+ *   uhdr_hip_apply_gainmap      <- UltraHdr::applyGainMap      lib/include/ultrahdr/ultrahdr.h:370-372
+ *                                                              lib/src/ultrahdr.cpp:360-515
+ *   uhdr_hip_tonemap            <- UltraHdr::toneMap           lib/include/ultrahdr/ultrahdr.h:381
+ *                                                              lib/src/ultrahdr.cpp:517-558
+ *   uhdr_hip_convert_yuv        <- JpegR::convertYuv           lib/include/ultrahdr/jpegr.h:329-330
+ *                                                              lib/src/jpegr.cpp:1132-1206
+ *
+ * Conventions
+ *  - plain C, POD only; no torch / STL types.  Enum VALUES are the reference's
+ *    (lib/include/ultrahdr/ultrahdr.h:36-120).  Return value is the reference's status_t value
+ *    for the same inputs (first failing check wins, same order); HIP failures map to
+ *    UHDR_HIP_UNKNOWN_ERROR (-1); "no usable GPU / library not initialised" is
+ *    UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE (-20009).  There is NO CPU fallback.
+ *  - images use the reference descriptor (ultrahdr_uncompressed_struct, ultrahdr.h:152-181):
+ *    strides in PIXELS (P010 chroma stride counts uint16 elements of the interleaved plane),
+ *    chroma_data must be non-NULL (callers normalise exactly as jpegr.cpp:265-278 does).
+ *    YUV420: U plane at chroma_data, V plane at chroma_data + chroma_stride*(height/2).
+ *  - mem_space says where every data pointer of the call lives:
+ *      UHDR_HIP_MEM_DEVICE  device pointers; the call only enqueues kernels on `stream`
+ *                           (asynchronous; graph-capturable; nothing is allocated or copied);
+ *      UHDR_HIP_MEM_HOST    host pointers; the library stages through its own device workspace
+ *                           (H2D, kernels, D2H) and returns after the result is back in host memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - the library never allocates result memory on behalf of the caller: the gain map buffer
+ *    ((width/4)*(height/4) bytes) is caller-provided in dest->data.  (The C++ shim in
+ *    include/ultrahdr_hip/ultrahdr.h reproduces the reference's new[] contract on top of this.)
+ */
+#ifndef UHDR_HIP_H
+#define UHDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UHDR_HIP_ABI_VERSION 1
+
+/* ultrahdr_color_gamut, ultrahdr.h:36-42 */
+#define UHDR_HIP_CG_UNSPECIFIED (-1)
+#define UHDR_HIP_CG_BT709 0
+#define UHDR_HIP_CG_P3 1
+#define UHDR_HIP_CG_BT2100 2
+/* ultrahdr_transfer_function, ultrahdr.h:46-53 */
+#define UHDR_HIP_TF_LINEAR 0
+#define UHDR_HIP_TF_HLG 1
+#define UHDR_HIP_TF_PQ 2
+#define UHDR_HIP_TF_SRGB 3
+/* ultrahdr_output_format, ultrahdr.h:56-64 */
+#define UHDR_HIP_OUTPUT_SDR 0
+#define UHDR_HIP_OUTPUT_HDR_LINEAR 1            /* RGBA F16, 8 B/pixel */
+#define UHDR_HIP_OUTPUT_HDR_PQ 2                /* RGBA1010102, 4 B/pixel */
+#define UHDR_HIP_OUTPUT_HDR_HLG 3               /* RGBA1010102, 4 B/pixel */
+#define UHDR_HIP_OUTPUT_HDR_LINEAR_RGB_10BIT 4  /* three planar uint16 planes, 6 B/pixel */
+/* ultrahdr_pixel_format, ultrahdr.h:67-75 */
+#define UHDR_HIP_PIX_FMT_UNSPECIFIED (-1)
+#define UHDR_HIP_PIX_FMT_P010 0
+#define UHDR_HIP_PIX_FMT_YUV420 1
+#define UHDR_HIP_PIX_FMT_MONOCHROME 2
+/* status_t, ultrahdr.h:91-120 */
+#define UHDR_HIP_NO_ERROR 0
+#define UHDR_HIP_UNKNOWN_ERROR (-1)
+#define UHDR_HIP_ERROR_BAD_PTR (-10001)
+#define UHDR_HIP_ERROR_INVALID_COLORGAMUT (-10003)
+#define UHDR_HIP_ERROR_INVALID_TRANS_FUNC (-10005)
+#define UHDR_HIP_ERROR_RESOLUTION_MISMATCH (-10006)
+#define UHDR_HIP_ERROR_BAD_METADATA (-10010)
+#define UHDR_HIP_ERROR_UNSUPPORTED_MAP_SCALE_FACTOR (-20008)
+#define UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE (-20009)
+
+#define UHDR_HIP_MEM_HOST 0
+#define UHDR_HIP_MEM_DEVICE 1
+
+/* arithmetic mode of uhdr_hip_apply_gainmap*:
+ *   FAST  : float transcendentals on the CDNA4 special-function unit; every 10-bit channel within
+ *           1 LSB and every F16 channel within 1 half-ULP of the reference CPU path;
+ *   EXACT : the reference's float/double promotion pattern replayed with double libm-grade
+ *           pow/exp/log/exp2 (same bytes as the CPU path; several times slower).
+ * generate/tonemap/convert_yuv have a single, bit-exact mode. */
+#define UHDR_HIP_APPLY_FAST 0
+#define UHDR_HIP_APPLY_EXACT 1
+
+/* POD mirror of ultrahdr_uncompressed_struct (ultrahdr.h:152-181) */
+typedef struct uhdr_hip_image {
+  void* data;           /* luma plane (or gain map / packed output) */
+  size_t width;         /* luma width in pixels */
+  size_t height;        /* luma height in pixels */
+  int32_t colorGamut;   /* UHDR_HIP_CG_* */
+  void* chroma_data;    /* U plane (YUV420) / interleaved UV plane (P010); must be non-NULL */
+  size_t luma_stride;   /* pixels */
+  size_t chroma_stride; /* pixels (P010: uint16 elements of the interleaved plane) */
+  int32_t pixelFormat;  /* UHDR_HIP_PIX_FMT_* */
+} uhdr_hip_image_t;
+
+/* POD mirror of ultrahdr_metadata_struct (ultrahdr.h:129-147); version is the NUL-terminated
+ * string the reference keeps in a std::string ("1.0", ultrahdr.h:210) */
+typedef struct uhdr_hip_metadata {
+  char version[8];
+  float maxContentBoost;
+  float minContentBoost;
+  float gamma;
+  float offsetSdr;
+  float offsetHdr;
+  float hdrCapacityMin;
+  float hdrCapacityMax;
+} uhdr_hip_metadata_t;
+
+/* ---- library / device management -------------------------------------------------------- */
+
+/* ABI version of the loaded library (== UHDR_HIP_ABI_VERSION of the header it was built from) */
+int uhdr_hip_abi_version(void);
+/* number of visible HIP devices (0 when there is no GPU; never fails) */
+int uhdr_hip_device_count(void);
+/* bind the calling process to `device` (hipSetDevice), upload the constant tables, create the
+ * staging workspace.  Must be called once per device before any compute call. */
+int uhdr_hip_init(int device);
+/* release the workspace of every initialised device */
+int uhdr_hip_shutdown(void);
+/* last HIP error text seen by the library on this thread ("" if none) */
+const char* uhdr_hip_last_error(void);
+
+/* ---- single image ------------------------------------------------------------------------ */
+
+/* UltraHdr::generateGainMap (ultrahdr.cpp:185-358).  Writes the (width/4)x(height/4) u8 map into
+ * dest->data (caller-allocated, stride == map width), fills dest->{width,height,colorGamut,
+ * luma_stride,chroma_data,chroma_stride,pixelFormat} and *metadata (the reference's constants,
+ * ultrahdr.cpp:250-257). */
+int uhdr_hip_generate_gainmap(const uhdr_hip_image_t* yuv420_image, const uhdr_hip_image_t* p010_image,
+                              int hdr_tf, uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dest,
+                              int sdr_is_601, int mem_space, void* stream);
+
+/* UltraHdr::applyGainMap (ultrahdr.cpp:360-515).  dest->data is caller-allocated:
+ * width*height*{8|4|6} bytes for HDR_LINEAR | HDR_PQ,HDR_HLG | HDR_LINEAR_RGB_10BIT; any other
+ * output_format writes nothing and returns NO_ERROR, like the reference (ultrahdr.cpp:491-493). */
+int uhdr_hip_apply_gainmap(const uhdr_hip_image_t* yuv420_image, const uhdr_hip_image_t* gainmap_image,
+                           const uhdr_hip_metadata_t* metadata, int output_format,
+                           float max_display_boost, uhdr_hip_image_t* dest, int apply_mode,
+                           int mem_space, void* stream);
+
+/* UltraHdr::toneMap (ultrahdr.cpp:517-558): P010 -> YUV420 by bit shift, stride padding zeroed. */
+int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int mem_space, void* stream);
+
+/* JpegR::convertYuv (jpegr.cpp:1132-1206): in-place YUV420 matrix re-encode between
+ * BT.709 / BT.601(P3) / BT.2100 encodings. */
+int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_encoding, int mem_space,
+                         void* stream);
+
+/* ---- batches (device memory only, asynchronous on `stream`) ------------------------------ */
+/* The reference processes one image per call; a batch is n independent calls with identical
+ * (hdr_tf, sdr_is_601 | metadata, output_format, max_display_boost).  Images of equal size share
+ * one kernel launch (grid.y = image).  Descriptor arrays live in HOST memory and are consumed
+ * before the call returns; the data pointers inside them are DEVICE pointers. */
+
+/* content_minmax (optional, DEVICE pointer to 2*n floats): per image i, [2i] = min and [2i+1] =
+ * max over map pixels of the UNCLAMPED gain (gainmapmath.cpp:531-534 before the clamp).  This
+ * statistic has no reference counterpart (the reference writes constants, ultrahdr.cpp:250-257);
+ * the emitted metadata stays the reference's constants. */
+int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuv420_images,
+                                    const uhdr_hip_image_t* p010_images, int hdr_tf,
+                                    uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dests,
+                                    int sdr_is_601, float* content_minmax, void* stream);
+
+int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuv420_images,
+                                 const uhdr_hip_image_t* gainmap_images,
+                                 const uhdr_hip_metadata_t* metadata, int output_format,
+                                 float max_display_boost, uhdr_hip_image_t* dests, int apply_mode,
+                                 void* stream);
+
+/* ---- introspection for tests -------------------------------------------------------------- */
+/* copies the 4 Shepard IDW weight tables (standard, no-right, no-bottom, corner; each
+ * scale*scale*4 floats; gainmapmath.h:184-228) the apply kernels use for `scale` into out[] */
+int uhdr_hip_idw_tables(int scale, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UHDR_HIP_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of include/uhdr_hip.h (the drop-in C-ABI).  No compute happens in Python.
+
+Names follow the reference (lib/include/ultrahdr/ultrahdr.h): images are described by the fields
+of ``ultrahdr_uncompressed_struct``, metadata by ``ultrahdr_metadata_struct``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuhdr_hip.so")
+
+# enum values: ultrahdr.h:36-120
+CG_UNSPECIFIED, CG_BT709, CG_P3, CG_BT2100 = -1, 0, 1, 2
+TF_LINEAR, TF_HLG, TF_PQ, TF_SRGB = 0, 1, 2, 3
+OUTPUT_SDR, OUTPUT_HDR_LINEAR, OUTPUT_HDR_PQ, OUTPUT_HDR_HLG, OUTPUT_HDR_LINEAR_RGB_10BIT = 0, 1, 2, 3, 4
+PIX_FMT_P010, PIX_FMT_YUV420, PIX_FMT_MONOCHROME = 0, 1, 2
+NO_ERROR, UNKNOWN_ERROR = 0, -1
+ERROR_BAD_PTR, ERROR_INVALID_COLORGAMUT, ERROR_INVALID_TRANS_FUNC = -10001, -10003, -10005
+ERROR_RESOLUTION_MISMATCH, ERROR_BAD_METADATA = -10006, -10010
+ERROR_UNSUPPORTED_MAP_SCALE_FACTOR, ERROR_INSUFFICIENT_RESOURCE = -20008, -20009
+MEM_HOST, MEM_DEVICE = 0, 1
+APPLY_FAST, APPLY_EXACT = 0, 1
+FLT_MAX = 3.4028234663852886e38
+
+
+class Image(C.Structure):
+    """uhdr_hip_image_t == ultrahdr_uncompressed_struct (ultrahdr.h:152-181); strides in pixels."""
+    _fields_ = [("data", C.c_void_p), ("width", C.c_size_t), ("height", C.c_size_t),
+                ("colorGamut", C.c_int32), ("chroma_data", C.c_void_p),
+                ("luma_stride", C.c_size_t), ("chroma_stride", C.c_size_t),
+                ("pixelFormat", C.c_int32)]
+
+
+class Metadata(C.Structure):
+    """uhdr_hip_metadata_t == ultrahdr_metadata_struct (ultrahdr.h:129-147)."""
+    _fields_ = [("version", C.c_char * 8), ("maxContentBoost", C.c_float),
+                ("minContentBoost", C.c_float), ("gamma", C.c_float), ("offsetSdr", C.c_float),
+                ("offsetHdr", C.c_float), ("hdrCapacityMin", C.c_float),
+                ("hdrCapacityMax", C.c_float)]
+
+
+# every symbol include/uhdr_hip.h declares, with its signature
+_IP, _MP = C.POINTER(Image), C.POINTER(Metadata)
+SIGNATURES = {
+    "uhdr_hip_abi_version": (C.c_int, []),
+    "uhdr_hip_device_count": (C.c_int, []),
+    "uhdr_hip_init": (C.c_int, [C.c_int]),
+    "uhdr_hip_shutdown": (C.c_int, []),
+    "uhdr_hip_last_error": (C.c_char_p, []),
+    "uhdr_hip_generate_gainmap": (C.c_int, [_IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_void_p]),
+    "uhdr_hip_apply_gainmap": (C.c_int, [_IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_int, C.c_void_p]),
+    "uhdr_hip_tonemap": (C.c_int, [_IP, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_convert_yuv": (C.c_int, [_IP, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uhdr_hip_generate_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_void_p, C.c_void_p]),
+    "uhdr_hip_apply_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_idw_tables": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libuhdr_hip.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libuhdr_hip.so is missing: build the HIP extension first "
+                "(python -m libultrahdr_dev_amd.build).  There is no CPU path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.uhdr_hip_abi_version() != 1:
+            raise ImportError("libuhdr_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+class UhdrHipError(RuntimeError):
+    pass
+
+
+_inited = set()
+
+
+def init(device=0):
+    """uhdr_hip_init(device); raises when there is no usable GPU."""
+    lib = load()
+    if device not in _inited:
+        rc = lib.uhdr_hip_init(device)
+        if rc != NO_ERROR:
+            raise UhdrHipError("uhdr_hip_init(%d) -> %d: %s" % (device, rc, lib.uhdr_hip_last_error().decode()))
+        _inited.add(device)
+    return lib
+
+
+# ---- descriptor helpers (device or host pointers; nothing is copied) --------------------------------
+
+def yuv420_image(ptr, w, h, gamut, luma_stride=None, chroma_stride=None, chroma_ptr=None):
+    ls = w if luma_stride is None else luma_stride
+    cs = ls // 2 if chroma_stride is None else chroma_stride
+    cp = ptr + ls * h if chroma_ptr is None else chroma_ptr
+    return Image(ptr, w, h, gamut, cp, ls, cs, PIX_FMT_YUV420)
+
+
+def p010_image(ptr, w, h, gamut, luma_stride=None, chroma_stride=None, chroma_ptr=None):
+    ls = w if luma_stride is None else luma_stride
+    cs = ls if chroma_stride is None else chroma_stride
+    cp = ptr + ls * h * 2 if chroma_ptr is None else chroma_ptr
+    return Image(ptr, w, h, gamut, cp, ls, cs, PIX_FMT_P010)
+
+
+def mono_image(ptr, w, h):
+    return Image(ptr, w, h, CG_UNSPECIFIED, None, w, 0, PIX_FMT_MONOCHROME)
+
+
+def out_image(ptr):
+    return Image(ptr, 0, 0, CG_UNSPECIFIED, None, 0, 0, -1)
+
+
+def output_bytes(fmt, w, h):
+    return {OUTPUT_HDR_LINEAR: 8, OUTPUT_HDR_PQ: 4, OUTPUT_HDR_HLG: 4,
+            OUTPUT_HDR_LINEAR_RGB_10BIT: 6}.get(fmt, 0) * w * h
+
+
+def image_array(images):
+    arr = (Image * len(images))()
+    for i, im in enumerate(images):
+        arr[i] = im
+    return arr
+
+
+def metadata(max_boost, min_boost=1.0, version=b"1.0"):
+    return Metadata(version, float(max_boost), float(min_boost), 1.0, 0.0, 0.0, float(min_boost), float(max_boost))

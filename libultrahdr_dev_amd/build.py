@@ -1,0 +1,59 @@
+"""Build the gfx950 shared library (libuhdr_hip.so) in-tree with hipcc.
+
+    python -m libultrahdr_dev_amd.build            # build if stale
+    python -m libultrahdr_dev_amd.build --force
+
+hipcc cross-compiles for gfx950 without a GPU present.  -ffp-contract=off is a parity requirement
+(the reference's x86-64 build has no FMA; see csrc/uhdr_device_math.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libuhdr_hip.so")
+SHIM_LIB = os.path.join(HERE, "libultrahdr_shim.so")
+
+SOURCES = ["uhdr_kernels.hip", "uhdr_capi.hip"]
+DEPS = SOURCES + ["uhdr_kernels.h", "uhdr_device_math.h", os.path.join(ROOT, "include", "uhdr_hip.h")]
+SHIM_SOURCES = ["ultrahdr_shim.cpp"]
+SHIM_DEPS = SHIM_SOURCES + [os.path.join(ROOT, "include", "uhdr_hip.h"),
+                            os.path.join(ROOT, "include", "ultrahdr_hip", "ultrahdr.h")]
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps, base):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    for d in deps:
+        p = d if os.path.isabs(d) else os.path.join(base, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip -> libuhdr_hip.so and the C++ shim -> libultrahdr_shim.so."""
+    if force or _stale(LIB, DEPS, CSRC):
+        cmd = [HIPCC] + FLAGS + ["-shared", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    shim_src = [os.path.join(CSRC, s) for s in SHIM_SOURCES]
+    if all(os.path.exists(s) for s in shim_src) and (force or _stale(SHIM_LIB, SHIM_DEPS, CSRC)):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+               "-o", SHIM_LIB] + shim_src + ["-L" + HERE, "-luhdr_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,698 @@
+// uhdr_capi.hip -- the C-ABI of include/uhdr_hip.h: argument validation in the reference's order,
+// per-call constants, host staging, batching.  All pixel work happens in uhdr_kernels.hip on the
+// GPU; there is deliberately no CPU fallback -- without a usable device every compute entry point
+// returns UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/uhdr_hip.h"
+#include "uhdr_kernels.h"
+
+namespace {
+
+using namespace uhdr;
+
+thread_local char t_err[256] = "";
+
+void set_err(const char* where, hipError_t e) {
+  snprintf(t_err, sizeof(t_err), "%s: %s", where, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                          \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) {                    \
+      set_err(#expr, _e);                      \
+      return UHDR_HIP_UNKNOWN_ERROR;           \
+    }                                          \
+  } while (0)
+
+// ---- per-device state --------------------------------------------------------------------------
+struct DeviceState {
+  bool ready = false;
+  std::map<int, float*> idw;  // scale -> device tables (4 * scale*scale*4 floats)
+  // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
+  void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+std::mutex g_mu;                    // guards g_dev (init / table cache)
+std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
+std::map<int, DeviceState> g_dev;
+
+// gainmapmath.cpp:69-110: sqrt runs in double on a float expression, weights are float divisions
+float euclid(float x1, float x2, float y1, float y2) {
+  return (float)std::sqrt((double)(((y2 - y1) * (y2 - y1)) + (x2 - x1) * (x2 - x1)));
+}
+void fill_idw(float* w, int scale, int incR, int incB) {
+  for (int y = 0; y < scale; y++)
+    for (int x = 0; x < scale; x++) {
+      const float pos_x = ((float)x) / scale, pos_y = ((float)y) / scale;
+      const int curr_x = (int)std::floor((double)pos_x), curr_y = (int)std::floor((double)pos_y);
+      const int next_x = curr_x + incR, next_y = curr_y + incB;
+      const float d1 = euclid(pos_x, curr_x, pos_y, curr_y);
+      float* o = w + y * scale * 4 + x * 4;
+      if (d1 == 0) {
+        o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+      } else {
+        const float w1 = 1.f / d1;
+        const float w2 = 1.f / euclid(pos_x, curr_x, pos_y, next_y);
+        const float w3 = 1.f / euclid(pos_x, next_x, pos_y, curr_y);
+        const float w4 = 1.f / euclid(pos_x, next_x, pos_y, next_y);
+        const float total = w1 + w2 + w3 + w4;
+        o[0] = w1 / total; o[1] = w2 / total; o[2] = w3 / total; o[3] = w4 / total;
+      }
+    }
+}
+// table order: std (1,1), no-right (0,1), no-bottom (1,0), corner (0,0)  gainmapmath.h:191-194
+void build_idw_tables(int scale, std::vector<float>& out) {
+  const size_t n = (size_t)scale * scale * 4;
+  out.assign(4 * n, 0.f);
+  fill_idw(out.data(), scale, 1, 1);
+  fill_idw(out.data() + n, scale, 0, 1);
+  fill_idw(out.data() + 2 * n, scale, 1, 0);
+  fill_idw(out.data() + 3 * n, scale, 0, 0);
+}
+
+int current_state(DeviceState** st) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_dev.find(dev);
+  if (it == g_dev.end() || !it->second.ready) {
+    snprintf(t_err, sizeof(t_err), "uhdr_hip_init(%d) has not been called", dev);
+    return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  }
+  *st = &it->second;
+  return UHDR_HIP_NO_ERROR;
+}
+
+int idw_for_scale(DeviceState* st, int scale, const float** dptr) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = st->idw.find(scale);
+  if (it == st->idw.end()) {
+    std::vector<float> t;
+    build_idw_tables(scale, t);
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(&d, t.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    it = st->idw.emplace(scale, d).first;
+  }
+  *dptr = it->second;
+  return UHDR_HIP_NO_ERROR;
+}
+
+// ---- colour constants (gainmapmath.cpp:121-248, 359-393, 447-481) ------------------------------
+struct YuvRgb { float cr, gcb, gcr, cb; };
+YuvRgb yuv_rgb_coeffs(int gamut) {
+  // G coefficients are float (B*Cb)/G and (R*Cr)/G exactly as the reference's static initialisers
+  switch (gamut) {
+    case UHDR_HIP_CG_BT709: {
+      const float R = 0.2126f, G = 0.7152f, B = 0.0722f, Cb = 1.8556f, Cr = 1.5748f;
+      return {Cr, B * Cb / G, R * Cr / G, Cb};
+    }
+    case UHDR_HIP_CG_P3: {
+      const float R = 0.299f, G = 0.587f, B = 0.114f, Cb = 1.772f, Cr = 1.402f;
+      return {Cr, B * Cb / G, R * Cr / G, Cb};
+    }
+    default: {
+      const float R = 0.2627f, G = 0.6780f, B = 0.0593f, Cb = 1.8814f, Cr = 1.4746f;
+      return {Cr, B * Cb / G, R * Cr / G, Cb};
+    }
+  }
+}
+void luminance_coeffs(int gamut, float* o) {
+  switch (gamut) {
+    case UHDR_HIP_CG_BT709: o[0] = 0.2126f; o[1] = 0.7152f; o[2] = 0.0722f; break;
+    case UHDR_HIP_CG_P3: o[0] = 0.20949f; o[1] = 0.72160f; o[2] = 0.06891f; break;
+    default: o[0] = 0.2627f; o[1] = 0.6780f; o[2] = 0.0593f; break;
+  }
+}
+const float kBt709ToP3[9] = {0.82254f, 0.17755f, 0.00006f, 0.03312f, 0.96684f, -0.00001f, 0.01706f, 0.07240f, 0.91049f};
+const float kBt709ToBt2100[9] = {0.62740f, 0.32930f, 0.04332f, 0.06904f, 0.91958f, 0.01138f, 0.01636f, 0.08799f, 0.89555f};
+const float kP3ToBt709[9] = {1.22482f, -0.22490f, -0.00007f, -0.04196f, 1.04199f, 0.00001f, -0.01961f, -0.07865f, 1.09831f};
+const float kP3ToBt2100[9] = {0.75378f, 0.19862f, 0.04754f, 0.04576f, 0.94177f, 0.01250f, -0.00121f, 0.01757f, 0.98359f};
+const float kBt2100ToBt709[9] = {1.66045f, -0.58764f, -0.07286f, -0.12445f, 1.13282f, -0.00837f, -0.01811f, -0.10057f, 1.11878f};
+const float kBt2100ToP3[9] = {1.34369f, -0.28223f, -0.06135f, -0.06533f, 1.07580f, -0.01051f, 0.00283f, -0.01957f, 1.01679f};
+// getHdrConversionFn(sdr_gamut, hdr_gamut): nullptr <=> identity
+const float* hdr_conversion(int sdr, int hdr) {
+  if (sdr == hdr) return nullptr;
+  switch (sdr) {
+    case UHDR_HIP_CG_BT709: return hdr == UHDR_HIP_CG_P3 ? kP3ToBt709 : kBt2100ToBt709;
+    case UHDR_HIP_CG_P3: return hdr == UHDR_HIP_CG_BT709 ? kBt709ToP3 : kBt2100ToP3;
+    default: return hdr == UHDR_HIP_CG_BT709 ? kBt709ToBt2100 : kP3ToBt2100;
+  }
+}
+const float kYuv709To601[9] = {1.0f, 0.101579f, 0.196076f, 0.0f, 0.989854f, -0.110653f, 0.0f, -0.072453f, 0.983398f};
+const float kYuv709To2100[9] = {1.0f, -0.016969f, 0.096312f, 0.0f, 0.995306f, -0.051192f, 0.0f, 0.011507f, 1.002637f};
+const float kYuv601To709[9] = {1.0f, -0.118188f, -0.212685f, 0.0f, 1.018640f, 0.114618f, 0.0f, 0.075049f, 1.025327f};
+const float kYuv601To2100[9] = {1.0f, -0.128245f, -0.115879f, 0.0f, 1.010016f, 0.061592f, 0.0f, 0.086969f, 1.029350f};
+const float kYuv2100To709[9] = {1.0f, 0.018149f, -0.095132f, 0.0f, 1.004123f, 0.051267f, 0.0f, -0.011524f, 0.996782f};
+const float kYuv2100To601[9] = {1.0f, 0.117887f, 0.105521f, 0.0f, 0.995211f, -0.059549f, 0.0f, -0.084085f, 0.976518f};
+
+bool valid_gamut(int g) { return g >= UHDR_HIP_CG_BT709 && g <= UHDR_HIP_CG_BT2100; }
+bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ---- generate ------------------------------------------------------------------------------------
+struct GenPlan {
+  GenConsts c;
+  int hdr_tf;
+};
+
+// checks of ultrahdr.cpp:189-202 + the switch defaults of :222-302, in the reference's order
+int validate_generate(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* p010, int hdr_tf,
+                      const uhdr_hip_metadata_t* md, const uhdr_hip_image_t* dest) {
+  if (yuv == nullptr || p010 == nullptr || md == nullptr || dest == nullptr || yuv->data == nullptr ||
+      yuv->chroma_data == nullptr || p010->data == nullptr || p010->chroma_data == nullptr)
+    return UHDR_HIP_ERROR_BAD_PTR;
+  if (yuv->width != p010->width || yuv->height != p010->height) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;
+  if (yuv->colorGamut == UHDR_HIP_CG_UNSPECIFIED || p010->colorGamut == UHDR_HIP_CG_UNSPECIFIED)
+    return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  if (hdr_tf != UHDR_HIP_TF_LINEAR && hdr_tf != UHDR_HIP_TF_HLG && hdr_tf != UHDR_HIP_TF_PQ)
+    return UHDR_HIP_ERROR_INVALID_TRANS_FUNC;
+  if (!valid_gamut(yuv->colorGamut) || !valid_gamut(p010->colorGamut)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  return UHDR_HIP_NO_ERROR;
+}
+
+void fill_generate_metadata(int hdr_tf, uhdr_hip_metadata_t* md) {  // ultrahdr.cpp:250-257
+  const float white = hdr_tf == UHDR_HIP_TF_PQ ? 10000.0f : 1000.0f;
+  memset(md->version, 0, sizeof(md->version));
+  strcpy(md->version, "1.0");
+  md->maxContentBoost = white / 203.0f;
+  md->minContentBoost = 1.0f;
+  md->gamma = 1.0f;
+  md->offsetSdr = 0.0f;
+  md->offsetHdr = 0.0f;
+  md->hdrCapacityMin = 1.0f;
+  md->hdrCapacityMax = md->maxContentBoost;
+}
+
+void fill_generate_dest(const uhdr_hip_image_t* yuv, uhdr_hip_image_t* dest) {  // ultrahdr.cpp:210-216
+  dest->width = yuv->width / 4;
+  dest->height = yuv->height / 4;
+  dest->colorGamut = UHDR_HIP_CG_UNSPECIFIED;
+  dest->luma_stride = dest->width;
+  dest->chroma_data = nullptr;
+  dest->chroma_stride = 0;
+  dest->pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
+}
+
+GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_601, size_t w, size_t h,
+                          const uhdr_hip_metadata_t& md) {
+  GenConsts c;
+  const YuvRgb s = yuv_rgb_coeffs(sdr_is_601 ? UHDR_HIP_CG_P3 : sdr_gamut);  // ultrahdr.cpp:267-286
+  const YuvRgb hh = yuv_rgb_coeffs(hdr_gamut);                               // :288-302
+  c.sdr_cr = s.cr; c.sdr_gcb = s.gcb; c.sdr_gcr = s.gcr; c.sdr_cb = s.cb;
+  c.hdr_cr = hh.cr; c.hdr_gcb = hh.gcb; c.hdr_gcr = hh.gcr; c.hdr_cb = hh.cb;
+  float l[3];
+  luminance_coeffs(sdr_gamut, l);  // the SDR gamut's luminance is used for BOTH images (:324,330)
+  c.lum_r = l[0]; c.lum_g = l[1]; c.lum_b = l[2];
+  const float* gm = hdr_conversion(sdr_gamut, hdr_gamut);
+  c.gm_identity = gm == nullptr;
+  for (int i = 0; i < 9; ++i) c.gm[i] = gm ? gm[i] : (i % 4 == 0 ? 1.0f : 0.0f);
+  c.hdr_white_nits = hdr_tf == UHDR_HIP_TF_PQ ? 10000.0f : 1000.0f;
+  c.min_boost = md.minContentBoost;
+  c.max_boost = md.maxContentBoost;
+  c.log2_min = (float)std::log2((double)md.minContentBoost);  // ultrahdr.cpp:259-260
+  c.log2_max = (float)std::log2((double)md.maxContentBoost);
+  c.width = (uint32_t)w; c.height = (uint32_t)h;
+  c.map_w = (uint32_t)(w / 4); c.map_h = (uint32_t)(h / 4);
+  return c;
+}
+
+GenImage gen_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& p010, void* map, uint32_t* keys) {
+  GenImage g;
+  g.y = static_cast<const uint8_t*>(yuv.data);
+  g.u = static_cast<const uint8_t*>(yuv.chroma_data);
+  g.v = g.u + yuv.chroma_stride * (yuv.height / 2);  // gainmapmath.cpp:568
+  g.hy = static_cast<const uint16_t*>(p010.data);
+  g.huv = static_cast<const uint16_t*>(p010.chroma_data);
+  g.map = static_cast<uint8_t*>(map);
+  g.stat_keys = keys;
+  g.y_stride = (uint32_t)yuv.luma_stride;
+  g.c_stride = (uint32_t)yuv.chroma_stride;
+  g.hy_stride = (uint32_t)(p010.luma_stride == 0 ? p010.width : p010.luma_stride);  // gainmapmath.cpp:585
+  g.huv_stride = (uint32_t)p010.chroma_stride;
+  return g;
+}
+bool gen_aligned(const GenImage& g, uint32_t w) {
+  return (w % 8u == 0) && al(g.hy, 16) && g.hy_stride % 8u == 0 && al(g.huv, 16) && g.huv_stride % 8u == 0 &&
+         al(g.y, 8) && g.y_stride % 8u == 0 && al(g.u, 4) && al(g.v, 4) && g.c_stride % 4u == 0 && al(g.map, 2);
+}
+
+// ---- apply ---------------------------------------------------------------------------------------
+// checks of ultrahdr.cpp:364-406 in order
+int validate_apply(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* map, const uhdr_hip_metadata_t* md,
+                   const uhdr_hip_image_t* dest) {
+  if (yuv == nullptr || map == nullptr || md == nullptr || dest == nullptr || yuv->data == nullptr ||
+      yuv->chroma_data == nullptr || map->data == nullptr)
+    return UHDR_HIP_ERROR_BAD_PTR;
+  if (strncmp(md->version, "1.0", sizeof(md->version)) != 0) return UHDR_HIP_ERROR_BAD_METADATA;
+  if (md->gamma != 1.0f) return UHDR_HIP_ERROR_BAD_METADATA;
+  if (md->offsetSdr != 0.0f || md->offsetHdr != 0.0f) return UHDR_HIP_ERROR_BAD_METADATA;
+  if (md->hdrCapacityMin != md->minContentBoost || md->hdrCapacityMax != md->maxContentBoost)
+    return UHDR_HIP_ERROR_BAD_METADATA;
+  if (map->width == 0 || map->height == 0) return UHDR_HIP_ERROR_UNSUPPORTED_MAP_SCALE_FACTOR;  // (ref: division by zero)
+  if (yuv->width % map->width != 0 || yuv->height % map->height != 0)
+    return UHDR_HIP_ERROR_UNSUPPORTED_MAP_SCALE_FACTOR;
+  if (yuv->width * map->height != yuv->height * map->width) return UHDR_HIP_ERROR_UNSUPPORTED_MAP_SCALE_FACTOR;
+  return UHDR_HIP_NO_ERROR;
+}
+bool apply_writes(int fmt) {
+  return fmt == UHDR_HIP_OUTPUT_HDR_LINEAR || fmt == UHDR_HIP_OUTPUT_HDR_PQ || fmt == UHDR_HIP_OUTPUT_HDR_HLG ||
+         fmt == UHDR_HIP_OUTPUT_HDR_LINEAR_RGB_10BIT;
+}
+size_t apply_bpp(int fmt) {
+  return fmt == UHDR_HIP_OUTPUT_HDR_LINEAR ? 8 : fmt == UHDR_HIP_OUTPUT_HDR_LINEAR_RGB_10BIT ? 6 : 4;
+}
+AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map, const uhdr_hip_metadata_t& md,
+                       float max_display_boost, const float* idw) {
+  AppConsts c;
+  c.width = (uint32_t)yuv.width; c.height = (uint32_t)yuv.height;
+  c.map_w = (uint32_t)map.width; c.map_h = (uint32_t)map.height;
+  c.scale = (uint32_t)(yuv.width / map.width);                                    // ultrahdr.cpp:409
+  c.display_boost = (std::min)(max_display_boost, md.maxContentBoost);            // :415
+  c.inv_display_boost = 1.0f / c.display_boost;
+  c.max_boost = md.maxContentBoost;
+  c.inv_max_boost = 1.0f / md.maxContentBoost;
+  c.log2_min_d = std::log2((double)md.minContentBoost);                           // gainmapmath.cpp:551-552
+  c.log2_max_d = std::log2((double)md.maxContentBoost);
+  c.idw = idw;
+  return c;
+}
+AppImage app_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map, void* dst) {
+  AppImage a;
+  a.y = static_cast<const uint8_t*>(yuv.data);
+  a.u = static_cast<const uint8_t*>(yuv.chroma_data);
+  a.v = a.u + yuv.chroma_stride * (yuv.height / 2);
+  a.map = static_cast<const uint8_t*>(map.data);
+  a.dst = dst;
+  a.y_stride = (uint32_t)yuv.luma_stride;
+  a.c_stride = (uint32_t)yuv.chroma_stride;
+  return a;
+}
+bool app_fast_s4(const AppConsts& c, const AppImage& a) {
+  return c.scale == 4 && c.width == 4u * c.map_w && c.height == 4u * c.map_h && al(a.y, 4) && a.y_stride % 4u == 0 &&
+         al(a.u, 2) && al(a.v, 2) && a.c_stride % 2u == 0 && al(a.dst, 16);
+}
+void fill_apply_dest(const uhdr_hip_image_t* yuv, uhdr_hip_image_t* dest) {  // ultrahdr.cpp:411-413
+  dest->width = yuv->width;
+  dest->height = yuv->height;
+  dest->colorGamut = yuv->colorGamut;
+}
+
+// ---- host staging ----------------------------------------------------------------------------------
+int stage_reserve(DeviceState* st, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  if (st->stage_bytes[slot] >= bytes) return UHDR_HIP_NO_ERROR;
+  if (st->stage[slot]) HIP_TRY(hipFree(st->stage[slot]));
+  st->stage[slot] = nullptr;
+  st->stage_bytes[slot] = 0;
+  HIP_TRY(hipMalloc(&st->stage[slot], bytes));
+  st->stage_bytes[slot] = bytes;
+  return UHDR_HIP_NO_ERROR;
+}
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// copy `rows` rows of `row_elems` elements of `esz` bytes from a strided host plane into a device
+// plane with pitch dpitch_elems.  Only bytes the reference itself would touch are read.
+int h2d_plane(void* d, size_t dpitch_elems, const void* h, size_t hstride_elems, size_t row_elems, size_t rows,
+              size_t esz, hipStream_t s) {
+  if (rows == 0 || row_elems == 0) return UHDR_HIP_NO_ERROR;
+  if (hstride_elems == 0) {  // degenerate stride: every row aliases row 0
+    for (size_t r = 0; r < rows; ++r)
+      HIP_TRY(hipMemcpyAsync(static_cast<char*>(d) + r * dpitch_elems * esz, h, row_elems * esz, hipMemcpyHostToDevice, s));
+    return UHDR_HIP_NO_ERROR;
+  }
+  HIP_TRY(hipMemcpy2DAsync(d, dpitch_elems * esz, h, hstride_elems * esz, row_elems * esz, rows, hipMemcpyHostToDevice, s));
+  return UHDR_HIP_NO_ERROR;
+}
+int d2h_plane(void* h, size_t hstride_elems, const void* d, size_t dpitch_elems, size_t row_elems, size_t rows,
+              size_t esz, hipStream_t s) {
+  if (rows == 0 || row_elems == 0) return UHDR_HIP_NO_ERROR;
+  HIP_TRY(hipMemcpy2DAsync(h, hstride_elems * esz, d, dpitch_elems * esz, row_elems * esz, rows, hipMemcpyDeviceToHost, s));
+  return UHDR_HIP_NO_ERROR;
+}
+
+// device copy of a host YUV420 image in slots [slot, slot+1]: Y then U|V (pitch = 64-aligned)
+int stage_yuv420_in(DeviceState* st, int slot, const uhdr_hip_image_t& h, uhdr_hip_image_t* d, hipStream_t s) {
+  const size_t w = h.width, hh = h.height, cw = (w + 1) / 2, ch = (hh + 1) / 2;
+  const size_t lp = round_up(w ? w : 1, 64), cp = round_up(cw ? cw : 1, 64);
+  // the V plane must sit at u + cp*(hh/2) for the kernels (gainmapmath.cpp:568)
+  int rc;
+  if ((rc = stage_reserve(st, slot, lp * (hh ? hh : 1))) != 0) return rc;
+  if ((rc = stage_reserve(st, slot + 1, cp * ((hh / 2) + ch + 1))) != 0) return rc;
+  *d = h;
+  d->data = st->stage[slot];
+  d->chroma_data = st->stage[slot + 1];
+  d->luma_stride = lp;
+  d->chroma_stride = cp;
+  if ((rc = h2d_plane(d->data, lp, h.data, h.luma_stride, w, hh, 1, s)) != 0) return rc;
+  const uint8_t* hu = static_cast<const uint8_t*>(h.chroma_data);
+  const uint8_t* hv = hu + h.chroma_stride * (hh / 2);
+  uint8_t* du = static_cast<uint8_t*>(d->chroma_data);
+  if ((rc = h2d_plane(du, cp, hu, h.chroma_stride, cw, ch, 1, s)) != 0) return rc;
+  if ((rc = h2d_plane(du + cp * (hh / 2), cp, hv, h.chroma_stride, cw, ch, 1, s)) != 0) return rc;
+  return UHDR_HIP_NO_ERROR;
+}
+int stage_p010_in(DeviceState* st, int slot, const uhdr_hip_image_t& h, uhdr_hip_image_t* d, hipStream_t s) {
+  const size_t w = h.width, hh = h.height, cw2 = ((w + 1) / 2) * 2, ch = (hh + 1) / 2;
+  const size_t lp = round_up(w ? w : 1, 64), cp = round_up(cw2 ? cw2 : 2, 64);
+  int rc;
+  if ((rc = stage_reserve(st, slot, lp * (hh ? hh : 1) * 2)) != 0) return rc;
+  if ((rc = stage_reserve(st, slot + 1, cp * (ch ? ch : 1) * 2)) != 0) return rc;
+  *d = h;
+  d->data = st->stage[slot];
+  d->chroma_data = st->stage[slot + 1];
+  d->luma_stride = lp;
+  d->chroma_stride = cp;
+  const size_t hls = h.luma_stride == 0 ? h.width : h.luma_stride;  // gainmapmath.cpp:585
+  if ((rc = h2d_plane(d->data, lp, h.data, hls, w, hh, 2, s)) != 0) return rc;
+  if ((rc = h2d_plane(d->chroma_data, cp, h.chroma_data, h.chroma_stride, cw2, ch, 2, s)) != 0) return rc;
+  return UHDR_HIP_NO_ERROR;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int uhdr_hip_abi_version(void) { return UHDR_HIP_ABI_VERSION; }
+
+int uhdr_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char* uhdr_hip_last_error(void) { return t_err; }
+
+int uhdr_hip_init(int device) {
+  if (device < 0 || device >= uhdr_hip_device_count()) {
+    snprintf(t_err, sizeof(t_err), "uhdr_hip_init: no HIP device %d (this library has no CPU path)", device);
+    return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceState& st = g_dev[device];
+  if (!st.ready) {
+    std::vector<float> t;
+    build_idw_tables(4, t);
+    HIP_TRY(upload_idw4(t.data()));
+    st.ready = true;
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (auto& kv : g_dev) {
+    if (hipSetDevice(kv.first) != hipSuccess) continue;
+    (void)hipDeviceSynchronize();
+    for (auto& t : kv.second.idw) (void)hipFree(t.second);
+    for (int i = 0; i < 8; ++i)
+      if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
+  }
+  g_dev.clear();
+  if (prev >= 0) (void)hipSetDevice(prev);
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_idw_tables(int scale, float* out) {
+  if (out == nullptr || scale <= 0) return UHDR_HIP_ERROR_BAD_PTR;
+  std::vector<float> t;
+  build_idw_tables(scale, t);
+  memcpy(out, t.data(), t.size() * sizeof(float));
+  return UHDR_HIP_NO_ERROR;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr_hip_image_t* p010s, int hdr_tf,
+                                    uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dests, int sdr_is_601,
+                                    float* content_minmax, void* stream) {
+  if (n < 0 || (n > 0 && (yuvs == nullptr || p010s == nullptr || dests == nullptr)) || metadata == nullptr)
+    return UHDR_HIP_ERROR_BAD_PTR;
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate_generate(&yuvs[i], &p010s[i], hdr_tf, metadata, &dests[i]);
+    if (rc != UHDR_HIP_NO_ERROR) return rc;
+    if (dests[i].data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;  // C-ABI: caller provides the map buffer
+  }
+  if (hdr_tf != UHDR_HIP_TF_LINEAR && hdr_tf != UHDR_HIP_TF_HLG && hdr_tf != UHDR_HIP_TF_PQ)
+    return UHDR_HIP_ERROR_INVALID_TRANS_FUNC;
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  fill_generate_metadata(hdr_tf, metadata);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(content_minmax);
+  if (keys && n > 0) HIP_TRY(launch_stats_init(keys, n, s));
+
+  int i = 0;
+  while (i < n) {
+    // chunk = up to kMaxChunk consecutive images of identical size, gamuts and alignment class
+    const uhdr_hip_image_t& y0 = yuvs[i];
+    const GenConsts c = generate_consts(y0.colorGamut, p010s[i].colorGamut, hdr_tf, sdr_is_601, y0.width, y0.height, *metadata);
+    GenBatch b;
+    int m = 0;
+    bool aligned = true;
+    while (i + m < n && m < kMaxChunk) {
+      const uhdr_hip_image_t& y = yuvs[i + m];
+      if (y.width != y0.width || y.height != y0.height || y.colorGamut != y0.colorGamut ||
+          p010s[i + m].colorGamut != p010s[i].colorGamut)
+        break;
+      b.img[m] = gen_image(y, p010s[i + m], dests[i + m].data, keys ? keys + 2 * (i + m) : nullptr);
+      const bool a = gen_aligned(b.img[m], c.width);
+      if (m == 0) aligned = a;
+      else if (a != aligned) break;
+      fill_generate_dest(&y, &dests[i + m]);
+      ++m;
+    }
+    HIP_TRY(launch_generate(c, b, m, hdr_tf, aligned, s));
+    i += m;
+  }
+  if (keys && n > 0) HIP_TRY(launch_stats_finalize(keys, n, s));
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr_hip_image_t* maps,
+                                 const uhdr_hip_metadata_t* metadata, int output_format, float max_display_boost,
+                                 uhdr_hip_image_t* dests, int apply_mode, void* stream) {
+  if (n < 0 || (n > 0 && (yuvs == nullptr || maps == nullptr || dests == nullptr)) || metadata == nullptr)
+    return UHDR_HIP_ERROR_BAD_PTR;
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate_apply(&yuvs[i], &maps[i], metadata, &dests[i]);
+    if (rc != UHDR_HIP_NO_ERROR) return rc;
+  }
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool writes = apply_writes(output_format);
+  for (int i = 0; i < n; ++i)
+    if (writes && dests[i].data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+
+  int i = 0;
+  while (i < n) {
+    const uhdr_hip_image_t& y0 = yuvs[i];
+    const uhdr_hip_image_t& m0 = maps[i];
+    const int scale = (int)(y0.width / m0.width);
+    const float* idw = nullptr;
+    if ((rc = idw_for_scale(st, scale, &idw)) != UHDR_HIP_NO_ERROR) return rc;
+    const AppConsts c = apply_consts(y0, m0, *metadata, max_display_boost, idw);
+    AppBatch b;
+    int m = 0;
+    bool fast = true;
+    while (i + m < n && m < kMaxChunk) {
+      const uhdr_hip_image_t& y = yuvs[i + m];
+      const uhdr_hip_image_t& mp = maps[i + m];
+      if (y.width != y0.width || y.height != y0.height || mp.width != m0.width || mp.height != m0.height) break;
+      b.img[m] = app_image(y, mp, dests[i + m].data);
+      const bool f = app_fast_s4(c, b.img[m]);
+      if (m == 0) fast = f;
+      else if (f != fast) break;
+      fill_apply_dest(&y, &dests[i + m]);
+      ++m;
+    }
+    if (writes) HIP_TRY(launch_apply(c, b, m, output_format, apply_mode == UHDR_HIP_APPLY_EXACT, fast, s));
+    i += m;
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int uhdr_hip_generate_gainmap(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* p010, int hdr_tf,
+                              uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dest, int sdr_is_601, int mem_space,
+                              void* stream) {
+  int rc = validate_generate(yuv, p010, hdr_tf, metadata, dest);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (dest->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (mem_space == UHDR_HIP_MEM_DEVICE)
+    return uhdr_hip_generate_gainmap_batch(1, yuv, p010, hdr_tf, metadata, dest, sdr_is_601, nullptr, stream);
+
+  DeviceState* st = nullptr;
+  if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uhdr_hip_image_t dy, dp, dm = *dest;
+  if ((rc = stage_yuv420_in(st, 0, *yuv, &dy, s)) != 0) return rc;
+  if ((rc = stage_p010_in(st, 2, *p010, &dp, s)) != 0) return rc;
+  const size_t mw = yuv->width / 4, mh = yuv->height / 4;
+  if ((rc = stage_reserve(st, 4, mw * mh)) != 0) return rc;
+  dm.data = st->stage[4];
+  rc = uhdr_hip_generate_gainmap_batch(1, &dy, &dp, hdr_tf, metadata, &dm, sdr_is_601, nullptr, stream);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (mw * mh) HIP_TRY(hipMemcpyAsync(dest->data, dm.data, mw * mh, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  fill_generate_dest(yuv, dest);
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_apply_gainmap(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* map, const uhdr_hip_metadata_t* metadata,
+                           int output_format, float max_display_boost, uhdr_hip_image_t* dest, int apply_mode,
+                           int mem_space, void* stream) {
+  int rc = validate_apply(yuv, map, metadata, dest);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (mem_space == UHDR_HIP_MEM_DEVICE)
+    return uhdr_hip_apply_gainmap_batch(1, yuv, map, metadata, output_format, max_display_boost, dest, apply_mode, stream);
+
+  const bool writes = apply_writes(output_format);
+  if (writes && dest->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  DeviceState* st = nullptr;
+  if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uhdr_hip_image_t dy, dm = *map, dd = *dest;
+  if ((rc = stage_yuv420_in(st, 0, *yuv, &dy, s)) != 0) return rc;
+  const size_t map_bytes = map->width * map->height;  // the reference reads the map with stride == width
+  if ((rc = stage_reserve(st, 4, map_bytes)) != 0) return rc;
+  HIP_TRY(hipMemcpyAsync(st->stage[4], map->data, map_bytes, hipMemcpyHostToDevice, s));
+  dm.data = st->stage[4];
+  const size_t out_bytes = writes ? yuv->width * yuv->height * apply_bpp(output_format) : 0;
+  if ((rc = stage_reserve(st, 5, out_bytes)) != 0) return rc;
+  dd.data = st->stage[5];
+  rc = uhdr_hip_apply_gainmap_batch(1, &dy, &dm, metadata, output_format, max_display_boost, &dd, apply_mode, stream);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (out_bytes) HIP_TRY(hipMemcpyAsync(dest->data, dd.data, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  fill_apply_dest(yuv, dest);
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int mem_space, void* stream) {
+  // ultrahdr.cpp:518-523
+  if (src == nullptr || dest == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (src->width != dest->width || src->height != dest->height) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;
+  if (src->data == nullptr || src->chroma_data == nullptr || dest->data == nullptr || dest->chroma_data == nullptr)
+    return UHDR_HIP_ERROR_BAD_PTR;  // (the reference would dereference them)
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  auto run = [&](const uhdr_hip_image_t& sd, const uhdr_hip_image_t& dd) -> int {
+    ToneImage t;
+    t.sy = static_cast<const uint16_t*>(sd.data);
+    t.suv = static_cast<const uint16_t*>(sd.chroma_data);
+    t.dy = static_cast<uint8_t*>(dd.data);
+    t.du = static_cast<uint8_t*>(dd.chroma_data);
+    t.dv = t.du + (dd.chroma_stride * dd.height / 2);  // ultrahdr.cpp:539
+    t.sy_stride = (uint32_t)sd.luma_stride; t.suv_stride = (uint32_t)sd.chroma_stride;
+    t.dy_stride = (uint32_t)dd.luma_stride; t.dc_stride = (uint32_t)dd.chroma_stride;
+    t.width = (uint32_t)sd.width; t.height = (uint32_t)sd.height;
+    const bool aligned = t.width % 16u == 0 && al(t.sy, 16) && t.sy_stride % 8u == 0 && al(t.suv, 16) &&
+                         t.suv_stride % 8u == 0 && al(t.dy, 8) && t.dy_stride % 8u == 0 && t.dy_stride >= t.width &&
+                         al(t.du, 8) && al(t.dv, 8) && t.dc_stride % 8u == 0 && t.dc_stride >= t.width / 2u;
+    HIP_TRY(launch_tonemap(t, aligned, s));
+    return UHDR_HIP_NO_ERROR;
+  };
+
+  if (mem_space == UHDR_HIP_MEM_DEVICE) {
+    if ((rc = run(*src, *dest)) != 0) return rc;
+    dest->colorGamut = src->colorGamut;  // ultrahdr.cpp:556
+    return UHDR_HIP_NO_ERROR;
+  }
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  uhdr_hip_image_t ds, dd = *dest;
+  if ((rc = stage_p010_in(st, 2, *src, &ds, s)) != 0) return rc;
+  const size_t h = dest->height, ls = dest->luma_stride, cs = dest->chroma_stride;
+  if ((rc = stage_reserve(st, 0, ls * h)) != 0) return rc;
+  if ((rc = stage_reserve(st, 1, cs * h + cs)) != 0) return rc;
+  dd.data = st->stage[0];
+  dd.chroma_data = st->stage[1];
+  if ((rc = run(ds, dd)) != 0) return rc;
+  // the reference writes luma_stride bytes per luma row and chroma_stride bytes per chroma row
+  if (ls * h) HIP_TRY(hipMemcpyAsync(dest->data, dd.data, ls * h, hipMemcpyDeviceToHost, s));
+  const size_t v_off = cs * h / 2;
+  if (cs * (h / 2)) {
+    HIP_TRY(hipMemcpyAsync(dest->chroma_data, dd.chroma_data, cs * (h / 2), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(dest->chroma_data) + v_off, static_cast<uint8_t*>(dd.chroma_data) + v_off,
+                           cs * (h / 2), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  dest->colorGamut = src->colorGamut;
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_encoding, int mem_space, void* stream) {
+  // jpegr.cpp:1134-1197
+  if (image == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (src_encoding == UHDR_HIP_CG_UNSPECIFIED || dest_encoding == UHDR_HIP_CG_UNSPECIFIED)
+    return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  if (!valid_gamut(src_encoding) || !valid_gamut(dest_encoding)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  if (src_encoding == dest_encoding) return UHDR_HIP_NO_ERROR;
+  if (image->data == nullptr || image->chroma_data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  const float* m = nullptr;
+  switch (src_encoding) {
+    case UHDR_HIP_CG_BT709: m = dest_encoding == UHDR_HIP_CG_P3 ? kYuv709To601 : kYuv709To2100; break;
+    case UHDR_HIP_CG_P3: m = dest_encoding == UHDR_HIP_CG_BT709 ? kYuv601To709 : kYuv601To2100; break;
+    default: m = dest_encoding == UHDR_HIP_CG_BT709 ? kYuv2100To709 : kYuv2100To601; break;
+  }
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  auto run = [&](const uhdr_hip_image_t& d) -> int {
+    CvtImage t;
+    t.y = static_cast<uint8_t*>(d.data);
+    t.u = static_cast<uint8_t*>(d.chroma_data);
+    t.v = t.u + d.chroma_stride * (d.height / 2);
+    t.y_stride = (uint32_t)d.luma_stride; t.c_stride = (uint32_t)d.chroma_stride;
+    t.width = (uint32_t)d.width; t.height = (uint32_t)d.height;
+    for (int i = 0; i < 9; ++i) t.m[i] = m[i];
+    const bool aligned = t.width % 8u == 0 && al(t.y, 8) && t.y_stride % 8u == 0 && al(t.u, 4) && al(t.v, 4) &&
+                         t.c_stride % 4u == 0;
+    HIP_TRY(launch_convert_yuv(t, aligned, s));
+    return UHDR_HIP_NO_ERROR;
+  };
+  if (mem_space == UHDR_HIP_MEM_DEVICE) return run(*image);
+
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  uhdr_hip_image_t d;
+  if ((rc = stage_yuv420_in(st, 0, *image, &d, s)) != 0) return rc;
+  if ((rc = run(d)) != 0) return rc;
+  const size_t w = image->width, h = image->height, cw = w / 2, ch = h / 2;
+  if ((rc = d2h_plane(image->data, image->luma_stride, d.data, d.luma_stride, cw * 2, ch * 2, 1, s)) != 0) return rc;
+  uint8_t* hu = static_cast<uint8_t*>(image->chroma_data);
+  const uint8_t* du = static_cast<const uint8_t*>(d.chroma_data);
+  if ((rc = d2h_plane(hu, image->chroma_stride, du, d.chroma_stride, cw, ch, 1, s)) != 0) return rc;
+  if ((rc = d2h_plane(hu + image->chroma_stride * (h / 2), image->chroma_stride, du + d.chroma_stride * (h / 2),
+                      d.chroma_stride, cw, ch, 1, s)) != 0)
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return UHDR_HIP_NO_ERROR;
+}
+
+}  // extern "C"

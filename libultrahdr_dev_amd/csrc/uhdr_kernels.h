@@ -1,0 +1,83 @@
+// uhdr_kernels.h -- internal host<->kernel interface (POD kernel arguments + launchers).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace uhdr {
+
+constexpr int kMaxChunk = 32;  // images per launch (descriptors travel in the kernarg segment)
+
+// ---- generate ----------------------------------------------------------------------------------
+struct GenConsts {
+  float sdr_cr, sdr_gcb, sdr_gcr, sdr_cb;  // SDR YUV->RGB (gamut of the SDR image, or 601)
+  float hdr_cr, hdr_gcb, hdr_gcr, hdr_cb;  // HDR YUV->RGB (gamut of the P010 image)
+  float lum_r, lum_g, lum_b;               // luminance of the SDR gamut (used for both images)
+  float gm[9];                             // HDR->SDR gamut matrix
+  int gm_identity;
+  float hdr_white_nits;
+  float min_boost, max_boost, log2_min, log2_max;
+  uint32_t width, height, map_w, map_h;
+};
+struct GenImage {
+  const uint8_t* y;
+  const uint8_t* u;
+  const uint8_t* v;
+  const uint16_t* hy;
+  const uint16_t* huv;
+  uint8_t* map;
+  uint32_t* stat_keys;  // 2 words per image (min key, max key) or nullptr
+  uint32_t y_stride, c_stride, hy_stride, huv_stride;
+};
+struct GenBatch {
+  GenImage img[kMaxChunk];
+};
+
+// ---- apply -------------------------------------------------------------------------------------
+struct AppConsts {
+  uint32_t width, height, map_w, map_h, scale;
+  float display_boost, inv_display_boost, max_boost, inv_max_boost;
+  double log2_min_d, log2_max_d;  // log2((double)minContentBoost), log2((double)maxContentBoost)
+  const float* idw;               // device: 4 tables (std, NR, NB, C) of scale*scale*4 floats
+};
+struct AppImage {
+  const uint8_t* y;
+  const uint8_t* u;
+  const uint8_t* v;
+  const uint8_t* map;
+  void* dst;
+  uint32_t y_stride, c_stride;
+};
+struct AppBatch {
+  AppImage img[kMaxChunk];
+};
+
+// ---- toneMap / convertYuv ----------------------------------------------------------------------
+struct ToneImage {
+  const uint16_t* sy;
+  const uint16_t* suv;
+  uint8_t* dy;
+  uint8_t* du;
+  uint8_t* dv;
+  uint32_t sy_stride, suv_stride, dy_stride, dc_stride;
+  uint32_t width, height;
+};
+struct CvtImage {
+  uint8_t* y;
+  uint8_t* u;
+  uint8_t* v;
+  uint32_t y_stride, c_stride, width, height;
+  float m[9];
+};
+
+// launchers (enqueue only; return hipError_t of the launch)
+hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned,
+                           hipStream_t s);
+hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s);
+hipError_t launch_stats_finalize(uint32_t* keys, int n, hipStream_t s);
+hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, bool exact,
+                        bool fast_s4, hipStream_t s);
+hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s);
+hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s);
+hipError_t upload_idw4(const float* tables /* 4*64 floats */);
+
+}  // namespace uhdr

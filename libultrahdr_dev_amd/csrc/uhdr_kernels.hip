@@ -1,0 +1,646 @@
+// uhdr_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the Ultra HDR gain-map path.
+//
+//   k_generate<TF,ALIGNED>   UltraHdr::generateGainMap hot loop   (ref lib/src/ultrahdr.cpp:308-338)
+//   k_apply_s4<FMT>          UltraHdr::applyGainMap hot loop, scale 4, FAST arithmetic (:427-496)
+//   k_apply_px<FMT,EXACT>    same loop, any integer scale / any alignment / EXACT arithmetic
+//   k_tonemap_*              UltraHdr::toneMap                    (:517-558)
+//   k_convert_yuv<ALIGNED>   JpegR::convertYuv + transformYuv420  (lib/src/jpegr.cpp:1199-1203,
+//                                                                  lib/src/gainmapmath.cpp:483-520)
+//
+// All of it is pointwise, HBM-bound byte/float work: no MFMA.  Design rules followed here:
+//   * one wave64 reads whole contiguous row segments (16 B/lane for P010, 8 B/lane for 8-bit luma),
+//     stores are 16 B/lane; no LDS round trip is needed because every input byte is consumed by
+//     exactly one lane;
+//   * every per-call variant (gamut matrices, transfer function, boosts) is a kernel argument held
+//     in SGPRs or a template parameter -- never a per-lane function pointer;
+//   * a batch of equally sized images is ONE launch (grid.y = image), descriptors in the kernarg
+//     segment, so 64 frames x 2 kernels fill all 256 CUs without per-image launch gaps;
+//   * compiled with -ffp-contract=off; float op order is the reference's.
+#include "uhdr_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include "uhdr_device_math.h"
+
+namespace uhdr {
+
+// Shepard IDW weights for map scale 4: [table][oy*16 + ox*4 + k]; tables: 0 std, 1 no-right,
+// 2 no-bottom, 3 corner (gainmapmath.h:184-228).  Filled by the host at uhdr_hip_init().
+__constant__ float c_idw4[4 * 64];
+
+hipError_t upload_idw4(const float* tables) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(c_idw4), tables, sizeof(float) * 4 * 64);
+}
+
+constexpr float k255 = 1 / 255.0f;  // gainmapmath.cpp:579
+constexpr float k876 = 1 / 876.0f;  // gainmapmath.cpp:598
+constexpr float k896 = 1 / 896.0f;  // gainmapmath.cpp:599
+
+// BT.601 YUV->RGB used by apply for every image (ultrahdr.cpp:431, gainmapmath.cpp:184-202)
+constexpr float kP3YR = 0.299f, kP3YG = 0.587f, kP3YB = 0.114f;
+constexpr float kP3Cb = 1.772f, kP3Cr = 1.402f;
+constexpr float kP3GCb = kP3YB * kP3Cb / kP3YG;
+constexpr float kP3GCr = kP3YR * kP3Cr / kP3YG;
+
+// =================================================================================================
+// generate
+// =================================================================================================
+
+template <int TF>
+__device__ __forceinline__ float hdr_inv_oetf(float e) {
+  if (TF == 1) return hlg_inv_oetf_exact(e);
+  if (TF == 2) return pq_inv_oetf_exact(e);
+  return e;  // ULTRAHDR_TF_LINEAR: identityConversion (ultrahdr.cpp:223-228)
+}
+
+// One map pixel from its 4x4 block.  hy[r][0|1]: P010 luma cols (0,1)|(2,3) packed lo/hi 16 bits;
+// huv[r][0|1]: (U,V) of chroma col 0|1 for chroma row r; y8[r]: 4 luma bytes; u8/v8[r]: 2 chroma
+// bytes in bits 0-15.  Accumulation order is samplePixels' (gainmapmath.cpp:605-615): dy outer,
+// dx inner, one running float sum per channel.
+template <int TF>
+__device__ __forceinline__ void gen_px(const GenConsts& c, const uint32_t (&hy)[4][2],
+                                       const uint32_t (&huv)[2][2], const uint32_t (&y8)[4],
+                                       const uint32_t (&u8)[2], const uint32_t (&v8)[2],
+                                       uint8_t& out, float& gain) {
+  float sy = 0.0f, su = 0.0f, sv = 0.0f;
+  float hsy = 0.0f, hsu = 0.0f, hsv = 0.0f;
+#pragma unroll
+  for (int dy = 0; dy < 4; ++dy) {
+    const int r = dy >> 1;
+    float uf[2], vf[2], huf[2], hvf[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uf[k] = (float)((int)((u8[r] >> (8 * k)) & 0xffu) - 128) * k255;   // gainmapmath.cpp:579-580
+      vf[k] = (float)((int)((v8[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      huf[k] = (float)((int)((huv[r][k] & 0xffffu) >> 6) - 64) * k896 - 0.5f;  // :598-600
+      hvf[k] = (float)((int)(huv[r][k] >> 22) - 64) * k896 - 0.5f;
+    }
+#pragma unroll
+    for (int dx = 0; dx < 4; ++dx) {
+      sy += (float)((y8[dy] >> (8 * dx)) & 0xffu) * k255;
+      su += uf[dx >> 1];
+      sv += vf[dx >> 1];
+      const uint32_t y16 = (hy[dy][dx >> 1] >> (16 * (dx & 1))) & 0xffffu;
+      hsy += (float)((int)(y16 >> 6) - 64) * k876;
+      hsu += huf[dx >> 1];
+      hsv += hvf[dx >> 1];
+    }
+  }
+  // e / float(scale*scale)
+  sy = sy / 16.0f; su = su / 16.0f; sv = sv / 16.0f;
+  hsy = hsy / 16.0f; hsu = hsu / 16.0f; hsv = hsv / 16.0f;
+
+  // SDR: YUV->RGB (gainmapmath.cpp:142-146 shape), sRGB EOTF, luminance * 203 (ultrahdr.cpp:316-324)
+  float r = clamp01(sy + c.sdr_cr * sv);
+  float g = clamp01(sy - c.sdr_gcb * su - c.sdr_gcr * sv);
+  float b = clamp01(sy + c.sdr_cb * su);
+  r = srgb_inv_oetf_exact(r);
+  g = srgb_inv_oetf_exact(g);
+  b = srgb_inv_oetf_exact(b);
+  const float sdr_nits = (c.lum_r * r + c.lum_g * g + c.lum_b * b) * 203.0f;
+
+  // HDR: YUV->RGB, inverse OETF, gamut conversion, luminance * white (ultrahdr.cpp:326-330)
+  float hr = clamp01(hsy + c.hdr_cr * hsv);
+  float hg = clamp01(hsy - c.hdr_gcb * hsu - c.hdr_gcr * hsv);
+  float hb = clamp01(hsy + c.hdr_cb * hsu);
+  hr = hdr_inv_oetf<TF>(hr);
+  hg = hdr_inv_oetf<TF>(hg);
+  hb = hdr_inv_oetf<TF>(hb);
+  if (!c.gm_identity) {
+    const float t0 = c.gm[0] * hr + c.gm[1] * hg + c.gm[2] * hb;
+    const float t1 = c.gm[3] * hr + c.gm[4] * hg + c.gm[5] * hb;
+    const float t2 = c.gm[6] * hr + c.gm[7] * hg + c.gm[8] * hb;
+    hr = t0; hg = t1; hb = t2;
+  }
+  const float hdr_nits = (c.lum_r * hr + c.lum_g * hg + c.lum_b * hb) * c.hdr_white_nits;
+
+  gain = raw_gain(sdr_nits, hdr_nits);
+  out = encode_gain(gain, c.min_boost, c.max_boost, c.log2_min, c.log2_max);
+}
+
+__device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
+__device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *p; }
+
+// wave64 butterfly min/max, then one LDS slot per wave, then (rarely) one atomic pair per block
+__device__ __forceinline__ void block_minmax_to_keys(float gmin, float gmax, uint32_t* keys) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    gmin = fminf(gmin, __shfl_xor(gmin, off, 64));
+    gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+  }
+  __shared__ float s_min[4], s_max[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_min[wave] = gmin; s_max[wave] = gmax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gmin = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+    gmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    if (gmin <= gmax) {  // block saw at least one pixel
+      // keys[0] holds ~key(min), keys[1] holds key(max); both only grow, both start at 0.
+      const uint32_t kmin = ~float_to_key(gmin), kmax = float_to_key(gmax);
+      // a stale (smaller) value read here only costs an unnecessary atomic, never a lost update
+      if (__hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kmin)
+        atomicMax(&keys[0], kmin);
+      if (__hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kmax)
+        atomicMax(&keys[1], kmax);
+    }
+  }
+}
+
+// Thread = 2 horizontally adjacent map pixels = an 8x4 pixel block of both images.
+// A wave64 therefore consumes 1 KiB contiguous per P010 row (dwordx4/lane), 512 B per 8-bit luma
+// row (dwordx2/lane) and 256 B per chroma row (dword/lane).
+template <int TF, bool ALIGNED>
+__global__ void __launch_bounds__(256) k_generate(const GenConsts c, const GenBatch b) {
+  const GenImage& im = b.img[blockIdx.y];
+  const uint32_t pairs_per_row = (c.map_w + 1u) >> 1;
+  const uint32_t total = pairs_per_row * c.map_h;
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  float gmin = __builtin_inff(), gmax = -__builtin_inff();
+
+  if (idx < total) {
+    const uint32_t my = idx / pairs_per_row;
+    const uint32_t pr = idx - my * pairs_per_row;
+    const uint32_t mx = pr * 2u;
+    const bool two = ALIGNED || (mx + 1u < c.map_w);
+
+    uint32_t hy[2][4][2], huv[2][2][2], y8[2][4], u8[2][2], v8[2][2];
+    if (ALIGNED) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint4 q = *reinterpret_cast<const uint4*>(im.hy + (size_t)(4u * my + r) * im.hy_stride + 8u * pr);
+        hy[0][r][0] = q.x; hy[0][r][1] = q.y; hy[1][r][0] = q.z; hy[1][r][1] = q.w;
+        const uint2 p = *reinterpret_cast<const uint2*>(im.y + (size_t)(4u * my + r) * im.y_stride + 8u * pr);
+        y8[0][r] = p.x; y8[1][r] = p.y;
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const uint4 q = *reinterpret_cast<const uint4*>(im.huv + (size_t)(2u * my + r) * im.huv_stride + 8u * pr);
+        huv[0][r][0] = q.x; huv[0][r][1] = q.y; huv[1][r][0] = q.z; huv[1][r][1] = q.w;
+        const uint32_t uu = *reinterpret_cast<const uint32_t*>(im.u + (size_t)(2u * my + r) * im.c_stride + 4u * pr);
+        const uint32_t vv = *reinterpret_cast<const uint32_t*>(im.v + (size_t)(2u * my + r) * im.c_stride + 4u * pr);
+        u8[0][r] = uu & 0xffffu; u8[1][r] = uu >> 16;
+        v8[0][r] = vv & 0xffffu; v8[1][r] = vv >> 16;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool on = (k == 0) || two;
+        const uint32_t x0 = 4u * (mx + k);  // first image column of this map pixel
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint16_t* hrow = im.hy + (size_t)(4u * my + r) * im.hy_stride + x0;
+          const uint8_t* yrow = im.y + (size_t)(4u * my + r) * im.y_stride + x0;
+          hy[k][r][0] = on ? (ld16(hrow) | (ld16(hrow + 1) << 16)) : 0u;
+          hy[k][r][1] = on ? (ld16(hrow + 2) | (ld16(hrow + 3) << 16)) : 0u;
+          y8[k][r] = on ? (ld8(yrow) | (ld8(yrow + 1) << 8) | (ld8(yrow + 2) << 16) | (ld8(yrow + 3) << 24)) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const uint16_t* crow = im.huv + (size_t)(2u * my + r) * im.huv_stride + x0;  // (x & ~1)
+          const uint8_t* urow = im.u + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
+          const uint8_t* vrow = im.v + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
+          huv[k][r][0] = on ? (ld16(crow) | (ld16(crow + 1) << 16)) : 0u;
+          huv[k][r][1] = on ? (ld16(crow + 2) | (ld16(crow + 3) << 16)) : 0u;
+          u8[k][r] = on ? (ld8(urow) | (ld8(urow + 1) << 8)) : 0u;
+          v8[k][r] = on ? (ld8(vrow) | (ld8(vrow + 1) << 8)) : 0u;
+        }
+      }
+    }
+
+    uint8_t o0, o1 = 0;
+    float g0, g1;
+    gen_px<TF>(c, hy[0], huv[0], y8[0], u8[0], v8[0], o0, g0);
+    gmin = g0; gmax = g0;
+    if (two) {
+      gen_px<TF>(c, hy[1], huv[1], y8[1], u8[1], v8[1], o1, g1);
+      gmin = fminf(gmin, g1); gmax = fmaxf(gmax, g1);
+    }
+    uint8_t* mp = im.map + (size_t)my * c.map_w + mx;
+    if (ALIGNED) {
+      *reinterpret_cast<uint16_t*>(mp) = (uint16_t)(o0 | ((uint32_t)o1 << 8));
+    } else {
+      mp[0] = o0;
+      if (two) mp[1] = o1;
+    }
+  }
+  if (im.stat_keys != nullptr) block_minmax_to_keys(gmin, gmax, im.stat_keys);
+}
+
+__global__ void k_stats_finalize(uint32_t* keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k0 = keys[2 * i], k1 = keys[2 * i + 1];
+  float mn = __builtin_inff(), mx = -__builtin_inff();  // image without map pixels
+  if (k1 != 0u) { mn = key_to_float(~k0); mx = key_to_float(k1); }
+  keys[2 * i] = __float_as_uint(mn);
+  keys[2 * i + 1] = __float_as_uint(mx);
+}
+
+template <int TF, bool ALIGNED>
+static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
+  const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
+  if (total == 0 || n == 0) return hipSuccess;
+  dim3 grid((total + 255u) / 256u, (unsigned)n, 1), block(256, 1, 1);
+  hipLaunchKernelGGL((k_generate<TF, ALIGNED>), grid, block, 0, s, c, b);
+  return hipGetLastError();
+}
+
+hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned,
+                           hipStream_t s) {
+  switch (hdr_tf) {
+    case 0: return aligned ? launch_generate_t<0, true>(c, b, n, s) : launch_generate_t<0, false>(c, b, n, s);
+    case 1: return aligned ? launch_generate_t<1, true>(c, b, n, s) : launch_generate_t<1, false>(c, b, n, s);
+    case 2: return aligned ? launch_generate_t<2, true>(c, b, n, s) : launch_generate_t<2, false>(c, b, n, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s) {
+  return hipMemsetAsync(keys, 0, sizeof(uint32_t) * 2 * (size_t)n, s);
+}
+hipError_t launch_stats_finalize(uint32_t* keys, int n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_stats_finalize, dim3((n + 63) / 64), dim3(64), 0, s, keys, n);
+  return hipGetLastError();
+}
+
+// =================================================================================================
+// apply
+// =================================================================================================
+
+// FMT: 1 HDR_LINEAR (F16), 2 HDR_PQ, 3 HDR_HLG, 4 HDR_LINEAR_RGB_10BIT (ultrahdr.h:56-64)
+
+// Everything of ultrahdr.cpp:431-451 after the loads, for one pixel: BT.601 YUV->RGB was folded
+// into (yf, crv, gcbu, gcrv, cbu) by the caller, `gain` is sampleMap's result.
+template <bool EXACT>
+__device__ __forceinline__ F3 recover_hdr(const AppConsts& c, float yf, float crv, float gcbu,
+                                          float gcrv, float cbu, float gain) {
+  float r = clamp01(yf + crv);
+  float g = clamp01(yf - gcbu - gcrv);
+  float b = clamp01(yf + cbu);
+  // applyGain(e, gain, metadata, displayBoost)   gainmapmath.cpp:550-555
+  const float log_boost = (float)(c.log2_min_d * (double)(1.0f - gain) + c.log2_max_d * (double)gain);
+  F3 o;
+  if (EXACT) {
+    r = srgb_inv_oetf_exact(r); g = srgb_inv_oetf_exact(g); b = srgb_inv_oetf_exact(b);
+    const float factor = (float)exp2((double)(log_boost * c.display_boost / c.max_boost));
+    o.x = (r * factor) / c.display_boost;  // ultrahdr.cpp:451
+    o.y = (g * factor) / c.display_boost;
+    o.z = (b * factor) / c.display_boost;
+  } else {
+    r = srgb_inv_oetf_fast(r); g = srgb_inv_oetf_fast(g); b = srgb_inv_oetf_fast(b);
+    const float factor = __builtin_amdgcn_exp2f((log_boost * c.display_boost) * c.inv_max_boost);
+    o.x = (r * factor) * c.inv_display_boost;
+    o.y = (g * factor) * c.inv_display_boost;
+    o.z = (b * factor) * c.inv_display_boost;
+  }
+  return o;
+}
+
+template <int FMT, bool EXACT>
+__device__ __forceinline__ F3 hdr_oetf(F3 e) {
+  if (FMT == 3) {
+    if (EXACT) { e.x = hlg_oetf_exact(e.x); e.y = hlg_oetf_exact(e.y); e.z = hlg_oetf_exact(e.z); }
+    else { e.x = hlg_oetf_fast(e.x); e.y = hlg_oetf_fast(e.y); e.z = hlg_oetf_fast(e.z); }
+  } else if (FMT == 2) {
+    if (EXACT) { e.x = pq_oetf_exact(e.x); e.y = pq_oetf_exact(e.y); e.z = pq_oetf_exact(e.z); }
+    else { e.x = pq_oetf_fast(e.x); e.y = pq_oetf_fast(e.y); e.z = pq_oetf_fast(e.z); }
+  }
+  return e;
+}
+
+__device__ __forceinline__ float map_to_float(uint32_t v) { return (float)v / 255.0f; }  // gainmapmath.cpp:632
+
+// FAST path, scale factor 4: thread = one gain-map cell = a 4x4 pixel block.  The four map taps
+// and the four 2x2 chroma samples are loaded once and shared by the 16 pixels; each output row of
+// the block leaves as one 16 B (1010102) / 2x16 B (F16) / 3x8 B (planar 10 bit) store per lane, so
+// a wave64 writes 1 KiB contiguous per row.
+template <int FMT>
+__global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBatch b) {
+  const AppImage& im = b.img[blockIdx.y];
+  const uint32_t total = c.map_w * c.map_h;
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total) return;
+  const uint32_t cy = idx / c.map_w;
+  const uint32_t cx = idx - cy * c.map_w;
+
+  uint32_t yrow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    yrow[r] = *reinterpret_cast<const uint32_t*>(im.y + (size_t)(4u * cy + r) * im.y_stride + 4u * cx);
+  uint32_t uu[2], vv[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    uu[r] = *reinterpret_cast<const uint16_t*>(im.u + (size_t)(2u * cy + r) * im.c_stride + 2u * cx);
+    vv[r] = *reinterpret_cast<const uint16_t*>(im.v + (size_t)(2u * cy + r) * im.c_stride + 2u * cx);
+  }
+  // sampleMap taps (gainmapmath.cpp:690-703): the reference indexes the map with map->width
+  const uint32_t xu = min(cx + 1u, c.map_w - 1u), yu = min(cy + 1u, c.map_h - 1u);
+  const float e1 = map_to_float(im.map[(size_t)cy * c.map_w + cx]);
+  const float e2 = map_to_float(im.map[(size_t)yu * c.map_w + cx]);
+  const float e3 = map_to_float(im.map[(size_t)cy * c.map_w + xu]);
+  const float e4 = map_to_float(im.map[(size_t)yu * c.map_w + xu]);
+  // weight table choice (gainmapmath.cpp:710-716)
+  const bool edge_x = (xu == cx), edge_y = (yu == cy);
+  const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
+  // interior waves (all but the last column/row of cells) read the weights with scalar loads
+  const bool wave_interior = (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull);
+  const float* wt_lane = c_idw4 + tbl * 64;
+
+  // chroma terms of p3YuvToRgb, one set per 2x2 block
+  float crv[2][2], gcbu[2][2], gcrv[2][2], cbu[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float u = (float)((int)((uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      const float v = (float)((int)((vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      crv[r][k] = kP3Cr * v; gcbu[r][k] = kP3GCb * u; gcrv[r][k] = kP3GCr * v; cbu[r][k] = kP3Cb * u;
+    }
+
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy) {
+    F3 px[4];
+#pragma unroll
+    for (int ox = 0; ox < 4; ++ox) {
+      float w0, w1, w2, w3;
+      if (wave_interior) {
+        w0 = c_idw4[oy * 16 + ox * 4 + 0]; w1 = c_idw4[oy * 16 + ox * 4 + 1];
+        w2 = c_idw4[oy * 16 + ox * 4 + 2]; w3 = c_idw4[oy * 16 + ox * 4 + 3];
+      } else {
+        w0 = wt_lane[oy * 16 + ox * 4 + 0]; w1 = wt_lane[oy * 16 + ox * 4 + 1];
+        w2 = wt_lane[oy * 16 + ox * 4 + 2]; w3 = wt_lane[oy * 16 + ox * 4 + 3];
+      }
+      const float gain = e1 * w0 + e2 * w1 + e3 * w2 + e4 * w3;  // gainmapmath.cpp:719
+      const float yf = (float)((yrow[oy] >> (8 * ox)) & 0xffu) * k255;
+      const int r = oy >> 1, k = ox >> 1;
+      px[ox] = hdr_oetf<FMT, false>(recover_hdr<false>(c, yf, crv[r][k], gcbu[r][k], gcrv[r][k], cbu[r][k], gain));
+    }
+    const size_t pix0 = (size_t)(4u * cy + oy) * c.width + 4u * cx;
+    if (FMT == 2 || FMT == 3) {
+      uint4 o;
+      o.x = pack_1010102(px[0].x, px[0].y, px[0].z); o.y = pack_1010102(px[1].x, px[1].y, px[1].z);
+      o.z = pack_1010102(px[2].x, px[2].y, px[2].z); o.w = pack_1010102(px[3].x, px[3].y, px[3].z);
+      *reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0) = o;
+    } else if (FMT == 1) {
+      const uint2 a = pack_f16(px[0].x, px[0].y, px[0].z), bb = pack_f16(px[1].x, px[1].y, px[1].z);
+      const uint2 cc = pack_f16(px[2].x, px[2].y, px[2].z), d = pack_f16(px[3].x, px[3].y, px[3].z);
+      uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+      o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+      o[1] = make_uint4(cc.x, cc.y, d.x, d.y);
+    } else {  // FMT == 4: planar R,G,B uint16 (ultrahdr.cpp:460-468)
+      const size_t plane = (size_t)c.width * c.height;
+      uint16_t* base = static_cast<uint16_t*>(im.dst);
+      uint32_t q[3][4];
+#pragma unroll
+      for (int ox = 0; ox < 4; ++ox) {
+        q[0][ox] = 0x3ffu & (uint32_t)(px[ox].x * 1023.0f);
+        q[1][ox] = 0x3ffu & (uint32_t)(px[ox].y * 1023.0f);
+        q[2][ox] = 0x3ffu & (uint32_t)(px[ox].z * 1023.0f);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        *reinterpret_cast<uint2*>(base + p * plane + pix0) =
+            make_uint2(q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16));
+    }
+  }
+}
+
+// General path: one thread per pixel; any integer scale, any pointer/stride alignment, FAST or
+// EXACT arithmetic.  Mirrors ultrahdr.cpp:427-496 + gainmapmath.cpp:686-720 literally.
+template <int FMT, bool EXACT>
+__global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBatch b) {
+  const AppImage& im = b.img[blockIdx.y];
+  const size_t total = (size_t)c.width * c.height;
+  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total) return;
+  const uint32_t y = (uint32_t)(idx / c.width);
+  const uint32_t x = (uint32_t)(idx - (size_t)y * c.width);
+
+  const float yf = (float)im.y[(size_t)y * im.y_stride + x] * k255;
+  const size_t ci = (size_t)(y >> 1) * im.c_stride + (x >> 1);
+  const float u = (float)((int)im.u[ci] - 128) * k255;
+  const float v = (float)((int)im.v[ci] - 128) * k255;
+
+  const uint32_t s = c.scale;
+  uint32_t xl = x / s, yl = y / s;
+  uint32_t xu = xl + 1u, yu = yl + 1u;
+  xl = min(xl, c.map_w - 1u); xu = min(xu, c.map_w - 1u);
+  yl = min(yl, c.map_h - 1u); yu = min(yu, c.map_h - 1u);
+  const float e1 = map_to_float(im.map[(size_t)yl * c.map_w + xl]);
+  const float e2 = map_to_float(im.map[(size_t)yu * c.map_w + xl]);
+  const float e3 = map_to_float(im.map[(size_t)yl * c.map_w + xu]);
+  const float e4 = map_to_float(im.map[(size_t)yu * c.map_w + xu]);
+  const uint32_t ox = x % s, oy = y % s;
+  int tbl = 0;
+  if (xl == xu && yl == yu) tbl = 3;
+  else if (xl == xu) tbl = 1;
+  else if (yl == yu) tbl = 2;
+  const float* w = c.idw + (size_t)tbl * s * s * 4u + (size_t)oy * s * 4u + ox * 4u;
+  const float gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
+
+  const F3 lin = recover_hdr<EXACT>(c, yf, kP3Cr * v, kP3GCb * u, kP3GCr * v, kP3Cb * u, gain);
+  const F3 e = hdr_oetf<FMT, EXACT>(lin);
+  if (FMT == 2 || FMT == 3) {
+    static_cast<uint32_t*>(im.dst)[idx] = pack_1010102(e.x, e.y, e.z);
+  } else if (FMT == 1) {
+    static_cast<uint2*>(im.dst)[idx] = pack_f16(e.x, e.y, e.z);
+  } else {
+    uint16_t* base = static_cast<uint16_t*>(im.dst);
+    base[idx] = (uint16_t)(0x3ffu & (uint32_t)(e.x * 1023.0f));
+    base[total + idx] = (uint16_t)(0x3ffu & (uint32_t)(e.y * 1023.0f));
+    base[2 * total + idx] = (uint16_t)(0x3ffu & (uint32_t)(e.z * 1023.0f));
+  }
+}
+
+template <int FMT>
+static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, bool exact,
+                                 bool fast_s4, hipStream_t s) {
+  if (n == 0 || c.width == 0 || c.height == 0) return hipSuccess;
+  if (fast_s4 && !exact) {
+    const uint32_t total = c.map_w * c.map_h;
+    hipLaunchKernelGGL((k_apply_s4<FMT>), dim3((total + 255u) / 256u, n), dim3(256), 0, s, c, b);
+  } else {
+    const size_t total = (size_t)c.width * c.height;
+    const dim3 grid((unsigned)((total + 255u) / 256u), n);
+    if (exact) hipLaunchKernelGGL((k_apply_px<FMT, true>), grid, dim3(256), 0, s, c, b);
+    else hipLaunchKernelGGL((k_apply_px<FMT, false>), grid, dim3(256), 0, s, c, b);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, bool exact,
+                        bool fast_s4, hipStream_t s) {
+  switch (fmt) {
+    case 1: return launch_apply_t<1>(c, b, n, exact, fast_s4, s);
+    case 2: return launch_apply_t<2>(c, b, n, exact, fast_s4, s);
+    case 3: return launch_apply_t<3>(c, b, n, exact, fast_s4, s);
+    case 4: return launch_apply_t<4>(c, b, n, exact, fast_s4, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// =================================================================================================
+// toneMap (ultrahdr.cpp:517-558): Y8 = (Y16 >> 6 >> 2) & 0xff == bits 15..8 of the P010 word
+// =================================================================================================
+
+// luma: grid.y = row; one thread per 8 (ALIGNED) or 1 destination bytes across [0, dy_stride)
+template <bool ALIGNED>
+__global__ void __launch_bounds__(256) k_tonemap_luma(const ToneImage t) {
+  const uint32_t row = blockIdx.y;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint16_t* src = t.sy + (size_t)row * t.sy_stride;
+  uint8_t* dst = t.dy + (size_t)row * t.dy_stride;
+  if (ALIGNED) {
+    const uint32_t x = i * 8u;
+    if (x >= t.dy_stride) return;
+    uint2 o = make_uint2(0u, 0u);
+    if (x < t.width) {  // width % 8 == 0 on this path
+      const uint4 q = *reinterpret_cast<const uint4*>(src + x);
+      o.x = ((q.x >> 8) & 0xffu) | ((q.x >> 24) << 8) | (((q.y >> 8) & 0xffu) << 16) | ((q.y >> 24) << 24);
+      o.y = ((q.z >> 8) & 0xffu) | ((q.z >> 24) << 8) | (((q.w >> 8) & 0xffu) << 16) | ((q.w >> 24) << 24);
+    }
+    *reinterpret_cast<uint2*>(dst + x) = o;
+  } else {
+    if (i >= t.dy_stride && i >= t.width) return;
+    if (i < t.width) dst[i] = (uint8_t)((src[i] >> 6 >> 2) & 0xff);
+    else dst[i] = 0;  // memset(dst_y_row + width, 0, luma_stride - width)
+  }
+}
+
+// chroma: grid.y = chroma row; U and V de-interleaved, padding [width/2, dc_stride) zeroed
+template <bool ALIGNED>
+__global__ void __launch_bounds__(256) k_tonemap_chroma(const ToneImage t) {
+  const uint32_t row = blockIdx.y;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t cw = t.width / 2u;
+  const uint16_t* src = t.suv + (size_t)row * t.suv_stride;
+  uint8_t* du = t.du + (size_t)row * t.dc_stride;
+  uint8_t* dv = t.dv + (size_t)row * t.dc_stride;
+  if (ALIGNED) {
+    const uint32_t x = i * 8u;  // chroma sample index; cw % 8 == 0 on this path
+    if (x >= t.dc_stride) return;
+    uint2 ou = make_uint2(0u, 0u), ov = make_uint2(0u, 0u);
+    if (x < cw) {
+      const uint4 a = *reinterpret_cast<const uint4*>(src + 2u * x);
+      const uint4 bq = *reinterpret_cast<const uint4*>(src + 2u * x + 8u);
+      ou.x = ((a.x >> 8) & 0xffu) | (((a.y >> 8) & 0xffu) << 8) | (((a.z >> 8) & 0xffu) << 16) | (((a.w >> 8) & 0xffu) << 24);
+      ov.x = (a.x >> 24) | ((a.y >> 24) << 8) | ((a.z >> 24) << 16) | ((a.w >> 24) << 24);
+      ou.y = ((bq.x >> 8) & 0xffu) | (((bq.y >> 8) & 0xffu) << 8) | (((bq.z >> 8) & 0xffu) << 16) | (((bq.w >> 8) & 0xffu) << 24);
+      ov.y = (bq.x >> 24) | ((bq.y >> 24) << 8) | ((bq.z >> 24) << 16) | ((bq.w >> 24) << 24);
+    }
+    *reinterpret_cast<uint2*>(du + x) = ou;
+    *reinterpret_cast<uint2*>(dv + x) = ov;
+  } else {
+    if (i >= t.dc_stride && i >= cw) return;
+    if (i < cw) {
+      du[i] = (uint8_t)((src[2u * i] >> 6 >> 2) & 0xff);
+      dv[i] = (uint8_t)((src[2u * i + 1u] >> 6 >> 2) & 0xff);
+    } else {
+      du[i] = 0; dv[i] = 0;
+    }
+  }
+}
+
+hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s) {
+  if (t.width == 0 || t.height == 0) return hipSuccess;
+  const uint32_t lcols = t.dy_stride > t.width ? t.dy_stride : t.width;
+  const uint32_t cw = t.width / 2u;
+  const uint32_t ccols = t.dc_stride > cw ? t.dc_stride : cw;
+  if (aligned) {
+    hipLaunchKernelGGL((k_tonemap_luma<true>), dim3((lcols / 8u + 255u) / 256u, t.height), dim3(256), 0, s, t);
+    if (t.height / 2u)
+      hipLaunchKernelGGL((k_tonemap_chroma<true>), dim3((ccols / 8u + 255u) / 256u, t.height / 2u), dim3(256), 0, s, t);
+  } else {
+    hipLaunchKernelGGL((k_tonemap_luma<false>), dim3((lcols + 255u) / 256u, t.height), dim3(256), 0, s, t);
+    if (t.height / 2u && ccols)
+      hipLaunchKernelGGL((k_tonemap_chroma<false>), dim3((ccols + 255u) / 256u, t.height / 2u), dim3(256), 0, s, t);
+  }
+  return hipGetLastError();
+}
+
+// =================================================================================================
+// convertYuv (jpegr.cpp:1199-1203 over transformYuv420, gainmapmath.cpp:483-520), in place.
+// Every 2x2 block reads and writes only its own 4 luma + 1 U + 1 V bytes, so blocks are independent.
+// =================================================================================================
+
+struct Yuv { float y, u, v; };
+__device__ __forceinline__ Yuv yuv_mat(const float (&m)[9], float y, float u, float v) {
+  Yuv o;
+  o.y = m[0] * y + m[1] * u + m[2] * v;
+  o.u = m[3] * y + m[4] * u + m[5] * v;
+  o.v = m[6] * y + m[7] * u + m[8] * v;
+  return o;
+}
+__device__ __forceinline__ uint32_t round_u8(float x) {  // (uint8_t)CLIP3(x, 0, 255), x already + 0.5f
+  x = (x < 0.0f) ? 0.0f : (x > 255.0f) ? 255.0f : x;
+  return (uint32_t)x;
+}
+// one 2x2 block; y00..y11 luma bytes, ub/vb chroma bytes
+__device__ __forceinline__ void cvt_block(const float (&m)[9], uint32_t (&yb)[4], uint32_t& ub, uint32_t& vb) {
+  const float u = (float)((int)ub - 128) * k255, v = (float)((int)vb - 128) * k255;
+  Yuv p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = yuv_mat(m, (float)yb[i] * k255, u, v);
+  const float nu = (((p[0].u + p[1].u) + p[2].u) + p[3].u) / 4.0f;
+  const float nv = (((p[0].v + p[1].v) + p[2].v) + p[3].v) / 4.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) yb[i] = round_u8(p[i].y * 255.0f + 0.5f);
+  ub = round_u8(nu * 255.0f + 128.0f + 0.5f);
+  vb = round_u8(nv * 255.0f + 128.0f + 0.5f);
+}
+
+template <bool ALIGNED>
+__global__ void __launch_bounds__(256) k_convert_yuv(const CvtImage t) {
+  const uint32_t cyr = blockIdx.y;  // chroma row
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t cw = t.width / 2u;
+  uint8_t* y0 = t.y + (size_t)(2u * cyr) * t.y_stride;
+  uint8_t* y1 = y0 + t.y_stride;
+  uint8_t* ur = t.u + (size_t)cyr * t.c_stride;
+  uint8_t* vr = t.v + (size_t)cyr * t.c_stride;
+  if (ALIGNED) {  // 4 chroma samples = 8 luma columns per thread; cw % 4 == 0
+    const uint32_t cx = i * 4u;
+    if (cx >= cw) return;
+    uint2 a = *reinterpret_cast<const uint2*>(y0 + 2u * cx);
+    uint2 bq = *reinterpret_cast<const uint2*>(y1 + 2u * cx);
+    uint32_t uw = *reinterpret_cast<const uint32_t*>(ur + cx);
+    uint32_t vw = *reinterpret_cast<const uint32_t*>(vr + cx);
+    const uint32_t top[2] = {a.x, a.y}, bot[2] = {bq.x, bq.y};
+    uint32_t otop[2] = {0u, 0u}, obot[2] = {0u, 0u}, ou = 0u, ov = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int sh = 16 * (k & 1);
+      uint32_t yb[4] = {(top[k >> 1] >> sh) & 0xffu, (top[k >> 1] >> (sh + 8)) & 0xffu,
+                        (bot[k >> 1] >> sh) & 0xffu, (bot[k >> 1] >> (sh + 8)) & 0xffu};
+      uint32_t ub = (uw >> (8 * k)) & 0xffu, vb = (vw >> (8 * k)) & 0xffu;
+      cvt_block(t.m, yb, ub, vb);
+      otop[k >> 1] |= (yb[0] << sh) | (yb[1] << (sh + 8));
+      obot[k >> 1] |= (yb[2] << sh) | (yb[3] << (sh + 8));
+      ou |= ub << (8 * k); ov |= vb << (8 * k);
+    }
+    *reinterpret_cast<uint2*>(y0 + 2u * cx) = make_uint2(otop[0], otop[1]);
+    *reinterpret_cast<uint2*>(y1 + 2u * cx) = make_uint2(obot[0], obot[1]);
+    *reinterpret_cast<uint32_t*>(ur + cx) = ou;
+    *reinterpret_cast<uint32_t*>(vr + cx) = ov;
+  } else {
+    if (i >= cw) return;
+    uint32_t yb[4] = {y0[2u * i], y0[2u * i + 1u], y1[2u * i], y1[2u * i + 1u]};
+    uint32_t ub = ur[i], vb = vr[i];
+    cvt_block(t.m, yb, ub, vb);
+    y0[2u * i] = (uint8_t)yb[0]; y0[2u * i + 1u] = (uint8_t)yb[1];
+    y1[2u * i] = (uint8_t)yb[2]; y1[2u * i + 1u] = (uint8_t)yb[3];
+    ur[i] = (uint8_t)ub; vr[i] = (uint8_t)vb;
+  }
+}
+
+hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s) {
+  const uint32_t cw = t.width / 2u, ch = t.height / 2u;
+  if (cw == 0 || ch == 0) return hipSuccess;
+  if (aligned) hipLaunchKernelGGL((k_convert_yuv<true>), dim3((cw / 4u + 255u) / 256u, ch), dim3(256), 0, s, t);
+  else hipLaunchKernelGGL((k_convert_yuv<false>), dim3((cw + 255u) / 256u, ch), dim3(256), 0, s, t);
+  return hipGetLastError();
+}
+
+}  // namespace uhdr

@@ -1,0 +1,559 @@
+"""-m gpu parity tests: the HIP path (through the C-ABI, device pointers) against the CPU oracle on
+identical inputs, against the committed golden md5s/checksums the real reference produced
+(SURVEY.md 8(c)/(d)), and through size-independent properties at BASELINE.json's full sizes.
+
+Bars (BASELINE.json north_star / BASELINE.md section 4):
+  * gain maps, toneMap, convertYuv: bit-exact;
+  * applyGainMap EXACT mode: bit-exact;
+  * applyGainMap FAST mode: every 10-bit channel within 1 LSB, every F16 channel within 1 half-ULP.
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = 3.4028234663852886e38
+LSB_TOL = 1        # 10-bit code values
+HALF_ULP_TOL = 1   # half-precision ULPs
+
+
+def md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def smooth_frame(w, h, seed):
+    """low-frequency cosine planes in the legal P010 / 8-bit ranges (SURVEY.md 8(d) 'smooth' variant)"""
+    rng = np.random.RandomState(seed)
+
+    def plane(pw, ph, lo, hi):
+        yy, xx = np.mgrid[0:ph, 0:pw].astype(np.float64)
+        acc = np.zeros((ph, pw))
+        for _ in range(3):
+            fx, fy, p = rng.uniform(0.5, 3.0) / pw, rng.uniform(0.5, 3.0) / ph, rng.uniform(0, 6.28)
+            acc += np.cos(6.283185 * (fx * xx + fy * yy) + p)
+        return lo + (acc / 6.0 + 0.5) * (hi - lo)
+
+    p010 = np.empty(w * h * 3 // 2, np.uint16)
+    yuv = np.empty(w * h * 3 // 2, np.uint8)
+    p010[:w * h] = (plane(w, h, 64, 940).astype(np.uint16) << 6).reshape(-1)
+    uv = np.empty((h // 2, w), np.uint16)
+    uv[:, 0::2] = plane(w // 2, h // 2, 64, 960).astype(np.uint16) << 6
+    uv[:, 1::2] = plane(w // 2, h // 2, 64, 960).astype(np.uint16) << 6
+    p010[w * h:] = uv.reshape(-1)
+    yuv[:w * h] = plane(w, h, 0, 255).astype(np.uint8).reshape(-1)
+    yuv[w * h:w * h * 5 // 4] = plane(w // 2, h // 2, 0, 255).astype(np.uint8).reshape(-1)
+    yuv[w * h * 5 // 4:] = plane(w // 2, h // 2, 0, 255).astype(np.uint8).reshape(-1)
+    return p010, yuv
+
+
+def dev_pair(hip, p010, yuv, w, h, sdr_gamut, hdr_gamut):
+    from tests.gpu_util import to_dev
+    dp, dy = to_dev(p010), to_dev(yuv)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, sdr_gamut)
+    pi = hip.p010_image(dp.data_ptr(), w, h, hdr_gamut)
+    return (dp, dy), yi, pi
+
+
+# --------------------------------------------------------------------------------------------------
+# golden vectors produced by the real reference: its own 1280x720 test frames
+# --------------------------------------------------------------------------------------------------
+GOLDEN_720P = {
+    "HLG": dict(map="32e38116ea48d76872b525663d33d137", f16="237aa8455a4d5b18136f36e2c59eb8c3",
+                pq="87ffff4015d36d3fd664bc918039c00d", hlg="dfd56dc878636c93b7a92b45cf35ee53"),
+    "PQ": dict(map="83b1c43142efebcedc9d9178b7713aa6", f16="774d53f1befd175102baa1b0597a2082",
+               pq="af4217af4760fb92a1cfe7380fe8562a", hlg="4f7d2d8442c48aba6d26f0716ba24611"),
+}
+
+
+@pytest.mark.parametrize("tfname", ["HLG", "PQ"])
+def test_reference_fixture_generate_and_apply(hip, orc, fixture_720p, tfname):
+    from tests.gpu_util import gpu_generate, gpu_apply, to_dev, diff_1010102, half_ulp_diff
+    lib = hip.load()
+    p010, yuv, w, h = fixture_720p
+    tf = {"HLG": hip.TF_HLG, "PQ": hip.TF_PQ}[tfname]
+    keep, yi, pi = dev_pair(hip, p010, yuv, w, h, hip.CG_BT709, hip.CG_BT2100)
+    st, gmap, md, dest = gpu_generate(lib, yi, pi, tf)
+    assert st == 0
+    assert md5(gmap) == GOLDEN_720P[tfname]["map"], "gain map differs from the reference's bytes"
+    assert (dest.width, dest.height, dest.luma_stride, dest.pixelFormat) == (w // 4, h // 4, w // 4, hip.PIX_FMT_MONOCHROME)
+    assert md.version == b"1.0" and md.minContentBoost == 1.0 and md.hdrCapacityMax == md.maxContentBoost
+    assert abs(md.maxContentBoost - (10000.0 if tfname == "PQ" else 1000.0) / 203.0) < 1e-5
+
+    dmap = to_dev(gmap)
+    oyi = orc.yuv420_image(yuv, w, h, orc.CG_BT709)
+    omd = orc.Metadata(md.maxContentBoost, 1.0, 1.0, 0.0, 0.0, 1.0, md.maxContentBoost, 1)
+    for fmt, key in ((hip.OUTPUT_HDR_LINEAR, "f16"), (hip.OUTPUT_HDR_PQ, "pq"), (hip.OUTPUT_HDR_HLG, "hlg")):
+        # EXACT mode reproduces the reference's bytes
+        st, out, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, FLT_MAX, hip.APPLY_EXACT)
+        assert st == 0
+        assert md5(out) == GOLDEN_720P[tfname][key], "EXACT apply differs from the reference (%s)" % key
+        # FAST mode within tolerance of it
+        st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, FLT_MAX, hip.APPLY_FAST)
+        assert st == 0
+        if fmt == hip.OUTPUT_HDR_LINEAR:
+            worst, frac = half_ulp_diff(fast.view(np.uint16), out.view(np.uint16))
+            assert worst <= HALF_ULP_TOL, worst
+        else:
+            worst, frac, alpha_ok = diff_1010102(fast.view(np.uint32), out.view(np.uint32))
+            assert alpha_ok and worst <= LSB_TOL, worst
+        print("fixture %s apply->%s FAST: worst=%d, differing fraction=%.5f" % (tfname, key, worst, frac))
+
+
+def test_reference_fixture_tonemap(hip, fixture_720p):
+    from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr
+    lib = hip.load()
+    p010, _, w, h = fixture_720p
+    dp = to_dev(p010)
+    dout = dev_empty(w * h * 3 // 2, 0xAA)
+    src = hip.p010_image(dp.data_ptr(), w, h, hip.CG_BT2100)
+    dst = hip.yuv420_image(dout.data_ptr(), w, h, hip.CG_UNSPECIFIED)
+    assert lib.uhdr_hip_tonemap(C.byref(src), C.byref(dst), hip.MEM_DEVICE, stream_ptr()) == 0
+    assert md5(to_host(dout, w * h * 3 // 2)) == "f8a112ef5d54c8df357fd082b22c5397"
+    assert dst.colorGamut == hip.CG_BT2100
+
+
+# --------------------------------------------------------------------------------------------------
+# LCG synthetic frames: checksums of the real reference, incl. BASELINE full sizes
+# --------------------------------------------------------------------------------------------------
+LCG_GOLDEN = {
+    (640, 480, "HLG"): ("4baa71c620f8c58c", "8b23c9d4ef52f40f", "46e3f5bd53ca8081"),
+    (3840, 2160, "HLG"): ("f863201c194c1467", "e87c8f6a91c5e62b", "8228c9d4cdcdf93f"),
+    (3840, 2160, "PQ"): ("17d3a7b4d3b562bc", "ba0f86ac7a37a249", "7708aab03d375c7b"),
+    (7680, 4320, "PQ"): ("7daad082c8c5bc34", "8457f9951d03c044", "d14184fa8f72c71a"),
+}
+
+
+@pytest.mark.parametrize("key", sorted(LCG_GOLDEN))
+def test_lcg_frames_against_reference_checksums(hip, orc, key):
+    from tests.gpu_util import gpu_generate, gpu_apply, to_dev, diff_1010102
+    lib, olib = hip.load(), orc.load()
+    w, h, tfname = key
+    tf = {"HLG": hip.TF_HLG, "PQ": hip.TF_PQ}[tfname]
+    p010, yuv = orc.lcg_frame(w, h, 1234)
+    keep, yi, pi = dev_pair(hip, p010, yuv, w, h, hip.CG_BT709, hip.CG_BT2100)
+    st, gmap, md, _ = gpu_generate(lib, yi, pi, tf)
+    assert st == 0
+    cs = "%016x" % olib.orc_checksum_u8(gmap.ctypes.data, gmap.size)
+    assert cs == LCG_GOLDEN[key][0], "gain-map checksum differs from the reference's"
+    dmap = to_dev(gmap)
+    oyi = orc.yuv420_image(yuv, w, h, orc.CG_BT709)
+    omd = orc.Metadata(md.maxContentBoost, 1.0, 1.0, 0.0, 0.0, 1.0, md.maxContentBoost, 1)
+    for fmt, gi in ((hip.OUTPUT_HDR_HLG, 1), (hip.OUTPUT_HDR_PQ, 2)):
+        if w <= 640:  # EXACT (double) path at full size is only run on the small frame: bit-exact
+            st, out, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, FLT_MAX, hip.APPLY_EXACT)
+            assert st == 0
+            assert "%016x" % olib.orc_checksum_u32(out.ctypes.data, out.size // 4) == LCG_GOLDEN[key][gi]
+        st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, FLT_MAX, hip.APPLY_FAST)
+        assert st == 0
+        st2, ref, _ = orc.apply("orc_", oyi, gmap, omd, fmt, FLT_MAX, threads=16)
+        assert st2 == 0
+        assert "%016x" % olib.orc_checksum_u32(ref.ctypes.data, ref.size // 4) == LCG_GOLDEN[key][gi]
+        worst, frac, alpha_ok = diff_1010102(fast.view(np.uint32), ref.view(np.uint32))
+        assert alpha_ok and worst <= LSB_TOL
+        print("LCG %dx%d %s apply fmt %d FAST: worst=%d LSB, differing fraction=%.5f" % (w, h, tfname, fmt, worst, frac))
+
+
+# --------------------------------------------------------------------------------------------------
+# the whole variant space on small frames: 3 SDR gamuts x 3 HDR gamuts x {LINEAR,HLG,PQ} x sdr_is_601
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tf", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["lcg", "smooth"])
+def test_generate_all_gamut_variants(hip, orc, tf, kind):
+    from tests.gpu_util import gpu_generate
+    lib = hip.load()
+    w, h = 256, 144
+    p010, yuv = orc.lcg_frame(w, h, 77) if kind == "lcg" else smooth_frame(w, h, 5)
+    for sg in (0, 1, 2):
+        for hg in (0, 1, 2):
+            for is601 in (False, True):
+                keep, yi, pi = dev_pair(hip, p010, yuv, w, h, sg, hg)
+                st, gmap, md, _ = gpu_generate(lib, yi, pi, tf, is601)
+                st2, omap, omd = orc.generate("orc_", orc.yuv420_image(yuv, w, h, sg), orc.p010_image(p010, w, h, hg), tf, is601)
+                assert st == 0 and st2 == 0
+                assert np.array_equal(gmap, omap), (sg, hg, is601, int((gmap != omap).sum()))
+                assert md.maxContentBoost == omd.maxContentBoost
+
+
+@pytest.mark.parametrize("dims", [(8, 8), (16, 8), (70, 50), (644, 484), (1284, 724), (36, 20), (100, 4)])
+def test_generate_ragged_sizes(hip, orc, dims):
+    """map dims are floor(w/4) x floor(h/4); odd map widths and <8-column tails take the scalar path"""
+    from tests.gpu_util import gpu_generate
+    lib = hip.load()
+    w, h = dims
+    p010, yuv = orc.lcg_frame(w, h, 99)
+    keep, yi, pi = dev_pair(hip, p010, yuv, w, h, hip.CG_P3, hip.CG_BT2100)
+    st, gmap, md, _ = gpu_generate(lib, yi, pi, hip.TF_HLG)
+    st2, omap, _ = orc.generate("orc_", orc.yuv420_image(yuv, w, h, 1), orc.p010_image(p010, w, h, 2), 1)
+    assert st == 0 and st2 == 0 and gmap.shape == omap.shape
+    assert np.array_equal(gmap, omap)
+
+
+def _strided_copy(plane, w, h, stride, esz_dtype):
+    out = np.zeros(stride * h, esz_dtype)
+    out.reshape(h, stride)[:, :w] = plane.reshape(h, w)
+    return out
+
+
+@pytest.mark.parametrize("variant", ["luma_stride", "chroma_stride", "separate_chroma", "misaligned_ptr", "all"])
+def test_generate_stride_and_pointer_invariance(hip, orc, variant):
+    """mirrors the reference's stride / separate-chroma-pointer memcmp tests (jpegr_test.cpp:1485-1801)"""
+    from tests.gpu_util import gpu_generate, to_dev
+    lib = hip.load()
+    w, h = 320, 240
+    p010, yuv = orc.lcg_frame(w, h, 4242)
+    keep, yi, pi = dev_pair(hip, p010, yuv, w, h, hip.CG_BT709, hip.CG_BT2100)
+    st, base_map, _, _ = gpu_generate(lib, yi, pi, hip.TF_HLG)
+    assert st == 0
+    st2, omap, _ = orc.generate("orc_", orc.yuv420_image(yuv, w, h, 0), orc.p010_image(p010, w, h, 2), 1)
+    assert np.array_equal(base_map, omap)
+
+    ls = w + (18 if variant in ("luma_stride", "all") else 0)           # not a multiple of 8
+    ycs = w // 2 + (7 if variant in ("chroma_stride", "all") else 0)
+    pcs = w + (10 if variant in ("chroma_stride", "all") else 0)
+    off = 3 if variant in ("misaligned_ptr", "all") else 0              # odd byte offset into the allocation
+    sep = variant in ("separate_chroma", "all") or ls != w or ycs != w // 2 or pcs != w
+    yl = _strided_copy(yuv[:w * h], w, h, ls, np.uint8)
+    yu = _strided_copy(yuv[w * h:w * h * 5 // 4], w // 2, h // 2, ycs, np.uint8)
+    yv = _strided_copy(yuv[w * h * 5 // 4:], w // 2, h // 2, ycs, np.uint8)
+    pl = _strided_copy(p010[:w * h], w, h, ls, np.uint16)
+    pc = _strided_copy(p010[w * h:], w, h // 2, pcs, np.uint16)
+    if sep:
+        d_yl = to_dev(np.concatenate([np.zeros(off, np.uint8), yl]))
+        d_yc = to_dev(np.concatenate([np.zeros(off, np.uint8), yu, yv]))
+        d_pl = to_dev(np.concatenate([np.zeros(off, np.uint16), pl]))
+        d_pc = to_dev(np.concatenate([np.zeros(off, np.uint16), pc]))
+        yi2 = hip.yuv420_image(d_yl.data_ptr() + off, w, h, 0, ls, ycs, d_yc.data_ptr() + off)
+        pi2 = hip.p010_image(d_pl.data_ptr() + 2 * off, w, h, 2, ls, pcs, d_pc.data_ptr() + 2 * off)
+    else:
+        d_y = to_dev(np.concatenate([np.zeros(off, np.uint8), yuv]))
+        d_p = to_dev(np.concatenate([np.zeros(off, np.uint16), p010]))
+        yi2 = hip.yuv420_image(d_y.data_ptr() + off, w, h, 0)
+        pi2 = hip.p010_image(d_p.data_ptr() + 2 * off, w, h, 2)
+    st, gmap, _, _ = gpu_generate(lib, yi2, pi2, hip.TF_HLG)
+    assert st == 0
+    assert np.array_equal(gmap, base_map)
+
+
+# --------------------------------------------------------------------------------------------------
+# apply: formats, scale factors, display boost, edges
+# --------------------------------------------------------------------------------------------------
+def _oracle_apply(orc, yuv, w, h, gmap, maxb, fmt, boost, minb=1.0):
+    omd = orc.Metadata(float(maxb), float(minb), 1.0, 0.0, 0.0, float(minb), float(maxb), 1)
+    st, out, dest = orc.apply("orc_", orc.yuv420_image(yuv, w, h, orc.CG_BT709), gmap, omd, fmt, boost, threads=8)
+    assert st == 0
+    return out
+
+
+def _check_apply(hip, fmt, fast, ref, w, h):
+    from tests.gpu_util import diff_1010102, half_ulp_diff
+    if fmt == hip.OUTPUT_HDR_LINEAR:
+        worst, frac = half_ulp_diff(fast.view(np.uint16), ref.view(np.uint16))
+        assert worst <= HALF_ULP_TOL, worst
+    elif fmt == hip.OUTPUT_HDR_LINEAR_RGB_10BIT:
+        d = np.abs(fast.view(np.uint16).astype(np.int32) - ref.view(np.uint16).astype(np.int32))
+        # 10-bit wrap-around (0x3ff mask) can only happen when values exceed 1.0; compare modulo 1024
+        d = np.minimum(d, 1024 - d)
+        assert int(d.max()) <= LSB_TOL
+    else:
+        worst, frac, alpha_ok = diff_1010102(fast.view(np.uint32), ref.view(np.uint32))
+        assert alpha_ok and worst <= LSB_TOL, worst
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3, 4])
+@pytest.mark.parametrize("boost", [FLT_MAX, 2.0, 1.0])
+def test_apply_formats_and_display_boost(hip, orc, fmt, boost):
+    from tests.gpu_util import gpu_apply, to_dev
+    lib = hip.load()
+    w, h = 256, 128
+    _, yuv = smooth_frame(w, h, 11)
+    rng = np.random.RandomState(3)
+    gmap = rng.randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    maxb = 1000.0 / 203.0
+    dy, dmap = to_dev(yuv), to_dev(gmap)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    md = hip.metadata(np.float32(maxb))
+    ref = _oracle_apply(orc, yuv, w, h, gmap, np.float32(maxb), fmt, boost)
+    st, exact, dest = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, boost, hip.APPLY_EXACT)
+    assert st == 0 and (dest.width, dest.height, dest.colorGamut) == (w, h, hip.CG_BT709)
+    assert np.array_equal(exact, ref), "EXACT apply is not bit-exact (fmt %d): %d bytes differ" % (fmt, int((exact != ref).sum()))
+    st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, boost, hip.APPLY_FAST)
+    assert st == 0
+    _check_apply(hip, fmt, fast, ref, w, h)
+
+
+@pytest.mark.parametrize("scale", [1, 2, 3, 4, 5, 8])
+def test_apply_scale_factors(hip, orc, scale):
+    from tests.gpu_util import gpu_apply, to_dev
+    lib = hip.load()
+    mw, mh = 24, 10
+    w, h = mw * scale, mh * scale
+    if w % 2 or h % 2:
+        w, h, mw, mh = w * 2, h * 2, mw * 2, mh * 2
+    _, yuv = orc.lcg_frame(w, h, 31)
+    gmap = np.random.RandomState(scale).randint(0, 256, (mh, mw)).astype(np.uint8)
+    maxb = np.float32(10000.0 / 203.0)
+    dy, dmap = to_dev(yuv), to_dev(gmap)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    md = hip.metadata(maxb)
+    for fmt in (hip.OUTPUT_HDR_PQ, hip.OUTPUT_HDR_LINEAR):
+        ref = _oracle_apply(orc, yuv, w, h, gmap, maxb, fmt, FLT_MAX)
+        st, exact, _ = gpu_apply(lib, yi, dmap, mw, mh, md, fmt, FLT_MAX, hip.APPLY_EXACT)
+        assert st == 0 and np.array_equal(exact, ref)
+        st, fast, _ = gpu_apply(lib, yi, dmap, mw, mh, md, fmt, FLT_MAX, hip.APPLY_FAST)
+        assert st == 0
+        _check_apply(hip, fmt, fast, ref, w, h)
+
+
+def test_apply_min_boost_below_one_and_strides(hip, orc):
+    """minContentBoost != 1 exercises the log2(min)*(1-g) term; odd strides take the per-pixel kernel"""
+    from tests.gpu_util import gpu_apply, to_dev
+    lib = hip.load()
+    w, h = 64, 32
+    _, yuv = orc.lcg_frame(w, h, 8)
+    gmap = np.random.RandomState(1).randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    minb, maxb = np.float32(0.5), np.float32(6.0)
+    ref = _oracle_apply(orc, yuv, w, h, gmap, maxb, hip.OUTPUT_HDR_HLG, 4.0, minb)
+    ls, cs = w + 5, w // 2 + 3
+    yl = _strided_copy(yuv[:w * h], w, h, ls, np.uint8)
+    yu = _strided_copy(yuv[w * h:w * h * 5 // 4], w // 2, h // 2, cs, np.uint8)
+    yv = _strided_copy(yuv[w * h * 5 // 4:], w // 2, h // 2, cs, np.uint8)
+    d_l, d_c, dmap = to_dev(yl), to_dev(np.concatenate([yu, yv])), to_dev(gmap)
+    yi = hip.yuv420_image(d_l.data_ptr(), w, h, hip.CG_P3, ls, cs, d_c.data_ptr())
+    md = hip.metadata(maxb, minb)
+    st, exact, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, hip.OUTPUT_HDR_HLG, 4.0, hip.APPLY_EXACT)
+    assert st == 0 and np.array_equal(exact, ref)
+    st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, hip.OUTPUT_HDR_HLG, 4.0, hip.APPLY_FAST)
+    assert st == 0
+    _check_apply(hip, hip.OUTPUT_HDR_HLG, fast, ref, w, h)
+
+
+def test_apply_unwritten_formats_and_errors(hip):
+    from tests.gpu_util import to_dev, dev_empty, stream_ptr, to_host
+    lib = hip.load()
+    w, h = 32, 16
+    dy, dmap, dout = dev_empty(w * h * 3 // 2, 7), dev_empty(32, 9), dev_empty(w * h * 8, 0x5A)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    mi = hip.mono_image(dmap.data_ptr(), 8, 4)
+    dest = hip.out_image(dout.data_ptr())
+    md = hip.metadata(4.0)
+    call = lambda y, m, d, meta, fmt: lib.uhdr_hip_apply_gainmap(y, m, meta, fmt, 4.0, d, 0, hip.MEM_DEVICE, stream_ptr())
+    # ULTRAHDR_OUTPUT_SDR / unspecified: nothing is written, NO_ERROR (ultrahdr.cpp:491-493)
+    assert call(C.byref(yi), C.byref(mi), C.byref(dest), C.byref(md), hip.OUTPUT_SDR) == 0
+    assert (to_host(dout) == 0x5A).all() and dest.width == w
+    assert call(None, C.byref(mi), C.byref(dest), C.byref(md), 2) == hip.ERROR_BAD_PTR
+    bad = hip.metadata(4.0, version=b"1.1")
+    assert call(C.byref(yi), C.byref(mi), C.byref(dest), C.byref(bad), 2) == hip.ERROR_BAD_METADATA
+    bad = hip.metadata(4.0); bad.gamma = 2.2
+    assert call(C.byref(yi), C.byref(mi), C.byref(dest), C.byref(bad), 2) == hip.ERROR_BAD_METADATA
+    bad = hip.metadata(4.0); bad.offsetHdr = 0.1
+    assert call(C.byref(yi), C.byref(mi), C.byref(dest), C.byref(bad), 2) == hip.ERROR_BAD_METADATA
+    bad = hip.metadata(4.0); bad.hdrCapacityMax = 5.0
+    assert call(C.byref(yi), C.byref(mi), C.byref(dest), C.byref(bad), 2) == hip.ERROR_BAD_METADATA
+    m2 = hip.mono_image(dmap.data_ptr(), 7, 4)
+    assert call(C.byref(yi), C.byref(m2), C.byref(dest), C.byref(md), 2) == hip.ERROR_UNSUPPORTED_MAP_SCALE_FACTOR
+    m3 = hip.mono_image(dmap.data_ptr(), 8, 8)
+    assert call(C.byref(yi), C.byref(m3), C.byref(dest), C.byref(md), 2) == hip.ERROR_UNSUPPORTED_MAP_SCALE_FACTOR
+
+
+def test_generate_errors(hip):
+    from tests.gpu_util import dev_empty, stream_ptr
+    lib = hip.load()
+    w, h = 32, 16
+    dy, dp, dm = dev_empty(w * h * 3 // 2), dev_empty(w * h * 3), dev_empty(64)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    pi = hip.p010_image(dp.data_ptr(), w, h, hip.CG_BT2100)
+    dest = hip.out_image(dm.data_ptr())
+    md = hip.Metadata()
+    call = lambda y, p, tf, m, d: lib.uhdr_hip_generate_gainmap(y, p, tf, m, d, 0, hip.MEM_DEVICE, stream_ptr())
+    assert call(None, C.byref(pi), 1, C.byref(md), C.byref(dest)) == hip.ERROR_BAD_PTR
+    nochroma = hip.yuv420_image(dy.data_ptr(), w, h, 0); nochroma.chroma_data = None
+    assert call(C.byref(nochroma), C.byref(pi), 1, C.byref(md), C.byref(dest)) == hip.ERROR_BAD_PTR
+    p2 = hip.p010_image(dp.data_ptr(), w + 2, h, 2)
+    assert call(C.byref(yi), C.byref(p2), 1, C.byref(md), C.byref(dest)) == hip.ERROR_RESOLUTION_MISMATCH
+    y2 = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_UNSPECIFIED)
+    assert call(C.byref(y2), C.byref(pi), 1, C.byref(md), C.byref(dest)) == hip.ERROR_INVALID_COLORGAMUT
+    assert call(C.byref(yi), C.byref(pi), hip.TF_SRGB, C.byref(md), C.byref(dest)) == hip.ERROR_INVALID_TRANS_FUNC
+    assert call(C.byref(yi), C.byref(pi), -1, C.byref(md), C.byref(dest)) == hip.ERROR_INVALID_TRANS_FUNC
+
+
+# --------------------------------------------------------------------------------------------------
+# toneMap / convertYuv
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(64, 32, 64, 32, 0), (64, 32, 80, 40, 0), (70, 30, 75, 41, 1), (1280, 720, 1280, 640, 0), (48, 16, 64, 32, 0)])
+def test_tonemap_strides_and_padding(hip, orc, cfg):
+    from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr
+    lib, olib = hip.load(), orc.load()
+    w, h, dls, dcs, off = cfg
+    sls, scs = w + (6 if off else 0), w + (4 if off else 0)
+    p010, _ = orc.lcg_frame(w, h, 5)
+    pl = _strided_copy(p010[:w * h], w, h, sls, np.uint16)
+    pc = _strided_copy(p010[w * h:], w, h // 2, scs, np.uint16)
+    # oracle
+    oy = np.full(dls * h, 0xEE, np.uint8); oc = np.full(dcs * h + dcs, 0xEE, np.uint8)
+    osrc = orc.p010_image(pl, w, h, orc.CG_P3, sls, scs, pc)
+    odst = orc.yuv420_image(oy, w, h, -1, dls, dcs, oc)
+    assert olib.orc_toneMap(C.byref(osrc), C.byref(odst)) == 0
+    # gpu
+    d_pl, d_pc = to_dev(np.concatenate([np.zeros(off, np.uint16), pl])), to_dev(np.concatenate([np.zeros(off, np.uint16), pc]))
+    d_y, d_c = dev_empty(dls * h + 8, 0xEE), dev_empty(dcs * h + dcs + 8, 0xEE)
+    src = hip.p010_image(d_pl.data_ptr() + 2 * off, w, h, hip.CG_P3, sls, scs, d_pc.data_ptr() + 2 * off)
+    dst = hip.yuv420_image(d_y.data_ptr() + off, w, h, -1, dls, dcs, d_c.data_ptr() + off)
+    assert lib.uhdr_hip_tonemap(C.byref(src), C.byref(dst), hip.MEM_DEVICE, stream_ptr()) == 0
+    assert dst.colorGamut == hip.CG_P3
+    assert np.array_equal(to_host(d_y)[off:off + dls * h], oy)
+    assert np.array_equal(to_host(d_c)[off:off + dcs * h + dcs], oc)
+
+
+@pytest.mark.parametrize("pair", [(0, 1), (0, 2), (1, 0), (1, 2), (2, 0), (2, 1)])
+@pytest.mark.parametrize("layout", ["tight", "strided"])
+def test_convert_yuv_all_matrices(hip, orc, pair, layout):
+    from tests.gpu_util import to_dev, to_host, stream_ptr
+    lib, olib = hip.load(), orc.load()
+    w, h = (128, 64) if layout == "tight" else (70, 34)
+    ls, cs = (w, w // 2) if layout == "tight" else (w + 3, w // 2 + 5)
+    _, yuv = orc.lcg_frame(w, h, 13)
+    yl = _strided_copy(yuv[:w * h], w, h, ls, np.uint8)
+    yc = np.concatenate([_strided_copy(yuv[w * h:w * h * 5 // 4], w // 2, h // 2, cs, np.uint8),
+                         _strided_copy(yuv[w * h * 5 // 4:], w // 2, h // 2, cs, np.uint8)])
+    ol, oc = yl.copy(), yc.copy()
+    oimg = orc.yuv420_image(ol, w, h, pair[0], ls, cs, oc)
+    assert olib.orc_convertYuv(C.byref(oimg), pair[0], pair[1]) == 0
+    d_l, d_c = to_dev(yl), to_dev(yc)
+    img = hip.yuv420_image(d_l.data_ptr(), w, h, pair[0], ls, cs, d_c.data_ptr())
+    assert lib.uhdr_hip_convert_yuv(C.byref(img), pair[0], pair[1], hip.MEM_DEVICE, stream_ptr()) == 0
+    assert np.array_equal(to_host(d_l, ls * h), ol)
+    assert np.array_equal(to_host(d_c, 2 * cs * (h // 2)), oc)
+    # same-encoding request is a no-op; UNSPECIFIED is rejected (jpegr.cpp:1137-1147)
+    assert lib.uhdr_hip_convert_yuv(C.byref(img), 1, 1, hip.MEM_DEVICE, stream_ptr()) == 0
+    assert lib.uhdr_hip_convert_yuv(C.byref(img), -1, 1, hip.MEM_DEVICE, stream_ptr()) == hip.ERROR_INVALID_COLORGAMUT
+    assert lib.uhdr_hip_convert_yuv(None, 0, 1, hip.MEM_DEVICE, stream_ptr()) == hip.ERROR_BAD_PTR
+
+
+# --------------------------------------------------------------------------------------------------
+# batches, content min/max, host-memory entry points
+# --------------------------------------------------------------------------------------------------
+def test_batch_generate_apply_and_content_minmax(hip, orc):
+    """a ragged batch (two sizes, > one chunk of 32) in one call; min/max is an extra statistic with no
+    reference counterpart: checked against the oracle's own definition only (parity unpinned)"""
+    import torch
+    from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr, diff_1010102
+    lib = hip.load()
+    sizes = [(128, 64)] * 35 + [(72, 40)] * 3 + [(128, 64)] * 2
+    n = len(sizes)
+    keep, yis, pis, dests, maps, oref = [], [], [], [], [], []
+    for i, (w, h) in enumerate(sizes):
+        p010, yuv = orc.lcg_frame(w, h, 1000 + i) if i % 2 else smooth_frame(w, h, i)
+        dp, dy, dm = to_dev(p010), to_dev(yuv), dev_empty((w // 4) * (h // 4), 0xCD)
+        keep += [dp, dy, dm]
+        yis.append(hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709))
+        pis.append(hip.p010_image(dp.data_ptr(), w, h, hip.CG_BT2100))
+        dests.append(hip.out_image(dm.data_ptr()))
+        maps.append(dm)
+        oref.append(orc.generate("orc_", orc.yuv420_image(yuv, w, h, 0), orc.p010_image(p010, w, h, 2), 1, stats=True) + (yuv,))
+    mm = torch.full((2 * n,), -7.0, dtype=torch.float32, device="cuda")
+    md = hip.Metadata()
+    ya, pa, da = hip.image_array(yis), hip.image_array(pis), hip.image_array(dests)
+    st = lib.uhdr_hip_generate_gainmap_batch(n, ya, pa, hip.TF_HLG, C.byref(md), da, 0, C.c_void_p(mm.data_ptr()), stream_ptr())
+    assert st == 0
+    mmh = mm.cpu().numpy()
+    for i, (w, h) in enumerate(sizes):
+        st_o, omap, omd, (omin, omax), _ = oref[i]
+        assert np.array_equal(to_host(maps[i], omap.size).reshape(omap.shape), omap), i
+        assert mmh[2 * i] == np.float32(omin) and mmh[2 * i + 1] == np.float32(omax), (i, mmh[2 * i:2 * i + 2], omin, omax)
+        assert (da[i].width, da[i].height) == (w // 4, h // 4)
+    # apply over the same batch, consuming the maps just produced
+    outs, odest, mimgs = [], [], []
+    for i, (w, h) in enumerate(sizes):
+        o = dev_empty(w * h * 4, 0)
+        outs.append(o)
+        odest.append(hip.out_image(o.data_ptr()))
+        mimgs.append(hip.mono_image(maps[i].data_ptr(), w // 4, h // 4))
+    st = lib.uhdr_hip_apply_gainmap_batch(n, ya, hip.image_array(mimgs), C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX,
+                                          hip.image_array(odest), hip.APPLY_FAST, stream_ptr())
+    assert st == 0
+    for i, (w, h) in enumerate(sizes):
+        ref = _oracle_apply(orc, oref[i][4], w, h, oref[i][1], md.maxContentBoost, hip.OUTPUT_HDR_HLG, FLT_MAX)
+        worst, frac, alpha_ok = diff_1010102(to_host(outs[i], w * h * 4).view(np.uint32), ref.view(np.uint32))
+        assert alpha_ok and worst <= LSB_TOL
+
+
+def test_host_memory_entry_points(hip, orc):
+    """UHDR_HIP_MEM_HOST: the drop-in form a CPU caller (JpegR) uses -- strided host planes in, host bytes out"""
+    lib, olib = hip.load(), orc.load()
+    w, h = 200, 120
+    p010, yuv = orc.lcg_frame(w, h, 2024)
+    ls, ycs, pcs = w + 9, w // 2 + 1, w + 2
+    yl = _strided_copy(yuv[:w * h], w, h, ls, np.uint8)
+    yc = np.concatenate([_strided_copy(yuv[w * h:w * h * 5 // 4], w // 2, h // 2, ycs, np.uint8),
+                         _strided_copy(yuv[w * h * 5 // 4:], w // 2, h // 2, ycs, np.uint8)])
+    pl = _strided_copy(p010[:w * h], w, h, ls, np.uint16)
+    pc = _strided_copy(p010[w * h:], w, h // 2, pcs, np.uint16)
+    yi = hip.yuv420_image(yl.ctypes.data, w, h, hip.CG_BT709, ls, ycs, yc.ctypes.data)
+    pi = hip.p010_image(pl.ctypes.data, w, h, hip.CG_P3, ls, pcs, pc.ctypes.data)
+    gmap = np.zeros((h // 4, w // 4), np.uint8)
+    dest = hip.out_image(gmap.ctypes.data)
+    md = hip.Metadata()
+    assert lib.uhdr_hip_generate_gainmap(C.byref(yi), C.byref(pi), hip.TF_PQ, C.byref(md), C.byref(dest), 0, hip.MEM_HOST, None) == 0
+    st, omap, omd = orc.generate("orc_", orc.yuv420_image(yl, w, h, 0, ls, ycs, yc), orc.p010_image(pl, w, h, 1, ls, pcs, pc), 2)
+    assert np.array_equal(gmap, omap) and dest.width == w // 4
+    # apply (EXACT) back on the host
+    out = np.zeros(w * h, np.uint32)
+    odest = hip.out_image(out.ctypes.data)
+    mi = hip.mono_image(gmap.ctypes.data, w // 4, h // 4)
+    assert lib.uhdr_hip_apply_gainmap(C.byref(yi), C.byref(mi), C.byref(md), hip.OUTPUT_HDR_PQ, FLT_MAX, C.byref(odest),
+                                      hip.APPLY_EXACT, hip.MEM_HOST, None) == 0
+    st, ref, _ = orc.apply("orc_", orc.yuv420_image(yl, w, h, 0, ls, ycs, yc), omap, omd, orc.OUT_HDR_PQ, FLT_MAX)
+    assert np.array_equal(out.view(np.uint8), ref)
+    # toneMap on the host
+    ty = np.full(ls * h, 0x11, np.uint8); tc = np.full(ycs * h + ycs, 0x11, np.uint8)
+    oy, oc = ty.copy(), tc.copy()
+    tdst = hip.yuv420_image(ty.ctypes.data, w, h, -1, ls, ycs, tc.ctypes.data)
+    assert lib.uhdr_hip_tonemap(C.byref(pi), C.byref(tdst), hip.MEM_HOST, None) == 0
+    osrc = orc.p010_image(pl, w, h, 1, ls, pcs, pc); odst = orc.yuv420_image(oy, w, h, -1, ls, ycs, oc)
+    assert olib.orc_toneMap(C.byref(osrc), C.byref(odst)) == 0
+    assert np.array_equal(ty, oy) and np.array_equal(tc[:ycs * h], oc[:ycs * h])
+    # convertYuv in place on the host
+    cl, cc = yl.copy(), yc.copy()
+    ol2, oc2 = yl.copy(), yc.copy()
+    cimg = hip.yuv420_image(cl.ctypes.data, w, h, 0, ls, ycs, cc.ctypes.data)
+    assert lib.uhdr_hip_convert_yuv(C.byref(cimg), 0, 1, hip.MEM_HOST, None) == 0
+    oimg = orc.yuv420_image(ol2, w, h, 0, ls, ycs, oc2)
+    assert olib.orc_convertYuv(C.byref(oimg), 0, 1) == 0
+    assert np.array_equal(cl, ol2) and np.array_equal(cc, oc2)
+
+
+def test_full_size_properties_4k(hip, orc):
+    """BASELINE config sizes: properties that need no CPU oracle at full size --
+    (a) stride/offset invariance of the map, (b) a batch of identical frames yields identical maps,
+    (c) apply is idempotent across launches, (d) content min/max brackets the decoded map range."""
+    import torch
+    from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr
+    lib = hip.load()
+    w, h = 3840, 2160
+    p010, yuv = orc.lcg_frame(w, h, 1235)
+    dp, dy = to_dev(p010), to_dev(yuv)
+    n = 4
+    maps = [dev_empty((w // 4) * (h // 4), 0) for _ in range(n)]
+    yis = hip.image_array([hip.yuv420_image(dy.data_ptr(), w, h, 0)] * n)
+    pis = hip.image_array([hip.p010_image(dp.data_ptr(), w, h, 2)] * n)
+    dests = hip.image_array([hip.out_image(m.data_ptr()) for m in maps])
+    mm = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+    md = hip.Metadata()
+    assert lib.uhdr_hip_generate_gainmap_batch(n, yis, pis, hip.TF_HLG, C.byref(md), dests, 0, C.c_void_p(mm.data_ptr()), stream_ptr()) == 0
+    m0 = to_host(maps[0], (w // 4) * (h // 4)).copy()
+    for m in maps[1:]:
+        assert np.array_equal(to_host(m, m0.size), m0)
+    mmh = mm.cpu().numpy()
+    assert (mmh[0::2] == mmh[0]).all() and (mmh[1::2] == mmh[1]).all() and mmh[0] <= mmh[1]
+    outs = [dev_empty(w * h * 4, 0) for _ in range(2)]
+    for o in outs:
+        mi = hip.mono_image(maps[0].data_ptr(), w // 4, h // 4)
+        d = hip.out_image(o.data_ptr())
+        assert lib.uhdr_hip_apply_gainmap(C.byref(yis[0]), C.byref(mi), C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX, C.byref(d), 0,
+                                          hip.MEM_DEVICE, stream_ptr()) == 0
+    a, b = to_host(outs[0], w * h * 4), to_host(outs[1], w * h * 4)
+    assert np.array_equal(a, b)
+    assert ((a.view(np.uint32) >> 30) == 3).all()

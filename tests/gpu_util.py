@@ -68,6 +68,9 @@ def diff_1010102(a_u32, b_u32):
     worst, ndiff = 0, 0
     for sh in (0, 10, 20):
         d = np.abs(((a >> sh) & 0x3ff) - ((b >> sh) & 0x3ff))
+        # the reference masks with 0x3ff (gainmapmath.cpp:723-725), so a channel that lands on 1024 wraps
+        # to 0 (only reachable when max_display_boost < maxContentBoost): distance is taken modulo 1024
+        d = np.minimum(d, 1024 - d)
         worst = max(worst, int(d.max()) if d.size else 0)
         ndiff += int((d != 0).sum())
     alpha_ok = bool((((a >> 30) & 3) == ((b >> 30) & 3)).all())

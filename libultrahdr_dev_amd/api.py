@@ -67,6 +67,14 @@ def load():
             raise ImportError(
                 "libuhdr_hip.so is missing: build the HIP extension first "
                 "(python -m libultrahdr_dev_amd.build).  There is no CPU path.")
+        # In a PyTorch process the library must bind to the HIP runtime torch bundles
+        # (torch/lib/libamdhip64.so), otherwise two HIP/HSA runtimes end up in one process and the
+        # second one sees no device.  Importing torch first makes the loader resolve our
+        # libamdhip64.so.7 dependency to the copy that is already mapped.
+        try:
+            import torch  # noqa: F401  (plumbing: device memory + streams for tests/bench)
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-from libultrahdr_dev_amd import api, synth
+from libultrahdr_dev_amd import api, sharding, synth
 
 W, H = 3840, 2160
 CHUNK = 32                       # images per kernel launch (kMaxChunk in csrc/uhdr_kernels.h)
@@ -58,7 +58,7 @@ class Batch:
         self.lib, self.n = lib, frames
         self.p010, self.yuv, self.maps, self.outs = [], [], [], []
         for i in range(frames):
-            p, y = synth.lcg_frame(W, H, 1234 + rank * frames + i)   # seed = 1234 + global image index
+            p, y = synth.lcg_frame(W, H, sharding.image_seed(rank * frames + i))   # seed = 1234 + global image index
             self.p010.append(p)
             self.yuv.append(y)
             self.maps.append(torch.zeros((W // 4) * (H // 4), dtype=torch.uint8, device="cuda"))
@@ -176,10 +176,7 @@ def main():
         batch.generate(stream, ev_gen)
         if world > 1:
             # the path's only exchange: batch-wide content min / max boost (8 bytes, latency-bound)
-            mm = batch.minmax.view(-1, 2)
-            red[0] = mm[:, 0].min()
-            red[1] = -mm[:, 1].max()
-            dist.all_reduce(red, op=dist.ReduceOp.MIN)
+            sharding.reduce_content_minmax(batch.minmax, dist, red)
         batch.apply(stream, fmt, ev_app)
 
     for _ in range(a.warmup):

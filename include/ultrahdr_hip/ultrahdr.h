@@ -1,0 +1,134 @@
+/*
+ * ultrahdr_hip/ultrahdr.h -- C++ host-side mirror of the reference's hot-path interface, implemented
+ * on top of the C-ABI in include/uhdr_hip.h (MI355X kernels).
+ *
+ * The reference keeps the pixel path behind protected members of ultrahdr::UltraHdr
+ * (lib/include/ultrahdr/ultrahdr.h:333-381) and private JpegR::convertYuv
+ * (lib/include/ultrahdr/jpegr.h:329-330).  `ultrahdr::UltraHdrHip` exposes the same four operations
+ * with the same names, argument meaning, ownership rules and status_t values, so that a caller written
+ * like lib/src/jpegr.cpp (encodeJPEGR :200,:284,:421,:502; decodeJPEGR :801; :224,:360 for convertYuv)
+ * compiles against it unchanged.  Type and enumerator names/values are the reference's.
+ *
+ * Ownership (same as the reference):
+ *   generateGainMap  allocates dest->data with new uint8_t[]; the caller frees it with delete[]
+ *                    (jpegr.cpp:207-208 wraps it in unique_ptr<uint8_t[]>);
+ *   applyGainMap / toneMap / convertYuv: the caller owns every buffer.
+ * All calls are synchronous on host memory (the image is staged through HBM and back).
+ */
+#ifndef ULTRAHDR_HIP_ULTRAHDR_H
+#define ULTRAHDR_HIP_ULTRAHDR_H
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace ultrahdr {
+
+typedef enum {
+  ULTRAHDR_COLORGAMUT_UNSPECIFIED = -1,
+  ULTRAHDR_COLORGAMUT_BT709,
+  ULTRAHDR_COLORGAMUT_P3,
+  ULTRAHDR_COLORGAMUT_BT2100,
+  ULTRAHDR_COLORGAMUT_MAX = ULTRAHDR_COLORGAMUT_BT2100,
+} ultrahdr_color_gamut;
+
+typedef enum {
+  ULTRAHDR_TF_UNSPECIFIED = -1,
+  ULTRAHDR_TF_LINEAR = 0,
+  ULTRAHDR_TF_HLG = 1,
+  ULTRAHDR_TF_PQ = 2,
+  ULTRAHDR_TF_SRGB = 3,
+  ULTRAHDR_TF_MAX = ULTRAHDR_TF_SRGB,
+} ultrahdr_transfer_function;
+
+typedef enum {
+  ULTRAHDR_OUTPUT_UNSPECIFIED = -1,
+  ULTRAHDR_OUTPUT_SDR,
+  ULTRAHDR_OUTPUT_HDR_LINEAR,
+  ULTRAHDR_OUTPUT_HDR_PQ,
+  ULTRAHDR_OUTPUT_HDR_HLG,
+  ULTRAHDR_OUTPUT_HDR_LINEAR_RGB_10BIT,
+  ULTRAHDR_OUTPUT_MAX = ULTRAHDR_OUTPUT_HDR_LINEAR_RGB_10BIT,
+} ultrahdr_output_format;
+
+typedef enum {
+  ULTRAHDR_PIX_FMT_UNSPECIFIED = -1,
+  ULTRAHDR_PIX_FMT_P010,
+  ULTRAHDR_PIX_FMT_YUV420,
+  ULTRAHDR_PIX_FMT_MONOCHROME,
+  ULTRAHDR_PIX_FMT_RGBA8888,
+  ULTRAHDR_PIX_FMT_RGBAF16,
+  ULTRAHDR_PIX_FMT_RGBA1010102,
+} ultrahdr_pixel_format;
+
+// only the codes the pixel path can return are listed; values are the reference's
+typedef enum {
+  ULTRAHDR_NO_ERROR = 0,
+  ULTRAHDR_UNKNOWN_ERROR = -1,
+  ERROR_ULTRAHDR_BAD_PTR = -10001,
+  ERROR_ULTRAHDR_INVALID_COLORGAMUT = -10003,
+  ERROR_ULTRAHDR_INVALID_TRANS_FUNC = -10005,
+  ERROR_ULTRAHDR_RESOLUTION_MISMATCH = -10006,
+  ERROR_ULTRAHDR_BAD_METADATA = -10010,
+  ERROR_ULTRAHDR_UNSUPPORTED_MAP_SCALE_FACTOR = -20008,
+  ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE = -20009,
+} status_t;
+
+struct ultrahdr_metadata_struct {
+  std::string version;
+  float maxContentBoost;
+  float minContentBoost;
+  float gamma;
+  float offsetSdr;
+  float offsetHdr;
+  float hdrCapacityMin;
+  float hdrCapacityMax;
+};
+typedef struct ultrahdr_metadata_struct* ultrahdr_metadata_ptr;
+
+struct ultrahdr_uncompressed_struct {
+  void* data;
+  size_t width;
+  size_t height;
+  ultrahdr_color_gamut colorGamut;
+  void* chroma_data = nullptr;
+  size_t luma_stride = 0;
+  size_t chroma_stride = 0;
+  ultrahdr_pixel_format pixelFormat = ULTRAHDR_PIX_FMT_UNSPECIFIED;
+};
+typedef struct ultrahdr_uncompressed_struct* uhdr_uncompressed_ptr;
+
+static const char* const kGainMapVersion = "1.0";
+static const size_t kMapDimensionScaleFactor = 4;
+
+class UltraHdrHip {
+ public:
+  // device: HIP device ordinal this object runs on (uhdr_hip_init is called lazily, once)
+  explicit UltraHdrHip(int device = 0);
+
+  status_t generateGainMap(uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_uncompressed_ptr p010_image_ptr,
+                           ultrahdr_transfer_function hdr_tf, ultrahdr_metadata_ptr metadata,
+                           uhdr_uncompressed_ptr dest, bool sdr_is_601 = false);
+
+  status_t applyGainMap(uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_uncompressed_ptr gainmap_image_ptr,
+                        ultrahdr_metadata_ptr metadata, ultrahdr_output_format output_format,
+                        float max_display_boost, uhdr_uncompressed_ptr dest);
+
+  status_t toneMap(uhdr_uncompressed_ptr src, uhdr_uncompressed_ptr dest);
+
+  status_t convertYuv(uhdr_uncompressed_ptr image, ultrahdr_color_gamut src_encoding,
+                      ultrahdr_color_gamut dest_encoding);
+
+  // UHDR_HIP_APPLY_FAST (default) or UHDR_HIP_APPLY_EXACT, see include/uhdr_hip.h
+  void setApplyMode(int mode) { mApplyMode = mode; }
+
+ private:
+  status_t ensureInit();
+  int mDevice;
+  bool mReady = false;
+  int mApplyMode = 0;
+};
+
+}  // namespace ultrahdr
+
+#endif  // ULTRAHDR_HIP_ULTRAHDR_H

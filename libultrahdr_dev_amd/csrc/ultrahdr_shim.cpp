@@ -1,0 +1,154 @@
+// ultrahdr_shim.cpp -- ultrahdr::UltraHdrHip: the reference's C++ member signatures on top of the
+// C-ABI (include/uhdr_hip.h).  Pure host glue: descriptor translation + the new[] ownership contract
+// of generateGainMap (ref lib/src/ultrahdr.cpp:209,217-218,356).
+#include "ultrahdr_hip/ultrahdr.h"
+
+#include <cstring>
+#include <memory>
+
+#include "uhdr_hip.h"
+
+namespace ultrahdr {
+namespace {
+
+uhdr_hip_image_t to_c(const ultrahdr_uncompressed_struct& s) {
+  uhdr_hip_image_t c;
+  c.data = s.data;
+  c.width = s.width;
+  c.height = s.height;
+  c.colorGamut = static_cast<int32_t>(s.colorGamut);
+  c.chroma_data = s.chroma_data;
+  c.luma_stride = s.luma_stride;
+  c.chroma_stride = s.chroma_stride;
+  c.pixelFormat = static_cast<int32_t>(s.pixelFormat);
+  return c;
+}
+void from_c(const uhdr_hip_image_t& c, ultrahdr_uncompressed_struct* s) {
+  s->data = c.data;
+  s->width = c.width;
+  s->height = c.height;
+  s->colorGamut = static_cast<ultrahdr_color_gamut>(c.colorGamut);
+  s->chroma_data = c.chroma_data;
+  s->luma_stride = c.luma_stride;
+  s->chroma_stride = c.chroma_stride;
+  s->pixelFormat = static_cast<ultrahdr_pixel_format>(c.pixelFormat);
+}
+uhdr_hip_metadata_t to_c(const ultrahdr_metadata_struct& m) {
+  uhdr_hip_metadata_t c;
+  std::memset(c.version, 0, sizeof(c.version));
+  // a longer-than-7-character version can never equal "1.0"; keep it unequal after truncation
+  std::strncpy(c.version, m.version.size() < sizeof(c.version) ? m.version.c_str() : "toolong", sizeof(c.version) - 1);
+  c.maxContentBoost = m.maxContentBoost;
+  c.minContentBoost = m.minContentBoost;
+  c.gamma = m.gamma;
+  c.offsetSdr = m.offsetSdr;
+  c.offsetHdr = m.offsetHdr;
+  c.hdrCapacityMin = m.hdrCapacityMin;
+  c.hdrCapacityMax = m.hdrCapacityMax;
+  return c;
+}
+
+}  // namespace
+
+UltraHdrHip::UltraHdrHip(int device) : mDevice(device) {}
+
+status_t UltraHdrHip::ensureInit() {
+  if (!mReady) {
+    const int rc = uhdr_hip_init(mDevice);
+    if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+    mReady = true;
+  }
+  return ULTRAHDR_NO_ERROR;
+}
+
+status_t UltraHdrHip::generateGainMap(uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_uncompressed_ptr p010_image_ptr,
+                                      ultrahdr_transfer_function hdr_tf, ultrahdr_metadata_ptr metadata,
+                                      uhdr_uncompressed_ptr dest, bool sdr_is_601) {
+  // pointer checks first, exactly as ultrahdr.cpp:189-194, so a null argument never reaches the device
+  if (yuv420_image_ptr == nullptr || p010_image_ptr == nullptr || metadata == nullptr || dest == nullptr ||
+      yuv420_image_ptr->data == nullptr || yuv420_image_ptr->chroma_data == nullptr ||
+      p010_image_ptr->data == nullptr || p010_image_ptr->chroma_data == nullptr)
+    return ERROR_ULTRAHDR_BAD_PTR;
+  if (yuv420_image_ptr->width != p010_image_ptr->width || yuv420_image_ptr->height != p010_image_ptr->height)
+    return ERROR_ULTRAHDR_RESOLUTION_MISMATCH;
+  if (yuv420_image_ptr->colorGamut == ULTRAHDR_COLORGAMUT_UNSPECIFIED ||
+      p010_image_ptr->colorGamut == ULTRAHDR_COLORGAMUT_UNSPECIFIED)
+    return ERROR_ULTRAHDR_INVALID_COLORGAMUT;
+  status_t st = ensureInit();
+  if (st != ULTRAHDR_NO_ERROR) return st;
+
+  const size_t map_w = yuv420_image_ptr->width / kMapDimensionScaleFactor;
+  const size_t map_h = yuv420_image_ptr->height / kMapDimensionScaleFactor;
+  std::unique_ptr<uint8_t[]> map_data(new uint8_t[map_w * map_h > 0 ? map_w * map_h : 1]);  // :209,217-218
+
+  uhdr_hip_image_t y = to_c(*yuv420_image_ptr), p = to_c(*p010_image_ptr), d = to_c(*dest);
+  d.data = map_data.get();
+  uhdr_hip_metadata_t md;
+  std::memset(&md, 0, sizeof(md));
+  const int rc = uhdr_hip_generate_gainmap(&y, &p, static_cast<int>(hdr_tf), &md, &d, sdr_is_601 ? 1 : 0,
+                                           UHDR_HIP_MEM_HOST, nullptr);
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  metadata->version = md.version;
+  metadata->maxContentBoost = md.maxContentBoost;
+  metadata->minContentBoost = md.minContentBoost;
+  metadata->gamma = md.gamma;
+  metadata->offsetSdr = md.offsetSdr;
+  metadata->offsetHdr = md.offsetHdr;
+  metadata->hdrCapacityMin = md.hdrCapacityMin;
+  metadata->hdrCapacityMax = md.hdrCapacityMax;
+  from_c(d, dest);
+  dest->data = map_data.release();  // :356 -- ownership passes to the caller (delete[])
+  return ULTRAHDR_NO_ERROR;
+}
+
+status_t UltraHdrHip::applyGainMap(uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_uncompressed_ptr gainmap_image_ptr,
+                                   ultrahdr_metadata_ptr metadata, ultrahdr_output_format output_format,
+                                   float max_display_boost, uhdr_uncompressed_ptr dest) {
+  if (yuv420_image_ptr == nullptr || gainmap_image_ptr == nullptr || metadata == nullptr || dest == nullptr ||
+      yuv420_image_ptr->data == nullptr || yuv420_image_ptr->chroma_data == nullptr ||
+      gainmap_image_ptr->data == nullptr)
+    return ERROR_ULTRAHDR_BAD_PTR;  // ultrahdr.cpp:364-368
+  uhdr_hip_image_t y = to_c(*yuv420_image_ptr), g = to_c(*gainmap_image_ptr), d = to_c(*dest);
+  const uhdr_hip_metadata_t md = to_c(*metadata);
+  // metadata / scale checks do not need the device; let the C-ABI produce the reference's codes first
+  int rc = uhdr_hip_apply_gainmap(&y, &g, &md, static_cast<int>(output_format), max_display_boost, &d, mApplyMode,
+                                  UHDR_HIP_MEM_HOST, nullptr);
+  if (rc == UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE && !mReady) {
+    const status_t st = ensureInit();
+    if (st != ULTRAHDR_NO_ERROR) return st;
+    rc = uhdr_hip_apply_gainmap(&y, &g, &md, static_cast<int>(output_format), max_display_boost, &d, mApplyMode,
+                                UHDR_HIP_MEM_HOST, nullptr);
+  }
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  dest->width = d.width;            // :411-413
+  dest->height = d.height;
+  dest->colorGamut = static_cast<ultrahdr_color_gamut>(d.colorGamut);
+  return ULTRAHDR_NO_ERROR;
+}
+
+status_t UltraHdrHip::toneMap(uhdr_uncompressed_ptr src, uhdr_uncompressed_ptr dest) {
+  if (src == nullptr || dest == nullptr) return ERROR_ULTRAHDR_BAD_PTR;
+  if (src->width != dest->width || src->height != dest->height) return ERROR_ULTRAHDR_RESOLUTION_MISMATCH;
+  const status_t st = ensureInit();
+  if (st != ULTRAHDR_NO_ERROR) return st;
+  uhdr_hip_image_t s = to_c(*src), d = to_c(*dest);
+  const int rc = uhdr_hip_tonemap(&s, &d, UHDR_HIP_MEM_HOST, nullptr);
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  dest->colorGamut = static_cast<ultrahdr_color_gamut>(d.colorGamut);  // :556
+  return ULTRAHDR_NO_ERROR;
+}
+
+status_t UltraHdrHip::convertYuv(uhdr_uncompressed_ptr image, ultrahdr_color_gamut src_encoding,
+                                 ultrahdr_color_gamut dest_encoding) {
+  if (image == nullptr) return ERROR_ULTRAHDR_BAD_PTR;  // jpegr.cpp:1134-1140
+  if (src_encoding == ULTRAHDR_COLORGAMUT_UNSPECIFIED || dest_encoding == ULTRAHDR_COLORGAMUT_UNSPECIFIED)
+    return ERROR_ULTRAHDR_INVALID_COLORGAMUT;
+  if (src_encoding == dest_encoding) return ULTRAHDR_NO_ERROR;
+  const status_t st = ensureInit();
+  if (st != ULTRAHDR_NO_ERROR) return st;
+  uhdr_hip_image_t i = to_c(*image);
+  return static_cast<status_t>(uhdr_hip_convert_yuv(&i, static_cast<int>(src_encoding), static_cast<int>(dest_encoding),
+                                                    UHDR_HIP_MEM_HOST, nullptr));
+}
+
+}  // namespace ultrahdr

@@ -1,0 +1,159 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/uhdr_hip.h
+declares, validates arguments with the reference's status codes, and REFUSES to compute without a GPU
+(no CPU fallback, no route through oracle/)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def api():
+    from libultrahdr_dev_amd import api as a
+    a.load()
+    return a
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "uhdr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(uhdr_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(api):
+    names = _declared_functions()
+    assert len(names) >= 12
+    lib = C.CDLL(api.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libuhdr_hip.so does not export %s" % n
+        assert n in api.SIGNATURES, "python binding lacks %s" % n
+    assert lib.uhdr_hip_abi_version() == 1
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (uhdr_hip_\w+)", out))
+    assert exported == set(names), exported ^ set(names)
+
+
+def test_shim_exports_reference_member_names():
+    shim = os.path.join(ROOT, "libultrahdr_dev_amd", "libultrahdr_shim.so")
+    assert os.path.exists(shim), "build() did not produce the C++ shim"
+    out = subprocess.check_output(["nm", "-DC", "--defined-only", shim]).decode()
+    for member in ("generateGainMap", "applyGainMap", "toneMap", "convertYuv"):
+        assert "ultrahdr::UltraHdrHip::%s(" % member in out
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under libultrahdr_dev_amd/ or include/ may reference it"""
+    for base in ("libultrahdr_dev_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "liboracle" not in txt and "uhdr_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_no_gpu_means_no_compute(api):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for the CPU-only container")
+    lib = api.load()
+    assert lib.uhdr_hip_device_count() == 0
+    assert lib.uhdr_hip_init(0) == api.ERROR_INSUFFICIENT_RESOURCE
+    assert b"no CPU path" in lib.uhdr_hip_last_error()
+    w, h = 16, 8
+    yuv = np.zeros(w * h * 3 // 2, np.uint8)
+    p010 = np.zeros(w * h * 3 // 2, np.uint16)
+    gmap = np.full(8, 0x77, np.uint8)
+    yi = api.yuv420_image(yuv.ctypes.data, w, h, api.CG_BT709)
+    pi = api.p010_image(p010.ctypes.data, w, h, api.CG_BT2100)
+    dest = api.out_image(gmap.ctypes.data)
+    md = api.Metadata()
+    rc = lib.uhdr_hip_generate_gainmap(C.byref(yi), C.byref(pi), api.TF_HLG, C.byref(md), C.byref(dest), 0, api.MEM_HOST, None)
+    assert rc == api.ERROR_INSUFFICIENT_RESOURCE and (gmap == 0x77).all()
+    out = np.full(w * h, 0x55555555, np.uint32)
+    od = api.out_image(out.ctypes.data)
+    mi = api.mono_image(gmap.ctypes.data, 4, 2)
+    good = api.metadata(4.0)
+    rc = lib.uhdr_hip_apply_gainmap(C.byref(yi), C.byref(mi), C.byref(good), api.OUTPUT_HDR_PQ, 4.0, C.byref(od), 0, api.MEM_HOST, None)
+    assert rc == api.ERROR_INSUFFICIENT_RESOURCE and (out == 0x55555555).all()
+    assert lib.uhdr_hip_tonemap(C.byref(pi), C.byref(yi), api.MEM_HOST, None) == api.ERROR_INSUFFICIENT_RESOURCE
+    assert lib.uhdr_hip_convert_yuv(C.byref(yi), 0, 1, api.MEM_HOST, None) == api.ERROR_INSUFFICIENT_RESOURCE
+
+
+def test_argument_validation_codes_without_device(api):
+    """the reference's checks run before anything touches the device (ultrahdr.cpp:189-202,364-406,518-523;
+    jpegr.cpp:1134-1147), so their status codes are observable on a CPU-only box"""
+    lib = api.load()
+    w, h = 16, 8
+    yuv = np.zeros(w * h * 3 // 2, np.uint8)
+    p010 = np.zeros(w * h * 3 // 2, np.uint16)
+    buf = np.zeros(w * h * 8, np.uint8)
+    yi = api.yuv420_image(yuv.ctypes.data, w, h, api.CG_BT709)
+    pi = api.p010_image(p010.ctypes.data, w, h, api.CG_BT2100)
+    dest = api.out_image(buf.ctypes.data)
+    md = api.Metadata()
+    gen = lambda y, p, tf, m, d: lib.uhdr_hip_generate_gainmap(y, p, tf, m, d, 0, api.MEM_HOST, None)
+    assert gen(None, C.byref(pi), 1, C.byref(md), C.byref(dest)) == api.ERROR_BAD_PTR
+    assert gen(C.byref(yi), None, 1, C.byref(md), C.byref(dest)) == api.ERROR_BAD_PTR
+    assert gen(C.byref(yi), C.byref(pi), 1, None, C.byref(dest)) == api.ERROR_BAD_PTR
+    assert gen(C.byref(yi), C.byref(pi), 1, C.byref(md), None) == api.ERROR_BAD_PTR
+    nc = api.p010_image(p010.ctypes.data, w, h, 2); nc.chroma_data = None
+    assert gen(C.byref(yi), C.byref(nc), 1, C.byref(md), C.byref(dest)) == api.ERROR_BAD_PTR
+    p2 = api.p010_image(p010.ctypes.data, w, h + 2, 2)
+    assert gen(C.byref(yi), C.byref(p2), 1, C.byref(md), C.byref(dest)) == api.ERROR_RESOLUTION_MISMATCH
+    yu = api.yuv420_image(yuv.ctypes.data, w, h, api.CG_UNSPECIFIED)
+    assert gen(C.byref(yu), C.byref(pi), 1, C.byref(md), C.byref(dest)) == api.ERROR_INVALID_COLORGAMUT
+    # resolution mismatch wins over the gamut check, gamut over the transfer function (reference order)
+    assert gen(C.byref(yu), C.byref(p2), 7, C.byref(md), C.byref(dest)) == api.ERROR_RESOLUTION_MISMATCH
+    assert gen(C.byref(yu), C.byref(pi), 7, C.byref(md), C.byref(dest)) == api.ERROR_INVALID_COLORGAMUT
+    assert gen(C.byref(yi), C.byref(pi), api.TF_SRGB, C.byref(md), C.byref(dest)) == api.ERROR_INVALID_TRANS_FUNC
+
+    mi = api.mono_image(buf.ctypes.data, 4, 2)
+    app = lambda y, m, meta, d: lib.uhdr_hip_apply_gainmap(y, m, meta, api.OUTPUT_HDR_PQ, 4.0, d, 0, api.MEM_HOST, None)
+    good = api.metadata(4.0)
+    assert app(None, C.byref(mi), C.byref(good), C.byref(dest)) == api.ERROR_BAD_PTR
+    assert app(C.byref(yi), C.byref(mi), None, C.byref(dest)) == api.ERROR_BAD_PTR
+    for mut in ("version", "gamma", "offsetSdr", "offsetHdr", "hdrCapacityMin", "hdrCapacityMax"):
+        bad = api.metadata(4.0)
+        setattr(bad, mut, b"2.0" if mut == "version" else 3.0)
+        assert app(C.byref(yi), C.byref(mi), C.byref(bad), C.byref(dest)) == api.ERROR_BAD_METADATA, mut
+    assert app(C.byref(yi), C.byref(api.mono_image(buf.ctypes.data, 5, 2)), C.byref(good), C.byref(dest)) == api.ERROR_UNSUPPORTED_MAP_SCALE_FACTOR
+    assert app(C.byref(yi), C.byref(api.mono_image(buf.ctypes.data, 4, 4)), C.byref(good), C.byref(dest)) == api.ERROR_UNSUPPORTED_MAP_SCALE_FACTOR
+    # bad metadata is reported before a bad scale factor
+    bad = api.metadata(4.0); bad.gamma = 2.0
+    assert app(C.byref(yi), C.byref(api.mono_image(buf.ctypes.data, 5, 2)), C.byref(bad), C.byref(dest)) == api.ERROR_BAD_METADATA
+
+    assert lib.uhdr_hip_tonemap(None, C.byref(yi), api.MEM_HOST, None) == api.ERROR_BAD_PTR
+    y2 = api.yuv420_image(yuv.ctypes.data, w + 2, h, 0)
+    assert lib.uhdr_hip_tonemap(C.byref(pi), C.byref(y2), api.MEM_HOST, None) == api.ERROR_RESOLUTION_MISMATCH
+    assert lib.uhdr_hip_convert_yuv(None, 0, 1, api.MEM_HOST, None) == api.ERROR_BAD_PTR
+    assert lib.uhdr_hip_convert_yuv(C.byref(yi), -1, 1, api.MEM_HOST, None) == api.ERROR_INVALID_COLORGAMUT
+    assert lib.uhdr_hip_convert_yuv(C.byref(yi), 0, -1, api.MEM_HOST, None) == api.ERROR_INVALID_COLORGAMUT
+    assert lib.uhdr_hip_convert_yuv(C.byref(yi), 2, 2, api.MEM_HOST, None) == api.NO_ERROR   # same encoding: no-op
+
+
+def test_idw_tables_equal_the_oracle(api, orc):
+    """the Shepard IDW weights the apply kernels use (host-computed once per scale) are bit-identical to
+    the reference's fillShepardsIDW (gainmapmath.cpp:69-110)"""
+    lib, L = api.load(), orc.load()
+    for scale in (1, 2, 3, 4, 5, 6, 8):
+        n = scale * scale * 4
+        got = (C.c_float * (4 * n))()
+        assert lib.uhdr_hip_idw_tables(scale, got) == 0
+        for t, (incR, incB) in enumerate(((1, 1), (0, 1), (1, 0), (0, 0))):
+            want = (C.c_float * n)()
+            L.orc_fillShepardsIDW(want, scale, incR, incB)
+            assert list(got)[t * n:(t + 1) * n] == list(want), (scale, t)
+
+
+def test_synthetic_frames_match_the_survey_lcg(orc):
+    """libultrahdr_dev_amd.synth (jump-ahead LCG, used by bench.py on the GPU) == SURVEY 8(d) serial LCG"""
+    from libultrahdr_dev_amd import synth
+    for (w, h, seed) in ((64, 32, 1234), (40, 24, 1299)):
+        p, y = synth.lcg_frame(w, h, seed, device="cpu")
+        op, oy = orc.lcg_frame(w, h, seed)
+        assert np.array_equal(p.numpy().view(np.uint16), op) and np.array_equal(y.numpy(), oy)

@@ -1,0 +1,59 @@
+"""-m gpu: the C++ host shim (ultrahdr::UltraHdrHip, include/ultrahdr_hip/ultrahdr.h) driven by a C++ program
+shaped like the reference's own harness, and the HBM-side synthetic frame generator used by bench.py."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def test_cpp_shim_on_reference_fixture(hip, orc, tmp_path):
+    exe = str(tmp_path / "shim_test")
+    pkg = os.path.join(ROOT, "libultrahdr_dev_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_test.cpp"), "-o", exe,
+                           "-L" + pkg, "-lultrahdr_shim", "-luhdr_hip", "-Wl,-rpath," + pkg])
+    g = os.path.join(ROOT, "tests", "golden")
+    env = dict(os.environ)
+    # a pure C++ host links the system ROCm runtime; nothing of torch is involved in this process
+    r = subprocess.run([exe, os.path.join(g, "raw_p010_image.p010"), os.path.join(g, "raw_yuv420_image.yuv420"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # golden md5s of the real reference
+    assert md5(tmp_path / "map_hlg.bin") == "32e38116ea48d76872b525663d33d137"
+    assert md5(tmp_path / "apply_hlg_exact.bin") == "dfd56dc878636c93b7a92b45cf35ee53"
+    assert md5(tmp_path / "apply_f16_exact.bin") == "237aa8455a4d5b18136f36e2c59eb8c3"
+    assert md5(tmp_path / "tonemap.bin") == "f8a112ef5d54c8df357fd082b22c5397"
+    # FAST PQ within 1 LSB of the reference bytes (re-created by the oracle, itself md5-pinned)
+    w, h = 1280, 720
+    yuv = np.fromfile(os.path.join(g, "raw_yuv420_image.yuv420"), np.uint8)
+    gmap = np.fromfile(tmp_path / "map_hlg.bin", np.uint8).reshape(h // 4, w // 4)
+    mb = float(np.float32(1000.0) / np.float32(203.0))
+    omd = orc.Metadata(mb, 1.0, 1.0, 0.0, 0.0, 1.0, mb, 1)
+    st, ref, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, 0), gmap, omd, orc.OUT_HDR_PQ, 3.4028234663852886e38, threads=8)
+    assert hashlib.md5(ref.tobytes()).hexdigest() == "87ffff4015d36d3fd664bc918039c00d"
+    from tests.gpu_util import diff_1010102
+    worst, frac, alpha_ok = diff_1010102(np.fromfile(tmp_path / "apply_pq_fast.bin", np.uint32), ref.view(np.uint32))
+    assert alpha_ok and worst <= 1
+    # convertYuv against the oracle
+    cv = yuv.copy()
+    img = orc.yuv420_image(cv, w, h, 0)
+    assert orc.load().orc_convertYuv(C.byref(img), 0, 1) == 0
+    assert np.array_equal(np.fromfile(tmp_path / "convert_709_601.bin", np.uint8), cv)
+
+
+def test_hbm_synthetic_frames_match_the_survey_lcg(hip, orc):
+    from libultrahdr_dev_amd import synth
+    for (w, h, seed) in ((640, 480, 1234), (3840, 2160, 1235)):
+        p, y = synth.lcg_frame(w, h, seed)
+        op, oy = orc.lcg_frame(w, h, seed)
+        assert np.array_equal(p.cpu().numpy().view(np.uint16), op) and np.array_equal(y.cpu().numpy(), oy)

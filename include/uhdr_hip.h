@@ -182,6 +182,16 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuv420_images,
  * scale*scale*4 floats; gainmapmath.h:184-228) the apply kernels use for `scale` into out[] */
 int uhdr_hip_idw_tables(int scale, float* out);
 
+/* evaluates one scalar device function over n floats (DEVICE pointers), out[i] = f(in[i]):
+ *   fn 0/1/2  sRGB / HLG / PQ inverse OETF as generate computes them (lean f64 + rounding test + exact fallback)
+ *   fn 3      encodeGain byte (as float) of gain in[i] for (min_boost, max_boost), generate's version
+ *   fn 10..13 the same four through the exact (ocml f64) path;  14/15 HLG / PQ OETF exact
+ *   fn 20/24/25 apply-FAST sRGB EOTF / HLG OETF / PQ OETF
+ *   fn 100/101 1.0 where the lean path of fn 0/1 passed its rounding test, else 0.0
+ * Used by the exhaustive transfer-function tests. */
+int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float min_boost, float max_boost,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,7 @@ SIGNATURES = {
     "uhdr_hip_generate_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_void_p, C.c_void_p]),
     "uhdr_hip_apply_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_idw_tables": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    "uhdr_hip_eval_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]),
 }
 
 _lib = None

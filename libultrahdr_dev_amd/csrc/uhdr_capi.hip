@@ -203,6 +203,16 @@ void fill_generate_dest(const uhdr_hip_image_t* yuv, uhdr_hip_image_t* dest) {  
   dest->pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
 }
 
+// bytes encodeGain (gainmapmath.cpp:529-541) yields for a gain clamped to min / max, evaluated with the
+// host libm exactly as the reference does, and the scale of the in-range fast path
+void encode_constants(float min_boost, float max_boost, float l2min, float l2max, double* scale, uint32_t* bmin,
+                      uint32_t* bmax) {
+  const double den = (double)(l2max - l2min);
+  *scale = (double)255.0f / den;
+  *bmin = (uint8_t)((std::log2((double)min_boost) - (double)l2min) / den * (double)255.0f);
+  *bmax = (uint8_t)((std::log2((double)max_boost) - (double)l2min) / den * (double)255.0f);
+}
+
 GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_601, size_t w, size_t h,
                           const uhdr_hip_metadata_t& md) {
   GenConsts c;
@@ -221,6 +231,7 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   c.max_boost = md.maxContentBoost;
   c.log2_min = (float)std::log2((double)md.minContentBoost);  // ultrahdr.cpp:259-260
   c.log2_max = (float)std::log2((double)md.maxContentBoost);
+  encode_constants(c.min_boost, c.max_boost, c.log2_min, c.log2_max, &c.enc_scale, &c.enc_byte_min, &c.enc_byte_max);
   c.width = (uint32_t)w; c.height = (uint32_t)h;
   c.map_w = (uint32_t)(w / 4); c.map_h = (uint32_t)(h / 4);
   return c;
@@ -284,6 +295,16 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
   c.log2_min_d = std::log2((double)md.minContentBoost);                           // gainmapmath.cpp:551-552
   c.log2_max_d = std::log2((double)md.maxContentBoost);
   c.idw = idw;
+  // FAST scale-4 kernel: factor/display_boost = 2^(gain*A + B); weights pre-multiplied by A (k_apply_s4)
+  const double ratio = (double)c.display_boost / (double)md.maxContentBoost;
+  c.fast.A = (float)((c.log2_max_d - c.log2_min_d) * ratio);
+  c.fast.B = (float)(c.log2_min_d * ratio - std::log2((double)c.display_boost));
+  std::vector<float> t;
+  build_idw_tables(4, t);
+  for (int oy = 0; oy < 4; ++oy)
+    for (int pr = 0; pr < 2; ++pr)
+      for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 2; ++j) c.fast.wA[oy][pr][k][j] = t[oy * 16 + (2 * pr + j) * 4 + k] * c.fast.A;
   return c;
 }
 AppImage app_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map, void* dst) {
@@ -426,6 +447,22 @@ int uhdr_hip_shutdown(void) {
   }
   g_dev.clear();
   if (prev >= 0) (void)hipSetDevice(prev);
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float min_boost, float max_boost,
+                           void* stream) {
+  if (in == nullptr || out == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  DeviceState* st = nullptr;
+  const int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  EvalConsts ec;
+  ec.min_boost = min_boost;
+  ec.max_boost = max_boost;
+  ec.log2_min = (float)std::log2((double)min_boost);
+  ec.log2_max = (float)std::log2((double)max_boost);
+  encode_constants(min_boost, max_boost, ec.log2_min, ec.log2_max, &ec.enc_scale, &ec.enc_byte_min, &ec.enc_byte_max);
+  HIP_TRY(launch_eval_transfer(fn, in, out, n, ec, static_cast<hipStream_t>(stream)));
   return UHDR_HIP_NO_ERROR;
 }
 

@@ -82,6 +82,122 @@ __device__ __forceinline__ float pq_inv_oetf_exact(float e) {
                     (double)6.2773946361f);
 }
 
+// =================================================================================================
+// "guarded" double-precision transfer functions for generate.
+//
+// The reference rounds glibc's double pow/exp to float.  ocml's f64 pow/exp cost ~150-200 VALU slots
+// each and made k_generate compute-bound (round-1 v1 profile: 2790 VALU instructions per wave).
+// Here each call first evaluates a lean f64 polynomial (fast_log2 / fast_exp2, relative error well
+// below 2^-44), then applies Ziv's rounding test: if every double within 2^-38 (relative) of the
+// result rounds to the same float, that float is returned; otherwise (probability ~2^-13 per call)
+// the exact ocml path is taken in an out-of-line call.  Either way the returned float is the one
+// the exact path returns; uhdr_hip_selftest() verifies that exhaustively over the input domains.
+// =================================================================================================
+
+// log2(x) for normal positive x; |relative error| < 2^-50 (atanh series to s^19, division by
+// Newton-refined reciprocal)
+__device__ __forceinline__ double fast_log2(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);      // x = m * 2^e
+  const bool lo = m < 0x1.6a09e667f3bcdp-1;   // sqrt(1/2)
+  m = lo ? (m + m) : m;                       // [sqrt(1/2), sqrt(2))
+  e = lo ? e - 1 : e;
+  const double d = m + 1.0, n = m - 1.0;
+  double r = (double)__builtin_amdgcn_rcpf((float)d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double s = n * r, s2 = s * s;
+  double p = 0x1.3703c1f4d0ffep-3;
+  p = __builtin_fma(p, s2, 0x1.5b9ac9b743f0dp-3);
+  p = __builtin_fma(p, s2, 0x1.89f3b1694cffep-3);
+  p = __builtin_fma(p, s2, 0x1.c68f568d31760p-3);
+  p = __builtin_fma(p, s2, 0x1.0c9a84994022dp-2);
+  p = __builtin_fma(p, s2, 0x1.484b13d7c02a9p-2);
+  p = __builtin_fma(p, s2, 0x1.a61762a7aded9p-2);
+  p = __builtin_fma(p, s2, 0x1.2776c50ef9bfep-1);
+  p = __builtin_fma(p, s2, 0x1.ec709dc3a03fdp-1);
+  p = __builtin_fma(p, s2, 0x1.71547652b82fep+1);
+  return __builtin_fma(s, p, (double)e);
+}
+
+// 2^P for |P| < 1000; |relative error| < 2^-50 (Taylor to f^12 on |f| <= 1/2)
+__device__ __forceinline__ double fast_exp2(double P) {
+  const double k = __builtin_rint(P);
+  const double f = P - k;
+  double p = 0x1.c3bd650fc2986p-36;
+  p = __builtin_fma(p, f, 0x1.e8cac7351bb25p-32);
+  p = __builtin_fma(p, f, 0x1.e4cf5158b8ecap-28);
+  p = __builtin_fma(p, f, 0x1.b5253d395e7c4p-24);
+  p = __builtin_fma(p, f, 0x1.62c0223a5c824p-20);
+  p = __builtin_fma(p, f, 0x1.ffcbfc588b0c7p-17);
+  p = __builtin_fma(p, f, 0x1.430912f86c787p-13);
+  p = __builtin_fma(p, f, 0x1.5d87fe78a6731p-10);
+  p = __builtin_fma(p, f, 0x1.3b2ab6fba4e77p-7);
+  p = __builtin_fma(p, f, 0x1.c6b08d704a0c0p-5);
+  p = __builtin_fma(p, f, 0x1.ebfbdff82c58fp-3);
+  p = __builtin_fma(p, f, 0x1.62e42fefa39efp-1);
+  p = __builtin_fma(p, f, 1.0);
+  return __builtin_ldexp(p, (int)k);
+}
+
+// Ziv test: may y (relative error < 2^-38) be rounded to float without knowing its last bits?
+__device__ __forceinline__ bool ziv_safe(double y) {
+  const uint32_t lo = (uint32_t)__double2loint(y);
+  const int32_t dist = (int32_t)(lo & 0x1FFFFFFFu) - 0x10000000;  // low 29 bits vs the float midpoint
+  const uint32_t ad = (uint32_t)(dist < 0 ? -dist : dist);
+  return ad > (1u << 16) && y >= 0x1p-126;  // 2^-38 relative = 2^15 double ulps; 2x margin
+}
+
+// x / a for a compile-time constant a, as q + fma(-q, a, x) * (1/a).  Not correctly rounded for
+// every conceivable x; uhdr_hip_selftest() proves it equals IEEE division on the whole input
+// domain each call site can see.
+__device__ __forceinline__ float div_const(float x, float a, float ra) {
+  const float q = x * ra;
+  return __builtin_fmaf(__builtin_fmaf(-q, a, x), ra, q);
+}
+
+__device__ __attribute__((noinline)) float srgb_inv_oetf_slow(float e) { return srgb_inv_oetf_exact(e); }
+__device__ __attribute__((noinline)) float hlg_inv_oetf_slow(float e) { return hlg_inv_oetf_exact(e); }
+__device__ __attribute__((noinline)) float pq_inv_oetf_slow(float e) { return pq_inv_oetf_exact(e); }
+
+__device__ __forceinline__ float srgb_inv_oetf_guarded(float e) {
+  float lin = div_const(e, 12.92f, 1.0f / 12.92f);
+  // the fma remainder of div_const underflows for |e| < ~7e-32 (selftest): such values (never produced by
+  // 8-bit content, but representable) take the hardware IEEE division
+  if (e != 0.0f && e < 0x1p-100f) lin = e / 12.92f;
+  const float x = div_const(e + 0.055f, 1.055f, 1.0f / 1.055f);
+  const double y = fast_exp2(2.4 * fast_log2((double)x));
+  float p = (float)y;
+  if (e > 0.04045f && !ziv_safe(y)) p = srgb_inv_oetf_slow(e);
+  return (e <= 0.04045f) ? lin : p;
+}
+
+__device__ __forceinline__ float hlg_inv_oetf_guarded(float e) {
+  // e <= 0.5: (e*e)/3 in double, division by 3 as q + fma(-q,3,t)/3 (exact; selftest)
+  const double t = (double)e * (double)e;
+  const double q0 = t * 0x1.5555555555555p-2;
+  const float lo = (float)__builtin_fma(__builtin_fma(-q0, 3.0, t), 0x1.5555555555555p-2, q0);
+  // e > 0.5: (exp((e-c)/a) + b) / 12
+  const float v = div_const(e - UHDR_HLG_C, UHDR_HLG_A, 1.0f / UHDR_HLG_A);
+  const double y = (fast_exp2((double)v * 0x1.71547652b82fep+0) + (double)UHDR_HLG_B) * (1.0 / 12.0);
+  float hi = (float)y;
+  if (e > 0.5f && !ziv_safe(y)) hi = hlg_inv_oetf_slow(e);
+  return (e <= 0.5f) ? lo : hi;
+}
+
+__device__ __forceinline__ float pq_inv_oetf_guarded(float e) {
+  const float es = (e <= 0.0001f) ? 1.0f : e;
+  const double p = fast_exp2((double)0.0126833f * fast_log2((double)es));
+  const double num = __builtin_fma(128.0, p, -107.0), den = __builtin_fma(-2392.0, p, 2413.0);
+  double r = (double)__builtin_amdgcn_rcpf((float)den);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+  const double y = fast_exp2((double)6.2773946361f * fast_log2(num * r));
+  float o = (float)y;
+  if (e > 0.0001f && !ziv_safe(y)) o = pq_inv_oetf_slow(e);
+  return (e <= 0.0001f) ? 0.0f : o;
+}
+
 // ---- encodeGain (gainmapmath.cpp:529-541) ------------------------------------------------------
 __device__ __forceinline__ float raw_gain(float y_sdr, float y_hdr) {
   float gain = 1.0f;
@@ -94,6 +210,24 @@ __device__ __forceinline__ uint8_t encode_gain(float gain, float min_boost, floa
   if (gain > max_boost) gain = max_boost;
   return (uint8_t)((log2((double)gain) - (double)log2_min) / (double)(log2_max - log2_min) *
                    (double)255.0f);
+}
+
+__device__ __attribute__((noinline)) uint8_t encode_gain_slow(float gain, float min_boost, float max_boost,
+                                                              float log2_min, float log2_max) {
+  return encode_gain(gain, min_boost, max_boost, log2_min, log2_max);
+}
+// same byte as encode_gain(): clamped gains use host-computed bytes, the rest a fast log2 plus a
+// distance-to-integer test (the value is truncated, so only the integer part matters)
+__device__ __forceinline__ uint8_t encode_gain_guarded(float gain, float min_boost, float max_boost, float log2_min,
+                                                       float log2_max, double k_scale, uint32_t byte_min,
+                                                       uint32_t byte_max) {
+  if (!(gain > min_boost)) return (uint8_t)byte_min;
+  if (!(gain < max_boost)) return (uint8_t)byte_max;
+  const double v = (fast_log2((double)gain) - (double)log2_min) * k_scale;
+  const double fl = __builtin_floor(v), fr = v - fl;
+  if (fr < 0x1p-20 || fr > 1.0 - 0x1p-20 || !(v > 0.0) || !(v < 256.0))
+    return encode_gain_slow(gain, min_boost, max_boost, log2_min, log2_max);
+  return (uint8_t)(uint32_t)fl;
 }
 
 // ---- output packing (gainmapmath.cpp:722-732, gainmapmath.h:136-147) ---------------------------

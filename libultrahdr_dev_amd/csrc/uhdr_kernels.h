@@ -16,7 +16,15 @@ struct GenConsts {
   int gm_identity;
   float hdr_white_nits;
   float min_boost, max_boost, log2_min, log2_max;
+  // encode_gain_guarded: 255/(double)(log2_max - log2_min) and the bytes of gain == min / gain == max
+  double enc_scale;
+  uint32_t enc_byte_min, enc_byte_max;
   uint32_t width, height, map_w, map_h;
+};
+struct EvalConsts {
+  float min_boost, max_boost, log2_min, log2_max;
+  double enc_scale;
+  uint32_t enc_byte_min, enc_byte_max;
 };
 struct GenImage {
   const uint8_t* y;
@@ -33,11 +41,17 @@ struct GenBatch {
 };
 
 // ---- apply -------------------------------------------------------------------------------------
+// constants of the FAST scale-4 kernel (see k_apply_s4): wA[oy][pair][k] = (w_k(ox=2*pair), w_k(ox=2*pair+1)) * A
+struct AppFast {
+  float A, B;
+  float wA[4][2][4][2];
+};
 struct AppConsts {
   uint32_t width, height, map_w, map_h, scale;
   float display_boost, inv_display_boost, max_boost, inv_max_boost;
   double log2_min_d, log2_max_d;  // log2((double)minContentBoost), log2((double)maxContentBoost)
   const float* idw;               // device: 4 tables (std, NR, NB, C) of scale*scale*4 floats
+  AppFast fast;
 };
 struct AppImage {
   const uint8_t* y;
@@ -79,5 +93,6 @@ hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, b
 hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s);
 hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s);
 hipError_t upload_idw4(const float* tables /* 4*64 floats */);
+hipError_t launch_eval_transfer(int fn, const float* in, float* out, size_t n, const EvalConsts& ec, hipStream_t s);
 
 }  // namespace uhdr

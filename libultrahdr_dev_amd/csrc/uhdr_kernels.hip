@@ -48,8 +48,8 @@ constexpr float kP3GCr = kP3YR * kP3Cr / kP3YG;
 
 template <int TF>
 __device__ __forceinline__ float hdr_inv_oetf(float e) {
-  if (TF == 1) return hlg_inv_oetf_exact(e);
-  if (TF == 2) return pq_inv_oetf_exact(e);
+  if (TF == 1) return hlg_inv_oetf_guarded(e);
+  if (TF == 2) return pq_inv_oetf_guarded(e);
   return e;  // ULTRAHDR_TF_LINEAR: identityConversion (ultrahdr.cpp:223-228)
 }
 
@@ -94,9 +94,9 @@ __device__ __forceinline__ void gen_px(const GenConsts& c, const uint32_t (&hy)[
   float r = clamp01(sy + c.sdr_cr * sv);
   float g = clamp01(sy - c.sdr_gcb * su - c.sdr_gcr * sv);
   float b = clamp01(sy + c.sdr_cb * su);
-  r = srgb_inv_oetf_exact(r);
-  g = srgb_inv_oetf_exact(g);
-  b = srgb_inv_oetf_exact(b);
+  r = srgb_inv_oetf_guarded(r);
+  g = srgb_inv_oetf_guarded(g);
+  b = srgb_inv_oetf_guarded(b);
   const float sdr_nits = (c.lum_r * r + c.lum_g * g + c.lum_b * b) * 203.0f;
 
   // HDR: YUV->RGB, inverse OETF, gamut conversion, luminance * white (ultrahdr.cpp:326-330)
@@ -115,7 +115,8 @@ __device__ __forceinline__ void gen_px(const GenConsts& c, const uint32_t (&hy)[
   const float hdr_nits = (c.lum_r * hr + c.lum_g * hg + c.lum_b * hb) * c.hdr_white_nits;
 
   gain = raw_gain(sdr_nits, hdr_nits);
-  out = encode_gain(gain, c.min_boost, c.max_boost, c.log2_min, c.log2_max);
+  out = encode_gain_guarded(gain, c.min_boost, c.max_boost, c.log2_min, c.log2_max, c.enc_scale, c.enc_byte_min,
+                            c.enc_byte_max);
 }
 
 __device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
@@ -312,10 +313,143 @@ __device__ __forceinline__ F3 hdr_oetf(F3 e) {
 
 __device__ __forceinline__ float map_to_float(uint32_t v) { return (float)v / 255.0f; }  // gainmapmath.cpp:632
 
-// FAST path, scale factor 4: thread = one gain-map cell = a 4x4 pixel block.  The four map taps
-// and the four 2x2 chroma samples are loaded once and shared by the 16 pixels; each output row of
-// the block leaves as one 16 B (1010102) / 2x16 B (F16) / 3x8 B (planar 10 bit) store per lane, so
-// a wave64 writes 1 KiB contiguous per row.
+// ---- FAST path, scale factor 4 ---------------------------------------------------------------
+// Thread = one gain-map cell = a 4x4 pixel block.  The four map taps and the four 2x2 chroma samples
+// are loaded once and shared by the 16 pixels; each output row of the block leaves as one 16 B
+// (1010102) / 2x16 B (F16) / 3x8 B (planar 10 bit) store per lane, so a wave64 writes 1 KiB contiguous
+// per row.  The kernel is bound by VALU issue, not by HBM (13 special-function ops per pixel, see
+// DESIGN.md section 6), so the arithmetic is organised to minimise issue slots:
+//   * two horizontally adjacent pixels (they share one chroma sample) are processed as one packed
+//     float2 (v_pk_mul/add/fma_f32: two pixels per 4-cycle issue slot);
+//   * gain -> log-boost -> display scaling collapse into one exponent:
+//       factor/display_boost = 2^E,  E = sum_i e_i*(w_i*A) + B,
+//       A = (log2 max - log2 min) * display_boost / max,  B = log2 min * display_boost / max - log2 display_boost
+//     with the products w_i*A pre-multiplied on the host (AppFast::wA, SGPR operands);
+//   * the *1023 of the 10-bit pack is folded into the OETF constants;
+//   * clamps are written as min(max()) so that they fold into the producing add's clamp modifier.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+__device__ __forceinline__ float sat01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+__device__ __forceinline__ f2 log2_2(f2 v) { return (f2){__builtin_amdgcn_logf(v.x), __builtin_amdgcn_logf(v.y)}; }
+__device__ __forceinline__ f2 exp2_2(f2 v) { return (f2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
+__device__ __forceinline__ f2 sqrt_2(f2 v) { return (f2){__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)}; }
+__device__ __forceinline__ f2 rcp_2(f2 v) { return (f2){__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
+__device__ __forceinline__ f2 sel_le(f2 x, float thr, f2 a, f2 b) {  // x <= thr ? a : b
+  return (f2){x.x <= thr ? a.x : b.x, x.y <= thr ? a.y : b.y};
+}
+
+// sRGB EOTF of two values: x^2.4 = x^2 * 2^(0.4 log2 x)
+__device__ __forceinline__ f2 srgb_eotf2(f2 e) {
+  const f2 lin = e * splat(1.0f / 12.92f);
+  const f2 x = pk_fma(e, splat(1.0f / 1.055f), splat(0.055f / 1.055f));
+  const f2 t = exp2_2(log2_2(x) * splat(0.4f));
+  return sel_le(e, 0.04045f, lin, (x * x) * t);
+}
+
+// OETF of two linear values, scaled to 10-bit code units where the format is 10 bit
+template <int FMT>
+__device__ __forceinline__ f2 oetf2_scaled(f2 e) {
+  if (FMT == 3) {  // HLG: sqrt(3e) | a ln(12e-b)+c, times 1023
+    const f2 lo = sqrt_2(e * splat(3.0f * 1023.0f * 1023.0f));
+    const f2 hi = pk_fma(log2_2(pk_fma(e, splat(12.0f), splat(-UHDR_HLG_B))),
+                         splat(UHDR_HLG_A * 0.693147180559945f * 1023.0f), splat(UHDR_HLG_C * 1023.0f));
+    return sel_le(e, 1.0f / 12.0f, lo, hi);
+  } else if (FMT == 2) {  // PQ: ((c1 + c2 e^m1) / (1 + c3 e^m1))^m2, times 1023
+    const f2 p = exp2_2(log2_2(e) * splat(UHDR_PQ_M1));
+    const f2 q = pk_fma(p, splat(UHDR_PQ_C2), splat(UHDR_PQ_C1)) * rcp_2(pk_fma(p, splat(UHDR_PQ_C3), splat(1.0f)));
+    const f2 r = exp2_2(pk_fma(log2_2(q), splat(UHDR_PQ_M2), splat(9.99859042974533f)));  // + log2(1023)
+    return sel_le(e, 0.0f, splat(0.0f), r);
+  } else if (FMT == 4) {
+    return e * splat(1023.0f);
+  }
+  return e;
+}
+
+struct PairOut { f2 r, g, b; };
+
+// two horizontally adjacent pixels sharing one chroma sample
+template <int FMT>
+__device__ __forceinline__ PairOut apply_pair(f2 yf, float crv, float gsum, float cbu, f2 E) {
+  // p3YuvToRgb (gainmapmath.cpp:198-202); the clamp folds into the add
+  f2 r = (f2){sat01(yf.x + crv), sat01(yf.y + crv)};
+  f2 g = (f2){sat01(yf.x - gsum), sat01(yf.y - gsum)};
+  f2 b = (f2){sat01(yf.x + cbu), sat01(yf.y + cbu)};
+  const f2 factor = exp2_2(E);  // applyGain's 2^(logBoost*displayBoost/max) / displayBoost
+  PairOut o;
+  o.r = oetf2_scaled<FMT>(srgb_eotf2(r) * factor);
+  o.g = oetf2_scaled<FMT>(srgb_eotf2(g) * factor);
+  o.b = oetf2_scaled<FMT>(srgb_eotf2(b) * factor);
+  return o;
+}
+
+__device__ __forceinline__ uint32_t pack10_scaled(float r, float g, float b) {  // inputs already *1023
+  const uint32_t ri = (uint32_t)r, gi = (uint32_t)g, bi = (uint32_t)b;
+  return (ri & 0x3ffu) | ((gi & 0x3ffu) << 10) | ((bi & 0x3ffu) << 20) | 0xC0000000u;
+}
+
+template <int FMT, bool INTERIOR>
+__device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
+                                           const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
+                                           float e1, float e2, float e3, float e4, int tbl) {
+  float crv[2][2], gsum[2][2], cbu[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float u = (float)((int)((uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      const float v = (float)((int)((vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      crv[r][k] = kP3Cr * v;
+      gsum[r][k] = __builtin_fmaf(kP3GCb, u, kP3GCr * v);
+      cbu[r][k] = kP3Cb * u;
+    }
+  const float* wt = c_idw4 + tbl * 64;  // border cells only: per-lane table (gainmapmath.cpp:710-716)
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy) {
+    PairOut po[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      f2 w0, w1, w2, w3;
+      if (INTERIOR) {
+        w0 = (f2){c.fast.wA[oy][pr][0][0], c.fast.wA[oy][pr][0][1]}; w1 = (f2){c.fast.wA[oy][pr][1][0], c.fast.wA[oy][pr][1][1]};
+        w2 = (f2){c.fast.wA[oy][pr][2][0], c.fast.wA[oy][pr][2][1]}; w3 = (f2){c.fast.wA[oy][pr][3][0], c.fast.wA[oy][pr][3][1]};
+      } else {
+        const float* p0 = wt + oy * 16 + pr * 8;
+        w0 = (f2){p0[0], p0[4]} * splat(c.fast.A); w1 = (f2){p0[1], p0[5]} * splat(c.fast.A);
+        w2 = (f2){p0[2], p0[6]} * splat(c.fast.A); w3 = (f2){p0[3], p0[7]} * splat(c.fast.A);
+      }
+      const f2 E = pk_fma(splat(e4), w3, pk_fma(splat(e3), w2, pk_fma(splat(e2), w1, pk_fma(splat(e1), w0, splat(c.fast.B)))));
+      const uint32_t yw = yrow[oy] >> (16 * pr);
+      const f2 yf = (f2){(float)(yw & 0xffu), (float)((yw >> 8) & 0xffu)} * splat(k255);
+      po[pr] = apply_pair<FMT>(yf, crv[oy >> 1][pr], gsum[oy >> 1][pr], cbu[oy >> 1][pr], E);
+    }
+    const size_t pix0 = (size_t)(4u * cy + oy) * c.width + 4u * cx;
+    if (FMT == 2 || FMT == 3) {
+      uint4 o;
+      o.x = pack10_scaled(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled(po[0].r.y, po[0].g.y, po[0].b.y);
+      o.z = pack10_scaled(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled(po[1].r.y, po[1].g.y, po[1].b.y);
+      *reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0) = o;
+    } else if (FMT == 1) {
+      const uint2 a = pack_f16(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16(po[0].r.y, po[0].g.y, po[0].b.y);
+      const uint2 cc = pack_f16(po[1].r.x, po[1].g.x, po[1].b.x), d = pack_f16(po[1].r.y, po[1].g.y, po[1].b.y);
+      uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+      o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+      o[1] = make_uint4(cc.x, cc.y, d.x, d.y);
+    } else {  // FMT == 4: planar R,G,B uint16 (ultrahdr.cpp:460-468)
+      const size_t plane = (size_t)c.width * c.height;
+      uint16_t* base = static_cast<uint16_t*>(im.dst);
+      const f2 ch[3][2] = {{po[0].r, po[1].r}, {po[0].g, po[1].g}, {po[0].b, po[1].b}};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const uint32_t q0 = 0x3ffu & (uint32_t)ch[p][0].x, q1 = 0x3ffu & (uint32_t)ch[p][0].y;
+        const uint32_t q2 = 0x3ffu & (uint32_t)ch[p][1].x, q3 = 0x3ffu & (uint32_t)ch[p][1].y;
+        *reinterpret_cast<uint2*>(base + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+      }
+    }
+  }
+}
+
 template <int FMT>
 __global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBatch b) {
   const AppImage& im = b.img[blockIdx.y];
@@ -341,70 +475,13 @@ __global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBa
   const float e2 = map_to_float(im.map[(size_t)yu * c.map_w + cx]);
   const float e3 = map_to_float(im.map[(size_t)cy * c.map_w + xu]);
   const float e4 = map_to_float(im.map[(size_t)yu * c.map_w + xu]);
-  // weight table choice (gainmapmath.cpp:710-716)
   const bool edge_x = (xu == cx), edge_y = (yu == cy);
   const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
-  // interior waves (all but the last column/row of cells) read the weights with scalar loads
-  const bool wave_interior = (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull);
-  const float* wt_lane = c_idw4 + tbl * 64;
-
-  // chroma terms of p3YuvToRgb, one set per 2x2 block
-  float crv[2][2], gcbu[2][2], gcrv[2][2], cbu[2][2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float u = (float)((int)((uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
-      const float v = (float)((int)((vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
-      crv[r][k] = kP3Cr * v; gcbu[r][k] = kP3GCb * u; gcrv[r][k] = kP3GCr * v; cbu[r][k] = kP3Cb * u;
-    }
-
-#pragma unroll
-  for (int oy = 0; oy < 4; ++oy) {
-    F3 px[4];
-#pragma unroll
-    for (int ox = 0; ox < 4; ++ox) {
-      float w0, w1, w2, w3;
-      if (wave_interior) {
-        w0 = c_idw4[oy * 16 + ox * 4 + 0]; w1 = c_idw4[oy * 16 + ox * 4 + 1];
-        w2 = c_idw4[oy * 16 + ox * 4 + 2]; w3 = c_idw4[oy * 16 + ox * 4 + 3];
-      } else {
-        w0 = wt_lane[oy * 16 + ox * 4 + 0]; w1 = wt_lane[oy * 16 + ox * 4 + 1];
-        w2 = wt_lane[oy * 16 + ox * 4 + 2]; w3 = wt_lane[oy * 16 + ox * 4 + 3];
-      }
-      const float gain = e1 * w0 + e2 * w1 + e3 * w2 + e4 * w3;  // gainmapmath.cpp:719
-      const float yf = (float)((yrow[oy] >> (8 * ox)) & 0xffu) * k255;
-      const int r = oy >> 1, k = ox >> 1;
-      px[ox] = hdr_oetf<FMT, false>(recover_hdr<false>(c, yf, crv[r][k], gcbu[r][k], gcrv[r][k], cbu[r][k], gain));
-    }
-    const size_t pix0 = (size_t)(4u * cy + oy) * c.width + 4u * cx;
-    if (FMT == 2 || FMT == 3) {
-      uint4 o;
-      o.x = pack_1010102(px[0].x, px[0].y, px[0].z); o.y = pack_1010102(px[1].x, px[1].y, px[1].z);
-      o.z = pack_1010102(px[2].x, px[2].y, px[2].z); o.w = pack_1010102(px[3].x, px[3].y, px[3].z);
-      *reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0) = o;
-    } else if (FMT == 1) {
-      const uint2 a = pack_f16(px[0].x, px[0].y, px[0].z), bb = pack_f16(px[1].x, px[1].y, px[1].z);
-      const uint2 cc = pack_f16(px[2].x, px[2].y, px[2].z), d = pack_f16(px[3].x, px[3].y, px[3].z);
-      uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
-      o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
-      o[1] = make_uint4(cc.x, cc.y, d.x, d.y);
-    } else {  // FMT == 4: planar R,G,B uint16 (ultrahdr.cpp:460-468)
-      const size_t plane = (size_t)c.width * c.height;
-      uint16_t* base = static_cast<uint16_t*>(im.dst);
-      uint32_t q[3][4];
-#pragma unroll
-      for (int ox = 0; ox < 4; ++ox) {
-        q[0][ox] = 0x3ffu & (uint32_t)(px[ox].x * 1023.0f);
-        q[1][ox] = 0x3ffu & (uint32_t)(px[ox].y * 1023.0f);
-        q[2][ox] = 0x3ffu & (uint32_t)(px[ox].z * 1023.0f);
-      }
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        *reinterpret_cast<uint2*>(base + p * plane + pix0) =
-            make_uint2(q[p][0] | (q[p][1] << 16), q[p][2] | (q[p][3] << 16));
-    }
-  }
+  // all waves but those touching the last column/row of cells take the SGPR-weight path
+  if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull)
+    apply_cell<FMT, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0);
+  else
+    apply_cell<FMT, false>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, tbl);
 }
 
 // General path: one thread per pixel; any integer scale, any pointer/stride alignment, FAST or
@@ -640,6 +717,45 @@ hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s) {
   if (cw == 0 || ch == 0) return hipSuccess;
   if (aligned) hipLaunchKernelGGL((k_convert_yuv<true>), dim3((cw / 4u + 255u) / 256u, ch), dim3(256), 0, s, t);
   else hipLaunchKernelGGL((k_convert_yuv<false>), dim3((cw + 255u) / 256u, ch), dim3(256), 0, s, t);
+  return hipGetLastError();
+}
+
+// =================================================================================================
+// diagnostics: evaluate one transfer function over an array (tests/test_gpu_transfer_exhaustive.py)
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, float* out, size_t n, EvalConsts ec) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const float x = in[i];
+  float y = 0.0f;
+  switch (fn) {
+    case 0: y = srgb_inv_oetf_guarded(x); break;
+    case 1: y = hlg_inv_oetf_guarded(x); break;
+    case 2: y = pq_inv_oetf_guarded(x); break;
+    case 3: y = (float)encode_gain_guarded(x, ec.min_boost, ec.max_boost, ec.log2_min, ec.log2_max, ec.enc_scale,
+                                           ec.enc_byte_min, ec.enc_byte_max); break;
+    case 10: y = srgb_inv_oetf_exact(x); break;
+    case 11: y = hlg_inv_oetf_exact(x); break;
+    case 12: y = pq_inv_oetf_exact(x); break;
+    case 13: y = (float)encode_gain(x, ec.min_boost, ec.max_boost, ec.log2_min, ec.log2_max); break;
+    case 14: y = hlg_oetf_exact(x); break;
+    case 15: y = pq_oetf_exact(x); break;
+    case 24: y = hlg_oetf_fast(x); break;
+    case 25: y = pq_oetf_fast(x); break;
+    case 20: y = srgb_inv_oetf_fast(x); break;
+    // 1.0 where the lean f64 path was accepted by the rounding test, 0.0 where the exact path ran
+    case 100: { const float t = div_const(x + 0.055f, 1.055f, 1.0f / 1.055f);
+                y = (x <= 0.04045f || ziv_safe(fast_exp2(2.4 * fast_log2((double)t)))) ? 1.0f : 0.0f; break; }
+    case 101: { const float v = div_const(x - UHDR_HLG_C, UHDR_HLG_A, 1.0f / UHDR_HLG_A);
+                y = (x <= 0.5f || ziv_safe((fast_exp2((double)v * 0x1.71547652b82fep+0) + (double)UHDR_HLG_B) * (1.0 / 12.0))) ? 1.0f : 0.0f; break; }
+    default: break;
+  }
+  out[i] = y;
+}
+
+hipError_t launch_eval_transfer(int fn, const float* in, float* out, size_t n, const EvalConsts& ec, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_eval_transfer, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, in, out, n, ec);
   return hipGetLastError();
 }
 

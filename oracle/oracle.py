@@ -82,6 +82,7 @@ def _declare(lib, p):
         d("fill_lcg", None, C.c_void_p, C.c_void_p, sz, sz, C.c_uint32)
         d("checksum_u8", C.c_uint64, C.c_void_p, sz)
         d("checksum_u32", C.c_uint64, C.c_void_p, sz)
+        d("eval_transfer", None, i32, C.c_void_p, C.c_void_p, sz, f32, f32)
     else:
         for n in ("srgbInvOetfLUT", "hlgOetfLUT", "hlgInvOetfLUT", "pqOetfLUT", "pqInvOetfLUT"):
             d(n, f32, f32)
@@ -154,6 +155,24 @@ def lcg_frame(w, h, seed):
     yuv = np.empty(w * h * 3 // 2, np.uint8)
     lib.orc_fill_lcg(p010.ctypes.data, yuv.ctypes.data, w, h, seed)
     return p010, yuv
+
+
+def eval_transfer(fn, x, min_boost=1.0, max_boost=4.0, threads=8):
+    """out[i] = f(x[i]) with the oracle's scalar functions; x float32 ndarray"""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = load()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    n = x.size
+    step = (n + threads - 1) // threads
+
+    def run(lo):
+        hi = min(n, lo + step)
+        lib.orc_eval_transfer(fn, x.ctypes.data + 4 * lo, out.ctypes.data + 4 * lo, hi - lo, min_boost, max_boost)
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(run, range(0, n, step)))
+    return out
 
 
 def generate(lib_prefix, yuv_img, p010_img, tf, sdr_is_601=False, threads=0, stats=False):

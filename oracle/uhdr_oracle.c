@@ -710,6 +710,24 @@ int orc_toneMap(const orc_image* src, orc_image* dest) {
   return ORC_OK;
 }
 
+/* batch evaluation of the scalar functions (tests compare the device functions against these) */
+void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost) {
+  float l2min = (float)log2((double)minBoost), l2max = (float)log2((double)maxBoost);
+  for (size_t i = 0; i < n; ++i) {
+    float x = in[i], y = 0.0f;
+    switch (fn) {
+      case 0: y = orc_srgbInvOetf(x); break;
+      case 1: y = orc_hlgInvOetf(x); break;
+      case 2: y = orc_pqInvOetf(x); break;
+      case 3: y = (float)orc_encodeGain(1.0f, x, minBoost, maxBoost, l2min, l2max); break; /* gain = x/1 */
+      case 4: y = orc_hlgOetf(x); break;
+      case 5: y = orc_pqOetf(x); break;
+      default: break;
+    }
+    out[i] = y;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Synthetic input + checksum
  * ---------------------------------------------------------------------------------------- */

@@ -99,6 +99,9 @@ int orc_applyGainMap(const orc_image* yuv420, const orc_image* gainmap,
 int orc_toneMap(const orc_image* src, orc_image* dest);
 int orc_convertYuv(orc_image* image, int src_encoding, int dest_encoding);
 
+/* fn: 0 srgbInvOetf 1 hlgInvOetf 2 pqInvOetf 3 encodeGain(y_sdr=1,y_hdr=x) 4 hlgOetf 5 pqOetf */
+void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost);
+
 /* ---- helpers for tests / bench ---- */
 /* LCG synthetic frame of SURVEY.md 8(d): p010 and yuv each w*h*3/2 elements */
 void orc_fill_lcg(uint16_t* p010, uint8_t* yuv, size_t w, size_t h, uint32_t seed);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuhdr_hip.so")
+LIB_PATH = os.environ.get("UHDR_HIP_LIB") or os.path.join(_HERE, "libuhdr_hip.so")  # env override: A/B builds
 
 # enum values: ultrahdr.h:36-120
 CG_UNSPECIFIED, CG_BT709, CG_P3, CG_BT2100 = -1, 0, 1, 2

@@ -94,50 +94,94 @@ __device__ __forceinline__ float pq_inv_oetf_exact(float e) {
 // the exact path returns; uhdr_hip_selftest() verifies that exhaustively over the input domains.
 // =================================================================================================
 
-// log2(x) for normal positive x; |relative error| < 2^-50 (atanh series to s^19, division by
-// Newton-refined reciprocal)
-__device__ __forceinline__ double fast_log2(double x) {
-  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-  int e = __builtin_amdgcn_frexp_exp(x);      // x = m * 2^e
-  const bool lo = m < 0x1.6a09e667f3bcdp-1;   // sqrt(1/2)
-  m = lo ? (m + m) : m;                       // [sqrt(1/2), sqrt(2))
-  e = lo ? e - 1 : e;
-  const double d = m + 1.0, n = m - 1.0;
-  double r = (double)__builtin_amdgcn_rcpf((float)d);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  const double s = n * r, s2 = s * s;
-  double p = 0x1.3703c1f4d0ffep-3;
-  p = __builtin_fma(p, s2, 0x1.5b9ac9b743f0dp-3);
-  p = __builtin_fma(p, s2, 0x1.89f3b1694cffep-3);
-  p = __builtin_fma(p, s2, 0x1.c68f568d31760p-3);
-  p = __builtin_fma(p, s2, 0x1.0c9a84994022dp-2);
-  p = __builtin_fma(p, s2, 0x1.484b13d7c02a9p-2);
-  p = __builtin_fma(p, s2, 0x1.a61762a7aded9p-2);
-  p = __builtin_fma(p, s2, 0x1.2776c50ef9bfep-1);
-  p = __builtin_fma(p, s2, 0x1.ec709dc3a03fdp-1);
-  p = __builtin_fma(p, s2, 0x1.71547652b82fep+1);
-  return __builtin_fma(s, p, (double)e);
+// Horner step with the coefficient in an SGPR pair.  v_fma_f64 cannot take a 64-bit literal; left to itself
+// hipcc materialises every constant addend with two v_mov_b32 into the destination of a v_fmac_f64
+// (3 VALU slots per step -- 18 % of k_generate's VALU instructions in the first version), and a
+// __constant__ table costs a scalar-memory round trip per call site.  The "s" constraint makes the
+// compiler build the constant with s_mov_b32 on the scalar ALU, and the step is one VOP3 v_fma_f64.
+__device__ __forceinline__ double fma_sc(double a, double b, double c_in_sgprs) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_in_sgprs));
+  return r;
 }
 
-// 2^P for |P| < 1000; |relative error| < 2^-50 (Taylor to f^12 on |f| <= 1/2)
+// log2(x[j]) for normal positive x; |relative error| < 2^-50 (atanh series to s^19, division by a
+// Newton-refined reciprocal).  N independent evaluations advance in lock step so that consecutive
+// instructions never depend on each other (the f64 FMA latency would otherwise be exposed: measured
+// +60 % kernel time for serial Horner chains at 7 waves per SIMD).
+template <int N>
+__device__ __forceinline__ void fast_log2_n(const double (&x)[N], double (&out)[N]) {
+  double s[N], s2[N], p[N];
+  int e[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double m = __builtin_amdgcn_frexp_mant(x[j]);  // [0.5, 1)
+    e[j] = __builtin_amdgcn_frexp_exp(x[j]);       // x = m * 2^e
+    const bool lo = m < 0x1.6a09e667f3bcdp-1;      // sqrt(1/2)
+    m = lo ? (m + m) : m;                          // [sqrt(1/2), sqrt(2))
+    e[j] = lo ? e[j] - 1 : e[j];
+    const double d = m + 1.0, n = m - 1.0;
+    double r = (double)__builtin_amdgcn_rcpf((float)d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    s[j] = n * r;
+    s2[j] = s[j] * s[j];
+  }
+  // 2/((2k+1) ln 2), k = 9..0
+#define UHDR_STEP(C) _Pragma("unroll") for (int j = 0; j < N; ++j) p[j] = fma_sc(p[j], s2[j], C);
+#pragma unroll
+  for (int j = 0; j < N; ++j) p[j] = fma_sc(s2[j], 0x1.3703c1f4d0ffep-3, 0x1.5b9ac9b743f0dp-3);
+  UHDR_STEP(0x1.89f3b1694cffep-3)
+  UHDR_STEP(0x1.c68f568d31760p-3)
+  UHDR_STEP(0x1.0c9a84994022dp-2)
+  UHDR_STEP(0x1.484b13d7c02a9p-2)
+  UHDR_STEP(0x1.a61762a7aded9p-2)
+  UHDR_STEP(0x1.2776c50ef9bfep-1)
+  UHDR_STEP(0x1.ec709dc3a03fdp-1)
+  UHDR_STEP(0x1.71547652b82fep+1)
+#undef UHDR_STEP
+#pragma unroll
+  for (int j = 0; j < N; ++j) out[j] = __builtin_fma(s[j], p[j], (double)e[j]);
+}
+__device__ __forceinline__ double fast_log2(double x) {
+  const double in[1] = {x};
+  double out[1];
+  fast_log2_n<1>(in, out);
+  return out[0];
+}
+
+// 2^P[j] for |P| < 1000; |relative error| < 2^-50 (Taylor to f^12 on |f| <= 1/2); N in lock step
+template <int N>
+__device__ __forceinline__ void fast_exp2_n(const double (&P)[N], double (&out)[N]) {
+  double k[N], f[N], p[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    k[j] = __builtin_rint(P[j]);
+    f[j] = P[j] - k[j];
+  }
+  // (ln 2)^i / i!, i = 12..1
+#define UHDR_STEP(C) _Pragma("unroll") for (int j = 0; j < N; ++j) p[j] = fma_sc(p[j], f[j], C);
+#pragma unroll
+  for (int j = 0; j < N; ++j) p[j] = fma_sc(f[j], 0x1.c3bd650fc2986p-36, 0x1.e8cac7351bb25p-32);
+  UHDR_STEP(0x1.e4cf5158b8ecap-28)
+  UHDR_STEP(0x1.b5253d395e7c4p-24)
+  UHDR_STEP(0x1.62c0223a5c824p-20)
+  UHDR_STEP(0x1.ffcbfc588b0c7p-17)
+  UHDR_STEP(0x1.430912f86c787p-13)
+  UHDR_STEP(0x1.5d87fe78a6731p-10)
+  UHDR_STEP(0x1.3b2ab6fba4e77p-7)
+  UHDR_STEP(0x1.c6b08d704a0c0p-5)
+  UHDR_STEP(0x1.ebfbdff82c58fp-3)
+  UHDR_STEP(0x1.62e42fefa39efp-1)
+#undef UHDR_STEP
+#pragma unroll
+  for (int j = 0; j < N; ++j) out[j] = __builtin_ldexp(__builtin_fma(p[j], f[j], 1.0), (int)k[j]);
+}
 __device__ __forceinline__ double fast_exp2(double P) {
-  const double k = __builtin_rint(P);
-  const double f = P - k;
-  double p = 0x1.c3bd650fc2986p-36;
-  p = __builtin_fma(p, f, 0x1.e8cac7351bb25p-32);
-  p = __builtin_fma(p, f, 0x1.e4cf5158b8ecap-28);
-  p = __builtin_fma(p, f, 0x1.b5253d395e7c4p-24);
-  p = __builtin_fma(p, f, 0x1.62c0223a5c824p-20);
-  p = __builtin_fma(p, f, 0x1.ffcbfc588b0c7p-17);
-  p = __builtin_fma(p, f, 0x1.430912f86c787p-13);
-  p = __builtin_fma(p, f, 0x1.5d87fe78a6731p-10);
-  p = __builtin_fma(p, f, 0x1.3b2ab6fba4e77p-7);
-  p = __builtin_fma(p, f, 0x1.c6b08d704a0c0p-5);
-  p = __builtin_fma(p, f, 0x1.ebfbdff82c58fp-3);
-  p = __builtin_fma(p, f, 0x1.62e42fefa39efp-1);
-  p = __builtin_fma(p, f, 1.0);
-  return __builtin_ldexp(p, (int)k);
+  const double in[1] = {P};
+  double out[1];
+  fast_exp2_n<1>(in, out);
+  return out[0];
 }
 
 // Ziv test: may y (relative error < 2^-38) be rounded to float without knowing its last bits?
@@ -160,42 +204,95 @@ __device__ __attribute__((noinline)) float srgb_inv_oetf_slow(float e) { return 
 __device__ __attribute__((noinline)) float hlg_inv_oetf_slow(float e) { return hlg_inv_oetf_exact(e); }
 __device__ __attribute__((noinline)) float pq_inv_oetf_slow(float e) { return pq_inv_oetf_exact(e); }
 
+template <int N>
+__device__ __forceinline__ void srgb_inv_oetf_guarded_n(float (&e)[N]) {
+  float lin[N];
+  double xd[N], y[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    lin[j] = div_const(e[j], 12.92f, 1.0f / 12.92f);
+    // the fma remainder of div_const underflows for |e| < ~7e-32 (selftest): such values (never produced by
+    // 8-bit content, but representable) take the hardware IEEE division
+    if (e[j] != 0.0f && e[j] < 0x1p-100f) lin[j] = e[j] / 12.92f;
+    xd[j] = (double)div_const(e[j] + 0.055f, 1.055f, 1.0f / 1.055f);
+  }
+  fast_log2_n<N>(xd, y);
+#pragma unroll
+  for (int j = 0; j < N; ++j) y[j] *= 2.4;
+  fast_exp2_n<N>(y, y);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float p = (float)y[j];
+    if (e[j] > 0.04045f && !ziv_safe(y[j])) p = srgb_inv_oetf_slow(e[j]);
+    e[j] = (e[j] <= 0.04045f) ? lin[j] : p;
+  }
+}
 __device__ __forceinline__ float srgb_inv_oetf_guarded(float e) {
-  float lin = div_const(e, 12.92f, 1.0f / 12.92f);
-  // the fma remainder of div_const underflows for |e| < ~7e-32 (selftest): such values (never produced by
-  // 8-bit content, but representable) take the hardware IEEE division
-  if (e != 0.0f && e < 0x1p-100f) lin = e / 12.92f;
-  const float x = div_const(e + 0.055f, 1.055f, 1.0f / 1.055f);
-  const double y = fast_exp2(2.4 * fast_log2((double)x));
-  float p = (float)y;
-  if (e > 0.04045f && !ziv_safe(y)) p = srgb_inv_oetf_slow(e);
-  return (e <= 0.04045f) ? lin : p;
+  float v[1] = {e};
+  srgb_inv_oetf_guarded_n<1>(v);
+  return v[0];
 }
 
+template <int N>
+__device__ __forceinline__ void hlg_inv_oetf_guarded_n(float (&e)[N]) {
+  float lo[N];
+  double y[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    // e <= 0.5: (e*e)/3 in double, division by 3 as q + fma(-q,3,t)/3 (exact; selftest)
+    const double t = (double)e[j] * (double)e[j];
+    const double q0 = t * 0x1.5555555555555p-2;
+    lo[j] = (float)__builtin_fma(__builtin_fma(-q0, 3.0, t), 0x1.5555555555555p-2, q0);
+    // e > 0.5: (exp((e-c)/a) + b) / 12
+    y[j] = (double)div_const(e[j] - UHDR_HLG_C, UHDR_HLG_A, 1.0f / UHDR_HLG_A) * 0x1.71547652b82fep+0;
+  }
+  fast_exp2_n<N>(y, y);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double yy = (y[j] + (double)UHDR_HLG_B) * (1.0 / 12.0);
+    float hi = (float)yy;
+    if (e[j] > 0.5f && !ziv_safe(yy)) hi = hlg_inv_oetf_slow(e[j]);
+    e[j] = (e[j] <= 0.5f) ? lo[j] : hi;
+  }
+}
 __device__ __forceinline__ float hlg_inv_oetf_guarded(float e) {
-  // e <= 0.5: (e*e)/3 in double, division by 3 as q + fma(-q,3,t)/3 (exact; selftest)
-  const double t = (double)e * (double)e;
-  const double q0 = t * 0x1.5555555555555p-2;
-  const float lo = (float)__builtin_fma(__builtin_fma(-q0, 3.0, t), 0x1.5555555555555p-2, q0);
-  // e > 0.5: (exp((e-c)/a) + b) / 12
-  const float v = div_const(e - UHDR_HLG_C, UHDR_HLG_A, 1.0f / UHDR_HLG_A);
-  const double y = (fast_exp2((double)v * 0x1.71547652b82fep+0) + (double)UHDR_HLG_B) * (1.0 / 12.0);
-  float hi = (float)y;
-  if (e > 0.5f && !ziv_safe(y)) hi = hlg_inv_oetf_slow(e);
-  return (e <= 0.5f) ? lo : hi;
+  float v[1] = {e};
+  hlg_inv_oetf_guarded_n<1>(v);
+  return v[0];
 }
 
+template <int N>
+__device__ __forceinline__ void pq_inv_oetf_guarded_n(float (&e)[N]) {
+  double t[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = (double)((e[j] <= 0.0001f) ? 1.0f : e[j]);
+  fast_log2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] *= (double)0.0126833f;
+  fast_exp2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double num = __builtin_fma(128.0, t[j], -107.0), den = __builtin_fma(-2392.0, t[j], 2413.0);
+    double r = (double)__builtin_amdgcn_rcpf((float)den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    t[j] = num * r;
+  }
+  fast_log2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] *= (double)6.2773946361f;
+  fast_exp2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float o = (float)t[j];
+    if (e[j] > 0.0001f && !ziv_safe(t[j])) o = pq_inv_oetf_slow(e[j]);
+    e[j] = (e[j] <= 0.0001f) ? 0.0f : o;
+  }
+}
 __device__ __forceinline__ float pq_inv_oetf_guarded(float e) {
-  const float es = (e <= 0.0001f) ? 1.0f : e;
-  const double p = fast_exp2((double)0.0126833f * fast_log2((double)es));
-  const double num = __builtin_fma(128.0, p, -107.0), den = __builtin_fma(-2392.0, p, 2413.0);
-  double r = (double)__builtin_amdgcn_rcpf((float)den);
-  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-  const double y = fast_exp2((double)6.2773946361f * fast_log2(num * r));
-  float o = (float)y;
-  if (e > 0.0001f && !ziv_safe(y)) o = pq_inv_oetf_slow(e);
-  return (e <= 0.0001f) ? 0.0f : o;
+  float v[1] = {e};
+  pq_inv_oetf_guarded_n<1>(v);
+  return v[0];
 }
 
 // ---- encodeGain (gainmapmath.cpp:529-541) ------------------------------------------------------

@@ -42,6 +42,11 @@ constexpr float kP3Cb = 1.772f, kP3Cr = 1.402f;
 constexpr float kP3GCb = kP3YB * kP3Cb / kP3YG;
 constexpr float kP3GCr = kP3YR * kP3Cr / kP3YG;
 
+// two floats per lane: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 process both in one 4-cycle issue slot
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+
 // =================================================================================================
 // generate
 // =================================================================================================
@@ -53,70 +58,116 @@ __device__ __forceinline__ float hdr_inv_oetf(float e) {
   return e;  // ULTRAHDR_TF_LINEAR: identityConversion (ultrahdr.cpp:223-228)
 }
 
-// One map pixel from its 4x4 block.  hy[r][0|1]: P010 luma cols (0,1)|(2,3) packed lo/hi 16 bits;
-// huv[r][0|1]: (U,V) of chroma col 0|1 for chroma row r; y8[r]: 4 luma bytes; u8/v8[r]: 2 chroma
-// bytes in bits 0-15.  Accumulation order is samplePixels' (gainmapmath.cpp:605-615): dy outer,
+// Two horizontally adjacent map pixels (index 0|1 of every array) from their 4x4 blocks, processed as one
+// packed float2 wherever the arithmetic is float: both pixels run the identical IEEE operation sequence,
+// so packing changes nothing but the issue count.  hy[k][r][0|1]: P010 luma cols (0,1)|(2,3) packed lo/hi
+// 16 bits; huv[k][r][0|1]: (U,V) of chroma col 0|1 of chroma row r; y8[k][r]: 4 luma bytes; u8/v8[k][r]:
+// 2 chroma bytes in bits 0-15.  Accumulation order is samplePixels' (gainmapmath.cpp:605-615): dy outer,
 // dx inner, one running float sum per channel.
+__device__ __forceinline__ float clampf(float v) { return (v < 0.0f) ? 0.0f : (v > 1.0f) ? 1.0f : v; }
+__device__ __forceinline__ f2 clamp2(f2 v) { return (f2){clampf(v.x), clampf(v.y)}; }
+
 template <int TF>
-__device__ __forceinline__ void gen_px(const GenConsts& c, const uint32_t (&hy)[4][2],
-                                       const uint32_t (&huv)[2][2], const uint32_t (&y8)[4],
-                                       const uint32_t (&u8)[2], const uint32_t (&v8)[2],
-                                       uint8_t& out, float& gain) {
-  float sy = 0.0f, su = 0.0f, sv = 0.0f;
-  float hsy = 0.0f, hsu = 0.0f, hsv = 0.0f;
+__device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy)[2][4][2],
+                                         const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
+                                         const uint32_t (&u8)[2][2], const uint32_t (&v8)[2][2],
+                                         uint8_t (&out)[2], float (&gain)[2]) {
+  f2 sy = splat(0.0f), su = splat(0.0f), sv = splat(0.0f);
+  f2 hsy = splat(0.0f), hsu = splat(0.0f), hsv = splat(0.0f);
 #pragma unroll
-  for (int dy = 0; dy < 4; ++dy) {
-    const int r = dy >> 1;
-    float uf[2], vf[2], huf[2], hvf[2];
+  for (int r = 0; r < 2; ++r) {
+    f2 uf[2], vf[2], huf[2], hvf[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      uf[k] = (float)((int)((u8[r] >> (8 * k)) & 0xffu) - 128) * k255;   // gainmapmath.cpp:579-580
-      vf[k] = (float)((int)((v8[r] >> (8 * k)) & 0xffu) - 128) * k255;
-      huf[k] = (float)((int)((huv[r][k] & 0xffffu) >> 6) - 64) * k896 - 0.5f;  // :598-600
-      hvf[k] = (float)((int)(huv[r][k] >> 22) - 64) * k896 - 0.5f;
+      // float(u - 128) == float(u) - 128.0f exactly (small integers)   gainmapmath.cpp:579-580
+      const f2 ub = (f2){(float)((u8[0][r] >> (8 * k)) & 0xffu), (float)((u8[1][r] >> (8 * k)) & 0xffu)};
+      const f2 vb = (f2){(float)((v8[0][r] >> (8 * k)) & 0xffu), (float)((v8[1][r] >> (8 * k)) & 0xffu)};
+      uf[k] = (ub - splat(128.0f)) * splat(k255);
+      vf[k] = (vb - splat(128.0f)) * splat(k255);
+      // float((x >> 6) - 64) * (1/896) - 0.5                            gainmapmath.cpp:593-600
+      const f2 hu = (f2){(float)((huv[0][r][k] & 0xffffu) >> 6), (float)((huv[1][r][k] & 0xffffu) >> 6)};
+      const f2 hv = (f2){(float)(huv[0][r][k] >> 22), (float)(huv[1][r][k] >> 22)};
+      huf[k] = (hu - splat(64.0f)) * splat(k896) - splat(0.5f);
+      hvf[k] = (hv - splat(64.0f)) * splat(k896) - splat(0.5f);
     }
 #pragma unroll
-    for (int dx = 0; dx < 4; ++dx) {
-      sy += (float)((y8[dy] >> (8 * dx)) & 0xffu) * k255;
-      su += uf[dx >> 1];
-      sv += vf[dx >> 1];
-      const uint32_t y16 = (hy[dy][dx >> 1] >> (16 * (dx & 1))) & 0xffffu;
-      hsy += (float)((int)(y16 >> 6) - 64) * k876;
-      hsu += huf[dx >> 1];
-      hsv += hvf[dx >> 1];
+    for (int d = 0; d < 2; ++d) {
+      const int dy = 2 * r + d;
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const f2 yb = (f2){(float)((y8[0][dy] >> (8 * dx)) & 0xffu), (float)((y8[1][dy] >> (8 * dx)) & 0xffu)};
+        sy += yb * splat(k255);
+        su += uf[dx >> 1];
+        sv += vf[dx >> 1];
+        const f2 hb = (f2){(float)(((hy[0][dy][dx >> 1] >> (16 * (dx & 1))) & 0xffffu) >> 6),
+                           (float)(((hy[1][dy][dx >> 1] >> (16 * (dx & 1))) & 0xffffu) >> 6)};
+        hsy += (hb - splat(64.0f)) * splat(k876);
+        hsu += huf[dx >> 1];
+        hsv += hvf[dx >> 1];
+      }
     }
   }
-  // e / float(scale*scale)
-  sy = sy / 16.0f; su = su / 16.0f; sv = sv / 16.0f;
-  hsy = hsy / 16.0f; hsu = hsu / 16.0f; hsv = hsv / 16.0f;
+  // e / float(scale*scale): division by 16 == multiplication by 1/16 exactly
+  sy *= splat(0.0625f); su *= splat(0.0625f); sv *= splat(0.0625f);
+  hsy *= splat(0.0625f); hsu *= splat(0.0625f); hsv *= splat(0.0625f);
 
   // SDR: YUV->RGB (gainmapmath.cpp:142-146 shape), sRGB EOTF, luminance * 203 (ultrahdr.cpp:316-324)
-  float r = clamp01(sy + c.sdr_cr * sv);
-  float g = clamp01(sy - c.sdr_gcb * su - c.sdr_gcr * sv);
-  float b = clamp01(sy + c.sdr_cb * su);
-  r = srgb_inv_oetf_guarded(r);
-  g = srgb_inv_oetf_guarded(g);
-  b = srgb_inv_oetf_guarded(b);
-  const float sdr_nits = (c.lum_r * r + c.lum_g * g + c.lum_b * b) * 203.0f;
+  f2 r = clamp2(sy + splat(c.sdr_cr) * sv);
+  f2 g = clamp2(sy - splat(c.sdr_gcb) * su - splat(c.sdr_gcr) * sv);
+  f2 b = clamp2(sy + splat(c.sdr_cb) * su);
+  // independent f64 evaluations advanced in lock step: 6 = 3 channels x 2 pixels.  Measured on MI355X
+  // (scripts/ab): 6 -> 0.388 ms per 32-frame launch, 3 -> 0.432, 2 -> 0.490 although the narrower forms
+  // need fewer VGPRs (98 / 84 / 78): exposed f64 FMA latency costs more than the lost occupancy.
+#ifndef UHDR_LOCKSTEP
+#define UHDR_LOCKSTEP 6
+#endif
+  {
+    float ch[6] = {r.x, r.y, g.x, g.y, b.x, b.y};
+#pragma unroll
+    for (int i = 0; i < 6; i += UHDR_LOCKSTEP) {
+      float part[UHDR_LOCKSTEP];
+#pragma unroll
+      for (int j = 0; j < UHDR_LOCKSTEP; ++j) part[j] = ch[i + j];
+      srgb_inv_oetf_guarded_n<UHDR_LOCKSTEP>(part);
+#pragma unroll
+      for (int j = 0; j < UHDR_LOCKSTEP; ++j) ch[i + j] = part[j];
+    }
+    r = (f2){ch[0], ch[1]}; g = (f2){ch[2], ch[3]}; b = (f2){ch[4], ch[5]};
+  }
+  const f2 sdr_nits = (splat(c.lum_r) * r + splat(c.lum_g) * g + splat(c.lum_b) * b) * splat(203.0f);
 
   // HDR: YUV->RGB, inverse OETF, gamut conversion, luminance * white (ultrahdr.cpp:326-330)
-  float hr = clamp01(hsy + c.hdr_cr * hsv);
-  float hg = clamp01(hsy - c.hdr_gcb * hsu - c.hdr_gcr * hsv);
-  float hb = clamp01(hsy + c.hdr_cb * hsu);
-  hr = hdr_inv_oetf<TF>(hr);
-  hg = hdr_inv_oetf<TF>(hg);
-  hb = hdr_inv_oetf<TF>(hb);
+  f2 hr = clamp2(hsy + splat(c.hdr_cr) * hsv);
+  f2 hg = clamp2(hsy - splat(c.hdr_gcb) * hsu - splat(c.hdr_gcr) * hsv);
+  f2 hb = clamp2(hsy + splat(c.hdr_cb) * hsu);
+  if (TF != 0) {  // ULTRAHDR_TF_LINEAR: identityConversion (ultrahdr.cpp:223-228)
+    float ch[6] = {hr.x, hr.y, hg.x, hg.y, hb.x, hb.y};
+#pragma unroll
+    for (int i = 0; i < 6; i += UHDR_LOCKSTEP) {
+      float part[UHDR_LOCKSTEP];
+#pragma unroll
+      for (int j = 0; j < UHDR_LOCKSTEP; ++j) part[j] = ch[i + j];
+      if (TF == 1) hlg_inv_oetf_guarded_n<UHDR_LOCKSTEP>(part);
+      else pq_inv_oetf_guarded_n<UHDR_LOCKSTEP>(part);
+#pragma unroll
+      for (int j = 0; j < UHDR_LOCKSTEP; ++j) ch[i + j] = part[j];
+    }
+    hr = (f2){ch[0], ch[1]}; hg = (f2){ch[2], ch[3]}; hb = (f2){ch[4], ch[5]};
+  }
   if (!c.gm_identity) {
-    const float t0 = c.gm[0] * hr + c.gm[1] * hg + c.gm[2] * hb;
-    const float t1 = c.gm[3] * hr + c.gm[4] * hg + c.gm[5] * hb;
-    const float t2 = c.gm[6] * hr + c.gm[7] * hg + c.gm[8] * hb;
+    const f2 t0 = splat(c.gm[0]) * hr + splat(c.gm[1]) * hg + splat(c.gm[2]) * hb;
+    const f2 t1 = splat(c.gm[3]) * hr + splat(c.gm[4]) * hg + splat(c.gm[5]) * hb;
+    const f2 t2 = splat(c.gm[6]) * hr + splat(c.gm[7]) * hg + splat(c.gm[8]) * hb;
     hr = t0; hg = t1; hb = t2;
   }
-  const float hdr_nits = (c.lum_r * hr + c.lum_g * hg + c.lum_b * hb) * c.hdr_white_nits;
+  const f2 hdr_nits = (splat(c.lum_r) * hr + splat(c.lum_g) * hg + splat(c.lum_b) * hb) * splat(c.hdr_white_nits);
 
-  gain = raw_gain(sdr_nits, hdr_nits);
-  out = encode_gain_guarded(gain, c.min_boost, c.max_boost, c.log2_min, c.log2_max, c.enc_scale, c.enc_byte_min,
-                            c.enc_byte_max);
+  gain[0] = raw_gain(sdr_nits.x, hdr_nits.x);
+  gain[1] = raw_gain(sdr_nits.y, hdr_nits.y);
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    out[k] = encode_gain_guarded(gain[k], c.min_boost, c.max_boost, c.log2_min, c.log2_max, c.enc_scale, c.enc_byte_min,
+                                 c.enc_byte_max);
 }
 
 __device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
@@ -209,14 +260,12 @@ __global__ void __launch_bounds__(256) k_generate(const GenConsts c, const GenBa
       }
     }
 
-    uint8_t o0, o1 = 0;
-    float g0, g1;
-    gen_px<TF>(c, hy[0], huv[0], y8[0], u8[0], v8[0], o0, g0);
-    gmin = g0; gmax = g0;
-    if (two) {
-      gen_px<TF>(c, hy[1], huv[1], y8[1], u8[1], v8[1], o1, g1);
-      gmin = fminf(gmin, g1); gmax = fmaxf(gmax, g1);
-    }
+    uint8_t o[2];
+    float gn[2];
+    gen_pair<TF>(c, hy, huv, y8, u8, v8, o, gn);   // a missing second pixel is computed on zeros and dropped
+    const uint8_t o0 = o[0], o1 = o[1];
+    gmin = gn[0]; gmax = gn[0];
+    if (two) { gmin = fminf(gmin, gn[1]); gmax = fmaxf(gmax, gn[1]); }
     uint8_t* mp = im.map + (size_t)my * c.map_w + mx;
     if (ALIGNED) {
       *reinterpret_cast<uint16_t*>(mp) = (uint16_t)(o0 | ((uint32_t)o1 << 8));
@@ -327,10 +376,6 @@ __device__ __forceinline__ float map_to_float(uint32_t v) { return (float)v / 25
 //     with the products w_i*A pre-multiplied on the host (AppFast::wA, SGPR operands);
 //   * the *1023 of the 10-bit pack is folded into the OETF constants;
 //   * clamps are written as min(max()) so that they fold into the producing add's clamp modifier.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
 __device__ __forceinline__ float sat01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 __device__ __forceinline__ f2 log2_2(f2 v) { return (f2){__builtin_amdgcn_logf(v.x), __builtin_amdgcn_logf(v.y)}; }
 __device__ __forceinline__ f2 exp2_2(f2 v) { return (f2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }

@@ -173,6 +173,18 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
 __device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
 __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *p; }
 
+#ifndef UHDR_GEN_BLOCK
+#define UHDR_GEN_BLOCK 256
+#endif
+// launch geometry of k_generate, chosen by same-box A/B (scripts/ab, ms per 32-frame 4K launch):
+//   block 64/128/256/512/1024, 1 span: 0.64 / 0.50 / 0.39 / 0.355 / 0.43;   block 256, 4 spans: 0.350
+#ifndef UHDR_GEN_TILES
+#define UHDR_GEN_TILES 4
+#endif
+#ifndef UHDR_GEN_MINWAVES
+#define UHDR_GEN_MINWAVES 1
+#endif
+
 // wave64 butterfly min/max, then one LDS slot per wave, then (rarely) one atomic pair per block
 __device__ __forceinline__ void block_minmax_to_keys(float gmin, float gmax, uint32_t* keys) {
 #pragma unroll
@@ -180,13 +192,14 @@ __device__ __forceinline__ void block_minmax_to_keys(float gmin, float gmax, uin
     gmin = fminf(gmin, __shfl_xor(gmin, off, 64));
     gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
   }
-  __shared__ float s_min[4], s_max[4];
+  constexpr int kWaves = UHDR_GEN_BLOCK / 64;
+  __shared__ float s_min[kWaves], s_max[kWaves];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { s_min[wave] = gmin; s_max[wave] = gmax; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    gmin = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
-    gmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) { gmin = fminf(gmin, s_min[w]); gmax = fmaxf(gmax, s_max[w]); }
     if (gmin <= gmax) {  // block saw at least one pixel
       // keys[0] holds ~key(min), keys[1] holds key(max); both only grow, both start at 0.
       const uint32_t kmin = ~float_to_key(gmin), kmax = float_to_key(gmax);
@@ -203,14 +216,18 @@ __device__ __forceinline__ void block_minmax_to_keys(float gmin, float gmax, uin
 // A wave64 therefore consumes 1 KiB contiguous per P010 row (dwordx4/lane), 512 B per 8-bit luma
 // row (dwordx2/lane) and 256 B per chroma row (dword/lane).
 template <int TF, bool ALIGNED>
-__global__ void __launch_bounds__(256) k_generate(const GenConsts c, const GenBatch b) {
+__global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(const GenConsts c, const GenBatch b) {
   const GenImage& im = b.img[blockIdx.y];
   const uint32_t pairs_per_row = (c.map_w + 1u) >> 1;
   const uint32_t total = pairs_per_row * c.map_h;
-  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
   float gmin = __builtin_inff(), gmax = -__builtin_inff();
 
-  if (idx < total) {
+  // each block walks UHDR_GEN_TILES consecutive spans of UHDR_GEN_BLOCK pairs: fewer, longer-lived waves
+  // (wave launch + descriptor fetch is a measurable share of a ~10 us wave)
+#pragma unroll 1
+  for (uint32_t t = 0; t < (uint32_t)UHDR_GEN_TILES; ++t) {
+    const uint32_t idx = (blockIdx.x * (uint32_t)UHDR_GEN_TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
+    if (idx >= total) break;
     const uint32_t my = idx / pairs_per_row;
     const uint32_t pr = idx - my * pairs_per_row;
     const uint32_t mx = pr * 2u;
@@ -264,7 +281,7 @@ __global__ void __launch_bounds__(256) k_generate(const GenConsts c, const GenBa
     float gn[2];
     gen_pair<TF>(c, hy, huv, y8, u8, v8, o, gn);   // a missing second pixel is computed on zeros and dropped
     const uint8_t o0 = o[0], o1 = o[1];
-    gmin = gn[0]; gmax = gn[0];
+    gmin = fminf(gmin, gn[0]); gmax = fmaxf(gmax, gn[0]);
     if (two) { gmin = fminf(gmin, gn[1]); gmax = fmaxf(gmax, gn[1]); }
     uint8_t* mp = im.map + (size_t)my * c.map_w + mx;
     if (ALIGNED) {
@@ -291,7 +308,8 @@ template <int TF, bool ALIGNED>
 static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   if (total == 0 || n == 0) return hipSuccess;
-  dim3 grid((total + 255u) / 256u, (unsigned)n, 1), block(256, 1, 1);
+  constexpr uint32_t kSpan = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
+  dim3 grid((total + kSpan - 1u) / kSpan, (unsigned)n, 1), block(UHDR_GEN_BLOCK, 1, 1);
   hipLaunchKernelGGL((k_generate<TF, ALIGNED>), grid, block, 0, s, c, b);
   return hipGetLastError();
 }

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=64, help="4K frame pairs resident per GPU")
     ap.add_argument("--apply-format", default="hlg", choices=["hlg", "pq"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the extra configs[1]/[4] timings (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same batch timed on the host CPU")
     return ap.parse_args()
 
@@ -100,6 +101,47 @@ class Batch:
             if events is not None:
                 e1.record()
                 events.append((e0, e1, m))
+
+
+def other_configs(lib, stream):
+    """BASELINE configs[1] and configs[4] timed outside the headline region (reported, not `value`):
+    single 4K HLG generate latency, and 8K applyGainMap -> RGBA1010102 PQ / RGBA-F16 (max boost 10000/203)."""
+    out = {}
+
+    def timed(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    # configs[1]: one 3840x2160 pair, generate only
+    p, y = synth.lcg_frame(W, H, 1234)
+    m = torch.zeros((W // 4) * (H // 4), dtype=torch.uint8, device="cuda")
+    yi, pi = api.yuv420_image(y.data_ptr(), W, H, api.CG_BT709), api.p010_image(p.data_ptr(), W, H, api.CG_BT2100)
+    mi, md = api.out_image(m.data_ptr()), api.Metadata()
+    ms = timed(lambda: lib.uhdr_hip_generate_gainmap(C.byref(yi), C.byref(pi), api.TF_HLG, C.byref(md), C.byref(mi), 0,
+                                                     api.MEM_DEVICE, stream))
+    out["configs[1] single 4K HLG generate"] = {"ms": round(ms, 4), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1),
+                                                "GB/s": round(GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    # configs[4]: 7680x4320 decode-side apply
+    w8, h8 = 7680, 4320
+    _, y8 = synth.lcg_frame(w8, h8, 1234)
+    m8 = torch.randint(0, 256, ((w8 // 4) * (h8 // 4),), dtype=torch.uint8, device="cuda")
+    o8 = torch.zeros(w8 * h8 * 8, dtype=torch.uint8, device="cuda")
+    yi8, mi8, oi8 = api.yuv420_image(y8.data_ptr(), w8, h8, api.CG_BT709), api.mono_image(m8.data_ptr(), w8 // 4, h8 // 4), api.out_image(o8.data_ptr())
+    md8 = api.metadata(float(np.float32(10000.0) / np.float32(203.0)))
+    for name, fmt, bpp in (("PQ RGBA1010102", api.OUTPUT_HDR_PQ, 4), ("linear RGBA-F16", api.OUTPUT_HDR_LINEAR, 8)):
+        ms = timed(lambda: lib.uhdr_hip_apply_gainmap(C.byref(yi8), C.byref(mi8), C.byref(md8), fmt, api.FLT_MAX, C.byref(oi8),
+                                                      api.APPLY_FAST, api.MEM_DEVICE, stream), 10)
+        nbytes = w8 * h8 * 3 // 2 + (w8 // 4) * (h8 // 4) + w8 * h8 * bpp
+        out["configs[4] 8K apply -> " + name] = {"ms": round(ms, 4), "MPix/s": round(w8 * h8 / 1e6 / (ms * 1e-3), 1),
+                                                  "GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1)}
+    return out
 
 
 def cpu_baseline(batch, fmt, nframes):
@@ -249,6 +291,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, fmt, max(1, min(a.cpu_frames, a.frames)))
+        if world == 1 and not a.no_other_configs:
+            out["other_configs"] = other_configs(lib, stream)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,16 +1,19 @@
 #!/bin/bash
-# rocprofv3 passes over the bench command (run on the GPU box from the repo root).
-# 1) --kernel-trace --stats  2) --pmc FETCH_SIZE  3) --pmc WRITE_SIZE  4) SQ instruction mix
+# rocprofv3 passes over the bench command (run on the GPU box from the repo root):
+#   1) --kernel-trace --stats   2) --pmc FETCH_SIZE   3) --pmc WRITE_SIZE   4) SQ instruction mix   5) clocks / L2
+# Counters are collected in their own runs (never combined with trace domains other than kernel-trace).
+# usage: profile_bench.sh <tag>   -> gpurun_out/prof_<tag>.{txt,json} (+ traffic json)
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof
+TAG=${1:-run}
+OUT=$R/gpurun_out/prof_raw_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 4 --warmup 1 --no-cpu-baseline"
+ARGS="$R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVES --output-format csv -d $OUT/pmc_sq -- python3 $ARGS > $OUT/pmc_sq.log 2>&1
-find $OUT -name "*.csv" | head -50
-python3 $R/scripts/summarize_prof.py $OUT $R/gpurun_out/prof_summary
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_clk -- python3 $ARGS > $OUT/pmc_clk.log 2>&1 || true
+python3 $R/scripts/summarize_prof.py $OUT $R/gpurun_out/prof_$TAG
+rm -rf $OUT

@@ -38,7 +38,7 @@ summary["our_kernels_trace"] = {n: {"dispatches": len(v), "avg_ns": sum(v) / len
                                 for n, v in tr.items()}
 
 # PMC passes: average per dispatch per kernel
-for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(prof, tag, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -48,6 +48,19 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
             acc[short(n)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     summary[tag] = {n: {c: {"avg_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in d.items()} for n, d in acc.items()}
 
+# HBM traffic per launch of the two hot kernels.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies
+# 128-B read requests at 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
+traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 4 --warmup 1`; "
+                     "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch of 32 4K frames"}
+for key, pat in (("generate", "k_generate"), ("apply", "k_apply_s4")):
+    f = [v["FETCH_SIZE"]["avg_per_dispatch"] for n, v in summary.get("pmc_fetch", {}).items() if pat in n and "FETCH_SIZE" in v]
+    w = [v["WRITE_SIZE"]["avg_per_dispatch"] for n, v in summary.get("pmc_write", {}).items() if pat in n and "WRITE_SIZE" in v]
+    if f and w:
+        traffic[key] = int(2 * f[0] * 1024 + w[0] * 1024)
+        traffic[key + "_read_bytes"] = int(2 * f[0] * 1024)
+        traffic[key + "_write_bytes"] = int(w[0] * 1024)
+summary["traffic"] = traffic
+json.dump(traffic, open(outp + "_traffic.json", "w"), indent=1)
 json.dump(summary, open(outp + ".json", "w"), indent=1)
 with open(outp + ".txt", "w") as o:
     o.write("== rocprofv3 --kernel-trace --stats: top kernels ==\n")
@@ -56,10 +69,11 @@ with open(outp + ".txt", "w") as o:
     o.write("\n== our kernels (per dispatch) ==\n")
     for n, v in summary["our_kernels_trace"].items():
         o.write("%s\n   %s\n" % (n, json.dumps(v)))
-    for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
         o.write("\n== %s (avg per dispatch) ==\n" % tag)
         for n, d in summary[tag].items():
             o.write("%s\n" % n)
             for c, v in d.items():
                 o.write("   %-24s %18.1f  (n=%d)\n" % (c, v["avg_per_dispatch"], v["dispatches"]))
+    o.write("\n== HBM traffic per launch ==\n%s\n" % json.dumps(traffic, indent=1))
 print(open(outp + ".txt").read())

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64, help="4K frame pairs resident per GPU")
     ap.add_argument("--apply-format", default="hlg", choices=["hlg", "pq"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only to rehearse "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra configs[1]/[4] timings (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same batch timed on the host CPU")
@@ -204,10 +206,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    dev = local if local < ndev else local % ndev     # rehearsal on fewer GPUs than ranks shares devices (gloo only)
+    assert a.backend != "nccl" or local < ndev, "RCCL needs one GPU per rank"
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    lib = api.init(local)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(a.backend)
+    lib = api.init(dev)
     fmt = api.OUTPUT_HDR_HLG if a.apply_format == "hlg" else api.OUTPUT_HDR_PQ
 
     batch = Batch(lib, a.frames, rank)
@@ -216,10 +224,14 @@ def main():
 
     def step(ev_gen=None, ev_app=None):
         batch.generate(stream, ev_gen)
+        work = None
         if world > 1:
-            # the path's only exchange: batch-wide content min / max boost (8 bytes, latency-bound)
-            sharding.reduce_content_minmax(batch.minmax, dist, red)
+            # the path's only exchange: batch-wide content min / max boost (8 bytes, latency-bound); it is
+            # enqueued asynchronously so that it overlaps the apply kernels, and joined at the end of the step
+            _, work = sharding.reduce_content_minmax(batch.minmax, dist, red, async_op=True)
         batch.apply(stream, fmt, ev_app)
+        if world > 1:
+            sharding.finish_content_minmax(red, work)
 
     for _ in range(a.warmup):
         step()

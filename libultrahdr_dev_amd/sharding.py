@@ -19,9 +19,11 @@ def image_seed(global_index, base_seed=1234):
     return base_seed + global_index
 
 
-def reduce_content_minmax(per_image_minmax, dist=None, scratch=None):
+def reduce_content_minmax(per_image_minmax, dist=None, scratch=None, async_op=False):
     """per_image_minmax: float32 tensor [2*n] = (min_0, max_0, min_1, ...) of this rank's images.
-    Returns a 2-element tensor (global min, global max).  One all-reduce(MIN) on (min, -max)."""
+    Returns a 2-element tensor (global min, global max).  One all-reduce(MIN) on (min, -max).
+    With async_op=True returns (scratch, work): the collective overlaps whatever the caller enqueues next;
+    finish with finish_content_minmax(scratch, work)."""
     mm = per_image_minmax.view(-1, 2)
     red = scratch if scratch is not None else torch.empty(2, dtype=torch.float32, device=per_image_minmax.device)
     if mm.shape[0] == 0:
@@ -30,8 +32,17 @@ def reduce_content_minmax(per_image_minmax, dist=None, scratch=None):
     else:
         red[0] = mm[:, 0].min()
         red[1] = -mm[:, 1].max()
+    work = None
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(red, op=dist.ReduceOp.MIN)
+        work = dist.all_reduce(red, op=dist.ReduceOp.MIN, async_op=async_op)
+    if async_op:
+        return red, work
+    return finish_content_minmax(red, None)
+
+
+def finish_content_minmax(red, work):
+    if work is not None:
+        work.wait()
     out = red.clone()
     out[1] = -out[1]
     return out

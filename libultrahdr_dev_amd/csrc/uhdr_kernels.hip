@@ -447,12 +447,20 @@ __device__ __forceinline__ PairOut apply_pair(f2 yf, float crv, float gsum, floa
   return o;
 }
 
-__device__ __forceinline__ uint32_t pack10_scaled(float r, float g, float b) {  // inputs already *1023
-  const uint32_t ri = (uint32_t)r, gi = (uint32_t)g, bi = (uint32_t)b;
-  return (ri & 0x3ffu) | ((gi & 0x3ffu) << 10) | ((bi & 0x3ffu) << 20) | 0xC0000000u;
+// inputs already *1023.  The reference's `& 0x3ff` (gainmapmath.cpp:723-725) can only bite when a channel
+// reaches 1024, i.e. when max_display_boost < maxContentBoost lets values exceed 1.0; MASK is a per-call
+// (wave-uniform) property, so the common case packs with two v_lshl_or_b32 and one v_or_b32.
+template <bool MASK>
+__device__ __forceinline__ uint32_t pack10_scaled(float r, float g, float b) {
+  uint32_t ri = (uint32_t)r, gi = (uint32_t)g, bi = (uint32_t)b;
+  if (MASK) { ri &= 0x3ffu; gi &= 0x3ffu; bi &= 0x3ffu; }
+  uint32_t t;  // hipcc splits (g << 10) | r into a shift and an or; v_lshl_or_b32 does it in one slot
+  asm("v_lshl_or_b32 %0, %1, 10, %2" : "=v"(t) : "v"(gi), "v"(ri));
+  asm("v_lshl_or_b32 %0, %1, 20, %2" : "=v"(t) : "v"(bi), "v"(t));
+  return t | 0xC0000000u;
 }
 
-template <int FMT, bool INTERIOR>
+template <int FMT, bool INTERIOR, bool MASK>
 __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
                                            const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
                                            float e1, float e2, float e3, float e4, int tbl) {
@@ -490,8 +498,8 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
     const size_t pix0 = (size_t)(4u * cy + oy) * c.width + 4u * cx;
     if (FMT == 2 || FMT == 3) {
       uint4 o;
-      o.x = pack10_scaled(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled(po[0].r.y, po[0].g.y, po[0].b.y);
-      o.z = pack10_scaled(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled(po[1].r.y, po[1].g.y, po[1].b.y);
+      o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
+      o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
       *reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0) = o;
     } else if (FMT == 1) {
       const uint2 a = pack_f16(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16(po[0].r.y, po[0].g.y, po[0].b.y);
@@ -513,7 +521,7 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
   }
 }
 
-template <int FMT>
+template <int FMT, bool MASK>
 __global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBatch b) {
   const AppImage& im = b.img[blockIdx.y];
   const uint32_t total = c.map_w * c.map_h;
@@ -541,10 +549,12 @@ __global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBa
   const bool edge_x = (xu == cx), edge_y = (yu == cy);
   const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
   // all waves but those touching the last column/row of cells take the SGPR-weight path
-  if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull)
-    apply_cell<FMT, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0);
-  else
-    apply_cell<FMT, false>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, tbl);
+  if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) {
+    if (MASK) apply_cell<FMT, true, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0);
+    else apply_cell<FMT, true, false>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0);
+  } else {
+    apply_cell<FMT, false, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, tbl);
+  }
 }
 
 // General path: one thread per pixel; any integer scale, any pointer/stride alignment, FAST or
@@ -600,7 +610,10 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, b
   if (n == 0 || c.width == 0 || c.height == 0) return hipSuccess;
   if (fast_s4 && !exact) {
     const uint32_t total = c.map_w * c.map_h;
-    hipLaunchKernelGGL((k_apply_s4<FMT>), dim3((total + 255u) / 256u, n), dim3(256), 0, s, c, b);
+    // channels can only reach 1024 (and wrap through the reference's & 0x3ff) when the display boost is
+    // capped below the content boost
+    if (c.display_boost < c.max_boost) hipLaunchKernelGGL((k_apply_s4<FMT, true>), dim3((total + 255u) / 256u, n), dim3(256), 0, s, c, b);
+    else hipLaunchKernelGGL((k_apply_s4<FMT, false>), dim3((total + 255u) / 256u, n), dim3(256), 0, s, c, b);
   } else {
     const size_t total = (size_t)c.width * c.height;
     const dim3 grid((unsigned)((total + 255u) / 256u), n);

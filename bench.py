@@ -32,7 +32,7 @@ import torch
 from libultrahdr_dev_amd import api, sharding, synth
 
 W, H = 3840, 2160
-CHUNK = 32                       # images per kernel launch (kMaxChunk in csrc/uhdr_kernels.h)
+CHUNK = 64                       # images per kernel launch (kMaxChunk in csrc/uhdr_kernels.h)
 # algorithmic HBM bytes per 4K frame: every input byte read once, every output written once
 GEN_BYTES = W * H * 3 + W * H * 3 // 2 + (W // 4) * (H // 4)           # 24 883 200 + 12 441 600 + 518 400
 APP_BYTES = W * H * 3 // 2 + (W // 4) * (H // 4) + W * H * 4           # 12 441 600 + 518 400 + 33 177 600

@@ -234,27 +234,27 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   encode_constants(c.min_boost, c.max_boost, c.log2_min, c.log2_max, &c.enc_scale, &c.enc_byte_min, &c.enc_byte_max);
   c.width = (uint32_t)w; c.height = (uint32_t)h;
   c.map_w = (uint32_t)(w / 4); c.map_h = (uint32_t)(h / 4);
+  c.stat_keys = nullptr;
   return c;
 }
 
-GenImage gen_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& p010, void* map, uint32_t* keys) {
+GenImage gen_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& p010, void* map) {
   GenImage g;
   g.y = static_cast<const uint8_t*>(yuv.data);
   g.u = static_cast<const uint8_t*>(yuv.chroma_data);
-  g.v = g.u + yuv.chroma_stride * (yuv.height / 2);  // gainmapmath.cpp:568
   g.hy = static_cast<const uint16_t*>(p010.data);
   g.huv = static_cast<const uint16_t*>(p010.chroma_data);
   g.map = static_cast<uint8_t*>(map);
-  g.stat_keys = keys;
   g.y_stride = (uint32_t)yuv.luma_stride;
   g.c_stride = (uint32_t)yuv.chroma_stride;
   g.hy_stride = (uint32_t)(p010.luma_stride == 0 ? p010.width : p010.luma_stride);  // gainmapmath.cpp:585
   g.huv_stride = (uint32_t)p010.chroma_stride;
   return g;
 }
-bool gen_aligned(const GenImage& g, uint32_t w) {
+bool gen_aligned(const GenImage& g, uint32_t w, uint32_t h) {
+  const uint8_t* v = g.u + (size_t)g.c_stride * (h / 2u);
   return (w % 8u == 0) && al(g.hy, 16) && g.hy_stride % 8u == 0 && al(g.huv, 16) && g.huv_stride % 8u == 0 &&
-         al(g.y, 8) && g.y_stride % 8u == 0 && al(g.u, 4) && al(g.v, 4) && g.c_stride % 4u == 0 && al(g.map, 2);
+         al(g.y, 8) && g.y_stride % 8u == 0 && al(g.u, 4) && al(v, 4) && g.c_stride % 4u == 0 && al(g.map, 2);
 }
 
 // ---- apply ---------------------------------------------------------------------------------------
@@ -500,7 +500,8 @@ int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const u
   while (i < n) {
     // chunk = up to kMaxChunk consecutive images of identical size, gamuts and alignment class
     const uhdr_hip_image_t& y0 = yuvs[i];
-    const GenConsts c = generate_consts(y0.colorGamut, p010s[i].colorGamut, hdr_tf, sdr_is_601, y0.width, y0.height, *metadata);
+    GenConsts c = generate_consts(y0.colorGamut, p010s[i].colorGamut, hdr_tf, sdr_is_601, y0.width, y0.height, *metadata);
+    c.stat_keys = keys ? keys + 2 * i : nullptr;
     GenBatch b;
     int m = 0;
     bool aligned = true;
@@ -509,8 +510,8 @@ int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const u
       if (y.width != y0.width || y.height != y0.height || y.colorGamut != y0.colorGamut ||
           p010s[i + m].colorGamut != p010s[i].colorGamut)
         break;
-      b.img[m] = gen_image(y, p010s[i + m], dests[i + m].data, keys ? keys + 2 * (i + m) : nullptr);
-      const bool a = gen_aligned(b.img[m], c.width);
+      b.img[m] = gen_image(y, p010s[i + m], dests[i + m].data);
+      const bool a = gen_aligned(b.img[m], c.width, c.height);
       if (m == 0) aligned = a;
       else if (a != aligned) break;
       fill_generate_dest(&y, &dests[i + m]);

@@ -94,15 +94,34 @@ __device__ __forceinline__ float pq_inv_oetf_exact(float e) {
 // the exact path returns; uhdr_hip_selftest() verifies that exhaustively over the input domains.
 // =================================================================================================
 
-// Horner step with the coefficient in an SGPR pair.  v_fma_f64 cannot take a 64-bit literal; left to itself
+// Horner steps with the coefficient in an SGPR pair.  v_fma_f64 cannot take a 64-bit literal; left to itself
 // hipcc materialises every constant addend with two v_mov_b32 into the destination of a v_fmac_f64
-// (3 VALU slots per step -- 18 % of k_generate's VALU instructions in the first version), and a
-// __constant__ table costs a scalar-memory round trip per call site.  The "s" constraint makes the
-// compiler build the constant with s_mov_b32 on the scalar ALU, and the step is one VOP3 v_fma_f64.
-__device__ __forceinline__ double fma_sc(double a, double b, double c_in_sgprs) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_in_sgprs));
-  return r;
+// (3 VALU slots per step -- 18 % of k_generate's VALU instructions in the first version); a __constant__
+// table costs a scalar-memory round trip per call site; and constants handed to the compiler in SGPRs get
+// hoisted out of the span loop, where 44 live SGPRs push the kernel over the SGPR file and into
+// v_writelane/v_readlane spills (90 VALU instructions).  So each step is ONE asm statement: two s_mov_b32
+// into a reserved scratch pair (scalar ALU, off the VALU pipe) followed by the N independent v_fma_f64 of
+// the lock-step group.
+template <uint32_t HI, uint32_t LO, int N>
+__device__ __forceinline__ void horner_step(double (&p)[N], const double (&x)[N]) {
+  static_assert(N == 1 || N == 2 || N == 3 || N == 6, "lock-step width");
+#define UHDR_SETC "s_mov_b32 s96, %[lo]\n\ts_mov_b32 s97, %[hi]\n\t"
+  if constexpr (N == 1) {
+    asm(UHDR_SETC "v_fma_f64 %0, %0, %1, s[96:97]" : "+v"(p[0]) : "v"(x[0]), [lo] "i"(LO), [hi] "i"(HI) : "s96", "s97");
+  } else if constexpr (N == 2) {
+    asm(UHDR_SETC "v_fma_f64 %0, %0, %2, s[96:97]\n\tv_fma_f64 %1, %1, %3, s[96:97]"
+        : "+v"(p[0]), "+v"(p[1]) : "v"(x[0]), "v"(x[1]), [lo] "i"(LO), [hi] "i"(HI) : "s96", "s97");
+  } else if constexpr (N == 3) {
+    asm(UHDR_SETC "v_fma_f64 %0, %0, %3, s[96:97]\n\tv_fma_f64 %1, %1, %4, s[96:97]\n\tv_fma_f64 %2, %2, %5, s[96:97]"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(x[0]), "v"(x[1]), "v"(x[2]), [lo] "i"(LO), [hi] "i"(HI) : "s96", "s97");
+  } else {
+    asm(UHDR_SETC
+        "v_fma_f64 %0, %0, %6, s[96:97]\n\tv_fma_f64 %1, %1, %7, s[96:97]\n\tv_fma_f64 %2, %2, %8, s[96:97]\n\t"
+        "v_fma_f64 %3, %3, %9, s[96:97]\n\tv_fma_f64 %4, %4, %10, s[96:97]\n\tv_fma_f64 %5, %5, %11, s[96:97]"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), [lo] "i"(LO), [hi] "i"(HI) : "s96", "s97");
+  }
+#undef UHDR_SETC
 }
 
 // log2(x[j]) for normal positive x; |relative error| < 2^-50 (atanh series to s^19, division by a
@@ -128,18 +147,17 @@ __device__ __forceinline__ void fast_log2_n(const double (&x)[N], double (&out)[
     s2[j] = s[j] * s[j];
   }
   // 2/((2k+1) ln 2), k = 9..0
-#define UHDR_STEP(C) _Pragma("unroll") for (int j = 0; j < N; ++j) p[j] = fma_sc(p[j], s2[j], C);
 #pragma unroll
-  for (int j = 0; j < N; ++j) p[j] = fma_sc(s2[j], 0x1.3703c1f4d0ffep-3, 0x1.5b9ac9b743f0dp-3);
-  UHDR_STEP(0x1.89f3b1694cffep-3)
-  UHDR_STEP(0x1.c68f568d31760p-3)
-  UHDR_STEP(0x1.0c9a84994022dp-2)
-  UHDR_STEP(0x1.484b13d7c02a9p-2)
-  UHDR_STEP(0x1.a61762a7aded9p-2)
-  UHDR_STEP(0x1.2776c50ef9bfep-1)
-  UHDR_STEP(0x1.ec709dc3a03fdp-1)
-  UHDR_STEP(0x1.71547652b82fep+1)
-#undef UHDR_STEP
+  for (int j = 0; j < N; ++j) p[j] = 0x1.3703c1f4d0ffep-3;
+  horner_step<0x3fc5b9acu, 0x9b743f0du>(p, s2);
+  horner_step<0x3fc89f3bu, 0x1694cffeu>(p, s2);
+  horner_step<0x3fcc68f5u, 0x68d31760u>(p, s2);
+  horner_step<0x3fd0c9a8u, 0x4994022du>(p, s2);
+  horner_step<0x3fd484b1u, 0x3d7c02a9u>(p, s2);
+  horner_step<0x3fda6176u, 0x2a7aded9u>(p, s2);
+  horner_step<0x3fe2776cu, 0x50ef9bfeu>(p, s2);
+  horner_step<0x3feec709u, 0xdc3a03fdu>(p, s2);
+  horner_step<0x40071547u, 0x652b82feu>(p, s2);
 #pragma unroll
   for (int j = 0; j < N; ++j) out[j] = __builtin_fma(s[j], p[j], (double)e[j]);
 }
@@ -160,20 +178,19 @@ __device__ __forceinline__ void fast_exp2_n(const double (&P)[N], double (&out)[
     f[j] = P[j] - k[j];
   }
   // (ln 2)^i / i!, i = 12..1
-#define UHDR_STEP(C) _Pragma("unroll") for (int j = 0; j < N; ++j) p[j] = fma_sc(p[j], f[j], C);
 #pragma unroll
-  for (int j = 0; j < N; ++j) p[j] = fma_sc(f[j], 0x1.c3bd650fc2986p-36, 0x1.e8cac7351bb25p-32);
-  UHDR_STEP(0x1.e4cf5158b8ecap-28)
-  UHDR_STEP(0x1.b5253d395e7c4p-24)
-  UHDR_STEP(0x1.62c0223a5c824p-20)
-  UHDR_STEP(0x1.ffcbfc588b0c7p-17)
-  UHDR_STEP(0x1.430912f86c787p-13)
-  UHDR_STEP(0x1.5d87fe78a6731p-10)
-  UHDR_STEP(0x1.3b2ab6fba4e77p-7)
-  UHDR_STEP(0x1.c6b08d704a0c0p-5)
-  UHDR_STEP(0x1.ebfbdff82c58fp-3)
-  UHDR_STEP(0x1.62e42fefa39efp-1)
-#undef UHDR_STEP
+  for (int j = 0; j < N; ++j) p[j] = 0x1.c3bd650fc2986p-36;
+  horner_step<0x3dfe8cacu, 0x7351bb25u>(p, f);
+  horner_step<0x3e3e4cf5u, 0x158b8ecau>(p, f);
+  horner_step<0x3e7b5253u, 0xd395e7c4u>(p, f);
+  horner_step<0x3eb62c02u, 0x23a5c824u>(p, f);
+  horner_step<0x3eeffcbfu, 0xc588b0c7u>(p, f);
+  horner_step<0x3f243091u, 0x2f86c787u>(p, f);
+  horner_step<0x3f55d87fu, 0xe78a6731u>(p, f);
+  horner_step<0x3f83b2abu, 0x6fba4e77u>(p, f);
+  horner_step<0x3fac6b08u, 0xd704a0c0u>(p, f);
+  horner_step<0x3fcebfbdu, 0xff82c58fu>(p, f);
+  horner_step<0x3fe62e42u, 0xfefa39efu>(p, f);
 #pragma unroll
   for (int j = 0; j < N; ++j) out[j] = __builtin_ldexp(__builtin_fma(p[j], f[j], 1.0), (int)k[j]);
 }

@@ -5,7 +5,7 @@
 
 namespace uhdr {
 
-constexpr int kMaxChunk = 32;  // images per launch (descriptors travel in the kernarg segment)
+constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4 KiB kernarg segment: 64 x 56 B + consts)
 
 // ---- generate ----------------------------------------------------------------------------------
 struct GenConsts {
@@ -20,20 +20,19 @@ struct GenConsts {
   double enc_scale;
   uint32_t enc_byte_min, enc_byte_max;
   uint32_t width, height, map_w, map_h;
+  uint32_t* stat_keys;  // 2 words per image of the launch (min key, max key), or nullptr
 };
 struct EvalConsts {
   float min_boost, max_boost, log2_min, log2_max;
   double enc_scale;
   uint32_t enc_byte_min, enc_byte_max;
 };
-struct GenImage {
+struct GenImage {  // 56 bytes; the V plane is u + c_stride * (height / 2) (gainmapmath.cpp:568)
   const uint8_t* y;
   const uint8_t* u;
-  const uint8_t* v;
   const uint16_t* hy;
   const uint16_t* huv;
   uint8_t* map;
-  uint32_t* stat_keys;  // 2 words per image (min key, max key) or nullptr
   uint32_t y_stride, c_stride, hy_stride, huv_stride;
 };
 struct GenBatch {
@@ -82,6 +81,9 @@ struct CvtImage {
   uint32_t y_stride, c_stride, width, height;
   float m[9];
 };
+
+static_assert(sizeof(GenConsts) + sizeof(GenBatch) <= 4096, "generate kernel arguments exceed the kernarg segment");
+static_assert(sizeof(AppConsts) + sizeof(AppBatch) <= 4096, "apply kernel arguments exceed the kernarg segment");
 
 // launchers (enqueue only; return hipError_t of the launch)
 hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned,

@@ -218,6 +218,7 @@ __device__ __forceinline__ void block_minmax_to_keys(float gmin, float gmax, uin
 template <int TF, bool ALIGNED>
 __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(const GenConsts c, const GenBatch b) {
   const GenImage& im = b.img[blockIdx.y];
+  const uint8_t* im_v = im.u + (size_t)im.c_stride * (c.height / 2u);
   const uint32_t pairs_per_row = (c.map_w + 1u) >> 1;
   const uint32_t total = pairs_per_row * c.map_h;
   float gmin = __builtin_inff(), gmax = -__builtin_inff();
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
         const uint4 q = *reinterpret_cast<const uint4*>(im.huv + (size_t)(2u * my + r) * im.huv_stride + 8u * pr);
         huv[0][r][0] = q.x; huv[0][r][1] = q.y; huv[1][r][0] = q.z; huv[1][r][1] = q.w;
         const uint32_t uu = *reinterpret_cast<const uint32_t*>(im.u + (size_t)(2u * my + r) * im.c_stride + 4u * pr);
-        const uint32_t vv = *reinterpret_cast<const uint32_t*>(im.v + (size_t)(2u * my + r) * im.c_stride + 4u * pr);
+        const uint32_t vv = *reinterpret_cast<const uint32_t*>(im_v + (size_t)(2u * my + r) * im.c_stride + 4u * pr);
         u8[0][r] = uu & 0xffffu; u8[1][r] = uu >> 16;
         v8[0][r] = vv & 0xffffu; v8[1][r] = vv >> 16;
       }
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
         for (int r = 0; r < 2; ++r) {
           const uint16_t* crow = im.huv + (size_t)(2u * my + r) * im.huv_stride + x0;  // (x & ~1)
           const uint8_t* urow = im.u + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
-          const uint8_t* vrow = im.v + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
+          const uint8_t* vrow = im_v + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
           huv[k][r][0] = on ? (ld16(crow) | (ld16(crow + 1) << 16)) : 0u;
           huv[k][r][1] = on ? (ld16(crow + 2) | (ld16(crow + 3) << 16)) : 0u;
           u8[k][r] = on ? (ld8(urow) | (ld8(urow + 1) << 8)) : 0u;
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
       if (two) mp[1] = o1;
     }
   }
-  if (im.stat_keys != nullptr) block_minmax_to_keys(gmin, gmax, im.stat_keys);
+  if (c.stat_keys != nullptr) block_minmax_to_keys(gmin, gmax, c.stat_keys + 2u * blockIdx.y);
 }
 
 __global__ void k_stats_finalize(uint32_t* keys, int n) {

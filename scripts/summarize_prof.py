@@ -51,7 +51,7 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
 # HBM traffic per launch of the two hot kernels.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies
 # 128-B read requests at 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 4 --warmup 1`; "
-                     "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch of 32 4K frames"}
+                     "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch of 64 4K frames"}
 for key, pat in (("generate", "k_generate"), ("apply", "k_apply_s4")):
     f = [v["FETCH_SIZE"]["avg_per_dispatch"] for n, v in summary.get("pmc_fetch", {}).items() if pat in n and "FETCH_SIZE" in v]
     w = [v["WRITE_SIZE"]["avg_per_dispatch"] for n, v in summary.get("pmc_write", {}).items() if pat in n and "WRITE_SIZE" in v]

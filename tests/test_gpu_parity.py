@@ -436,12 +436,12 @@ def test_convert_yuv_all_matrices(hip, orc, pair, layout):
 # batches, content min/max, host-memory entry points
 # --------------------------------------------------------------------------------------------------
 def test_batch_generate_apply_and_content_minmax(hip, orc):
-    """a ragged batch (two sizes, > one chunk of 32) in one call; min/max is an extra statistic with no
+    """a ragged batch (two sizes, more images than one 64-image launch) in one call; min/max is an extra statistic with no
     reference counterpart: checked against the oracle's own definition only (parity unpinned)"""
     import torch
     from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr, diff_1010102
     lib = hip.load()
-    sizes = [(128, 64)] * 35 + [(72, 40)] * 3 + [(128, 64)] * 2
+    sizes = [(128, 64)] * 70 + [(72, 40)] * 3 + [(128, 64)] * 2
     n = len(sizes)
     keep, yis, pis, dests, maps, oref = [], [], [], [], [], []
     for i, (w, h) in enumerate(sizes):

@@ -221,22 +221,32 @@ __device__ __attribute__((noinline)) float srgb_inv_oetf_slow(float e) { return 
 __device__ __attribute__((noinline)) float hlg_inv_oetf_slow(float e) { return hlg_inv_oetf_exact(e); }
 __device__ __attribute__((noinline)) float pq_inv_oetf_slow(float e) { return pq_inv_oetf_exact(e); }
 
+// sRGB EOTF.  x^2.4 = x^2 * z with z = x^(2/5), i.e. z^5 = x^2: the special-function unit gives z0 = 2^(0.4 log2 x)
+// to ~2^-22, and ONE Newton step in f64, z1 = z0 - (z0^5 - x^2) * R with R ~ 1/(5 z0^4) from v_rcp_f32, leaves a
+// relative error ~2^-42 (2 e0^2 from the iteration + 2^-44 from R) -- 24 VALU slots instead of the 45 of
+// fast_log2 + fast_exp2.  The Ziv test below (2^-38) decides whether the float rounding is safe.
 template <int N>
 __device__ __forceinline__ void srgb_inv_oetf_guarded_n(float (&e)[N]) {
-  float lin[N];
-  double xd[N], y[N];
+  float lin[N], xf[N];
+  double y[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     lin[j] = div_const(e[j], 12.92f, 1.0f / 12.92f);
     // the fma remainder of div_const underflows for |e| < ~7e-32 (selftest): such values (never produced by
     // 8-bit content, but representable) take the hardware IEEE division
     if (e[j] != 0.0f && e[j] < 0x1p-100f) lin[j] = e[j] / 12.92f;
-    xd[j] = (double)div_const(e[j] + 0.055f, 1.055f, 1.0f / 1.055f);
+    xf[j] = div_const(e[j] + 0.055f, 1.055f, 1.0f / 1.055f);
   }
-  fast_log2_n<N>(xd, y);
 #pragma unroll
-  for (int j = 0; j < N; ++j) y[j] *= 2.4;
-  fast_exp2_n<N>(y, y);
+  for (int j = 0; j < N; ++j) {
+    const double x = (double)xf[j];
+    const double z0 = (double)__builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf(xf[j]));
+    const double X = x * x;                       // exact (48 significant bits)
+    const double z2 = z0 * z0, z4 = z2 * z2;
+    const double d = __builtin_fma(z4, z0, -X);   // z0^5 - x^2
+    const double R = (double)(0.2f * __builtin_amdgcn_rcpf((float)z4));
+    y[j] = X * __builtin_fma(-d, R, z0);
+  }
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     float p = (float)y[j];

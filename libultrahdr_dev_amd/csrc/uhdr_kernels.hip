@@ -822,7 +822,12 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 20: y = srgb_inv_oetf_fast(x); break;
     // 1.0 where the lean f64 path was accepted by the rounding test, 0.0 where the exact path ran
     case 100: { const float t = div_const(x + 0.055f, 1.055f, 1.0f / 1.055f);
-                y = (x <= 0.04045f || ziv_safe(fast_exp2(2.4 * fast_log2((double)t)))) ? 1.0f : 0.0f; break; }
+                float v1[1] = {x};
+                srgb_inv_oetf_guarded_n<1>(v1);   // (kept for symmetry; the acceptance rate is measured below)
+                const double xd = (double)t, z0 = (double)__builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf(t));
+                const double X = xd * xd, z2 = z0 * z0, z4 = z2 * z2;
+                const double yy = X * __builtin_fma(-__builtin_fma(z4, z0, -X), (double)(0.2f * __builtin_amdgcn_rcpf((float)z4)), z0);
+                y = (x <= 0.04045f || ziv_safe(yy)) ? 1.0f : 0.0f; break; }
     case 101: { const float v = div_const(x - UHDR_HLG_C, UHDR_HLG_A, 1.0f / UHDR_HLG_A);
                 y = (x <= 0.5f || ziv_safe((fast_exp2((double)v * 0x1.71547652b82fep+0) + (double)UHDR_HLG_B) * (1.0 / 12.0))) ? 1.0f : 0.0f; break; }
     default: break;

@@ -404,27 +404,59 @@ __device__ __forceinline__ f2 sel_le(f2 x, float thr, f2 a, f2 b) {  // x <= thr
   return (f2){x.x <= thr ? a.x : b.x, x.y <= thr ? a.y : b.y};
 }
 
-// sRGB EOTF of two values: x^2.4 = x^2 * 2^(0.4 log2 x)
-__device__ __forceinline__ f2 srgb_eotf2(f2 e) {
-  const f2 lin = e * splat(1.0f / 12.92f);
-  const f2 x = pk_fma(e, splat(1.0f / 1.055f), splat(0.055f / 1.055f));
-  const f2 t = exp2_2(log2_2(x) * splat(0.4f));
-  return sel_le(e, 0.04045f, lin, (x * x) * t);
+// packed add / mul with the VOP3P clamp modifier: both lanes saturate to [0, 1] for free (hipcc only
+// folds clamps into scalar ops, so these two are spelled out)
+__device__ __forceinline__ f2 pk_add_sat(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_mul_sat(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
-// OETF of two linear values, scaled to 10-bit code units where the format is 10 bit
-template <int FMT>
+// The piecewise transfer functions are evaluated WITHOUT per-lane selects (v_cmp + v_cndmask cost 2 issue
+// slots per value and cannot be packed).  For a function  f(e) = A(e) for e <= j,  B(e) for e > j :
+//     f(e) = A(min(e, j)) - A(j) + B(max(e, j)),
+// with  min(e, j) = j * sat(e / j)  and  max(e, j) = j + sat(e - j)  (0 <= e <= ~1), both packed ops with the
+// clamp modifier.  The identity is exact for e > j; for e <= j it adds B(j) - A(j), the reference function's own
+// jump at the junction (2.3e-9 for sRGB, ~1e-7 for HLG): far inside the 1-LSB tolerance.
+
+// sRGB EOTF of two values (gainmapmath.cpp:149-155): x^2.4 = x^2 * 2^(0.4 log2 x)
+__device__ __forceinline__ f2 srgb_eotf2(f2 e) {
+  constexpr float kThr = 0.04045f;
+  const f2 a = pk_mul_sat(e, splat(1.0f / kThr));                                      // min(e, thr) / thr
+  const f2 lin = pk_fma(a, splat(kThr / 12.92f), splat(-(kThr / 12.92f)));             // lin(min) - lin(thr)
+  const f2 d = pk_add_sat(e, splat(-kThr));                                            // max(e, thr) - thr
+  const f2 x = pk_fma(d, splat(1.0f / 1.055f), splat((kThr + 0.055f) / 1.055f));
+  const f2 t = exp2_2(log2_2(x) * splat(0.4f));
+  return pk_fma(x * x, t, lin);
+}
+
+// OETF of two linear values, scaled to 10-bit code units where the format is 10 bit.  UNBOUNDED: the inputs
+// may exceed 1.0 (max_display_boost < maxContentBoost), so max(e, j) - j cannot be had from a [0,1] clamp and
+// the HLG junction is selected per lane instead.
+template <int FMT, bool UNBOUNDED>
 __device__ __forceinline__ f2 oetf2_scaled(f2 e) {
-  if (FMT == 3) {  // HLG: sqrt(3e) | a ln(12e-b)+c, times 1023
+  if (FMT == 3 && UNBOUNDED) {
     const f2 lo = sqrt_2(e * splat(3.0f * 1023.0f * 1023.0f));
     const f2 hi = pk_fma(log2_2(pk_fma(e, splat(12.0f), splat(-UHDR_HLG_B))),
                          splat(UHDR_HLG_A * 0.693147180559945f * 1023.0f), splat(UHDR_HLG_C * 1023.0f));
     return sel_le(e, 1.0f / 12.0f, lo, hi);
-  } else if (FMT == 2) {  // PQ: ((c1 + c2 e^m1) / (1 + c3 e^m1))^m2, times 1023
+  } else if (FMT == 3) {  // HLG (gainmapmath.cpp:259-265): sqrt(3e) | a ln(12e-b)+c, times 1023
+    constexpr float K = 1023.0f;
+    const f2 lo = sqrt_2(pk_mul_sat(e, splat(12.0f))) * splat(0.5f * K);               // K sqrt(3 min(e, 1/12))
+    const f2 d = pk_add_sat(e, splat(-1.0f / 12.0f));                                  // max(e, 1/12) - 1/12
+    const f2 arg = pk_fma(d, splat(12.0f), splat(1.0f - UHDR_HLG_B));
+    const f2 hi = pk_fma(log2_2(arg), splat(UHDR_HLG_A * 0.693147180559945f * K), splat(UHDR_HLG_C * K - 0.5f * K));
+    return lo + hi;
+  } else if (FMT == 2) {  // PQ (gainmapmath.cpp:309-312): ((c1 + c2 e^m1) / (1 + c3 e^m1))^m2, times 1023
+    // e == 0: log2 -> -inf, e^m1 -> 0, result c1^m2 * 1023 = 7e-4, which truncates to the reference's 0
     const f2 p = exp2_2(log2_2(e) * splat(UHDR_PQ_M1));
     const f2 q = pk_fma(p, splat(UHDR_PQ_C2), splat(UHDR_PQ_C1)) * rcp_2(pk_fma(p, splat(UHDR_PQ_C3), splat(1.0f)));
-    const f2 r = exp2_2(pk_fma(log2_2(q), splat(UHDR_PQ_M2), splat(9.99859042974533f)));  // + log2(1023)
-    return sel_le(e, 0.0f, splat(0.0f), r);
+    return exp2_2(pk_fma(log2_2(q), splat(UHDR_PQ_M2), splat(9.99859042974533f)));     // + log2(1023)
   } else if (FMT == 4) {
     return e * splat(1023.0f);
   }
@@ -434,17 +466,17 @@ __device__ __forceinline__ f2 oetf2_scaled(f2 e) {
 struct PairOut { f2 r, g, b; };
 
 // two horizontally adjacent pixels sharing one chroma sample
-template <int FMT>
+template <int FMT, bool UNBOUNDED>
 __device__ __forceinline__ PairOut apply_pair(f2 yf, float crv, float gsum, float cbu, f2 E) {
-  // p3YuvToRgb (gainmapmath.cpp:198-202); the clamp folds into the add
-  f2 r = (f2){sat01(yf.x + crv), sat01(yf.y + crv)};
-  f2 g = (f2){sat01(yf.x - gsum), sat01(yf.y - gsum)};
-  f2 b = (f2){sat01(yf.x + cbu), sat01(yf.y + cbu)};
+  // p3YuvToRgb (gainmapmath.cpp:198-202); the clamp rides on the packed add
+  const f2 r = pk_add_sat(yf, splat(crv));
+  const f2 g = pk_add_sat(yf, splat(-gsum));
+  const f2 b = pk_add_sat(yf, splat(cbu));
   const f2 factor = exp2_2(E);  // applyGain's 2^(logBoost*displayBoost/max) / displayBoost
   PairOut o;
-  o.r = oetf2_scaled<FMT>(srgb_eotf2(r) * factor);
-  o.g = oetf2_scaled<FMT>(srgb_eotf2(g) * factor);
-  o.b = oetf2_scaled<FMT>(srgb_eotf2(b) * factor);
+  o.r = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(r) * factor);
+  o.g = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(g) * factor);
+  o.b = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(b) * factor);
   return o;
 }
 
@@ -494,7 +526,7 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
       const f2 E = pk_fma(splat(e4), w3, pk_fma(splat(e3), w2, pk_fma(splat(e2), w1, pk_fma(splat(e1), w0, splat(c.fast.B)))));
       const uint32_t yw = yrow[oy] >> (16 * pr);
       const f2 yf = (f2){(float)(yw & 0xffu), (float)((yw >> 8) & 0xffu)} * splat(k255);
-      po[pr] = apply_pair<FMT>(yf, crv[oy >> 1][pr], gsum[oy >> 1][pr], cbu[oy >> 1][pr], E);
+      po[pr] = apply_pair<FMT, MASK>(yf, crv[oy >> 1][pr], gsum[oy >> 1][pr], cbu[oy >> 1][pr], E);
     }
     const size_t pix0 = (size_t)(4u * cy + oy) * c.width + 4u * cx;
     if (FMT == 2 || FMT == 3) {

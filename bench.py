@@ -130,6 +130,37 @@ def other_configs(lib, stream):
                                                      api.MEM_DEVICE, stream))
     out["configs[1] single 4K HLG generate"] = {"ms": round(ms, 4), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1),
                                                 "GB/s": round(GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    # PQ generate (P010 BT.2100 PQ vs SDR BT.709): 2 f64 pow per HDR channel instead of 1 exp -- 8 frames in one launch
+    nb = 8
+    pq = [synth.lcg_frame(W, H, 4321 + i) for i in range(nb)]
+    pmaps = [torch.zeros((W // 4) * (H // 4), dtype=torch.uint8, device="cuda") for _ in range(nb)]
+    ya = api.image_array([api.yuv420_image(q[1].data_ptr(), W, H, api.CG_BT709) for q in pq])
+    pa = api.image_array([api.p010_image(q[0].data_ptr(), W, H, api.CG_BT2100) for q in pq])
+    ma = api.image_array([api.out_image(t.data_ptr()) for t in pmaps])
+    ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch(nb, ya, pa, api.TF_PQ, C.byref(md), ma, 0, None, stream), 10)
+    out["4K PQ generate, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+                                             "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    # the drop-in form a CPU caller uses: host planes in, host bytes out (PCIe Gen5 both ways; never `value`)
+    hp, hy = p.cpu().numpy(), y.cpu().numpy()
+    hmap = np.zeros((W // 4) * (H // 4), np.uint8)
+    hout = np.zeros(W * H, np.uint32)
+    hyi = api.yuv420_image(hy.ctypes.data, W, H, api.CG_BT709)
+    hpi = api.p010_image(hp.ctypes.data, W, H, api.CG_BT2100)
+    hmi, hoi, hmd = api.out_image(hmap.ctypes.data), api.out_image(hout.ctypes.data), api.Metadata()
+
+    def host_pair():
+        assert lib.uhdr_hip_generate_gainmap(C.byref(hyi), C.byref(hpi), api.TF_HLG, C.byref(hmd), C.byref(hmi), 0, api.MEM_HOST, None) == 0
+        assert lib.uhdr_hip_apply_gainmap(C.byref(hyi), C.byref(hmi), C.byref(hmd), api.OUTPUT_HDR_HLG, api.FLT_MAX, C.byref(hoi),
+                                          api.APPLY_FAST, api.MEM_HOST, None) == 0
+
+    for _ in range(2):
+        host_pair()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        host_pair()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    out["host-staged 4K pair (UHDR_HIP_MEM_HOST, pageable memory, PCIe both ways)"] = {
+        "ms": round(ms, 3), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1)}
     # configs[4]: 7680x4320 decode-side apply
     w8, h8 = 7680, 4320
     _, y8 = synth.lcg_frame(w8, h8, 1234)

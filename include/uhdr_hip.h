@@ -33,7 +33,7 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *  - the library never allocates result memory on behalf of the caller: the gain map buffer
  *    ((width/4)*(height/4) bytes) is caller-provided in dest->data.  (The C++ shim in
- *    include/ultrahdr_hip/ultrahdr.h reproduces the reference's new[] contract on top of this.)
+ *    include/ultrahdr_hip/ultrahdr_hip.h reproduces the reference's new[] contract on top of this.)
  */
 #ifndef UHDR_HIP_H
 #define UHDR_HIP_H

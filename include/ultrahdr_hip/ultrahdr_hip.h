@@ -1,5 +1,5 @@
 /*
- * ultrahdr_hip/ultrahdr.h -- C++ host-side mirror of the reference's hot-path interface, implemented
+ * ultrahdr_hip/ultrahdr_hip.h -- C++ host-side mirror of the reference's hot-path interface, implemented
  * on top of the C-ABI in include/uhdr_hip.h (MI355X kernels).
  *
  * The reference keeps the pixel path behind protected members of ultrahdr::UltraHdr
@@ -15,8 +15,8 @@
  *   applyGainMap / toneMap / convertYuv: the caller owns every buffer.
  * All calls are synchronous on host memory (the image is staged through HBM and back).
  */
-#ifndef ULTRAHDR_HIP_ULTRAHDR_H
-#define ULTRAHDR_HIP_ULTRAHDR_H
+#ifndef ULTRAHDR_HIP_SHIM_H
+#define ULTRAHDR_HIP_SHIM_H
 
 #include <cstddef>
 #include <cstdint>
@@ -24,79 +24,50 @@
 
 namespace ultrahdr {
 
-typedef enum {
-  ULTRAHDR_COLORGAMUT_UNSPECIFIED = -1,
-  ULTRAHDR_COLORGAMUT_BT709,
-  ULTRAHDR_COLORGAMUT_P3,
-  ULTRAHDR_COLORGAMUT_BT2100,
-  ULTRAHDR_COLORGAMUT_MAX = ULTRAHDR_COLORGAMUT_BT2100,
-} ultrahdr_color_gamut;
+// Enumerator names and numeric values are the reference's (lib/include/ultrahdr/ultrahdr.h:36-120), so that
+// caller code compiles unchanged; only the codes the pixel path can return are listed for status_t.
+enum ultrahdr_color_gamut : int {
+  ULTRAHDR_COLORGAMUT_UNSPECIFIED = -1, ULTRAHDR_COLORGAMUT_BT709 = 0, ULTRAHDR_COLORGAMUT_P3 = 1,
+  ULTRAHDR_COLORGAMUT_BT2100 = 2, ULTRAHDR_COLORGAMUT_MAX = 2
+};
+enum ultrahdr_transfer_function : int {
+  ULTRAHDR_TF_UNSPECIFIED = -1, ULTRAHDR_TF_LINEAR = 0, ULTRAHDR_TF_HLG = 1, ULTRAHDR_TF_PQ = 2, ULTRAHDR_TF_SRGB = 3,
+  ULTRAHDR_TF_MAX = 3
+};
+enum ultrahdr_output_format : int {
+  ULTRAHDR_OUTPUT_UNSPECIFIED = -1, ULTRAHDR_OUTPUT_SDR = 0, ULTRAHDR_OUTPUT_HDR_LINEAR = 1, ULTRAHDR_OUTPUT_HDR_PQ = 2,
+  ULTRAHDR_OUTPUT_HDR_HLG = 3, ULTRAHDR_OUTPUT_HDR_LINEAR_RGB_10BIT = 4, ULTRAHDR_OUTPUT_MAX = 4
+};
+enum ultrahdr_pixel_format : int {
+  ULTRAHDR_PIX_FMT_UNSPECIFIED = -1, ULTRAHDR_PIX_FMT_P010 = 0, ULTRAHDR_PIX_FMT_YUV420 = 1,
+  ULTRAHDR_PIX_FMT_MONOCHROME = 2, ULTRAHDR_PIX_FMT_RGBA8888 = 3, ULTRAHDR_PIX_FMT_RGBAF16 = 4,
+  ULTRAHDR_PIX_FMT_RGBA1010102 = 5
+};
+enum status_t : int {
+  ULTRAHDR_NO_ERROR = 0, ULTRAHDR_UNKNOWN_ERROR = -1, ERROR_ULTRAHDR_BAD_PTR = -10001,
+  ERROR_ULTRAHDR_INVALID_COLORGAMUT = -10003, ERROR_ULTRAHDR_INVALID_TRANS_FUNC = -10005,
+  ERROR_ULTRAHDR_RESOLUTION_MISMATCH = -10006, ERROR_ULTRAHDR_BAD_METADATA = -10010,
+  ERROR_ULTRAHDR_UNSUPPORTED_MAP_SCALE_FACTOR = -20008, ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE = -20009
+};
 
-typedef enum {
-  ULTRAHDR_TF_UNSPECIFIED = -1,
-  ULTRAHDR_TF_LINEAR = 0,
-  ULTRAHDR_TF_HLG = 1,
-  ULTRAHDR_TF_PQ = 2,
-  ULTRAHDR_TF_SRGB = 3,
-  ULTRAHDR_TF_MAX = ULTRAHDR_TF_SRGB,
-} ultrahdr_transfer_function;
-
-typedef enum {
-  ULTRAHDR_OUTPUT_UNSPECIFIED = -1,
-  ULTRAHDR_OUTPUT_SDR,
-  ULTRAHDR_OUTPUT_HDR_LINEAR,
-  ULTRAHDR_OUTPUT_HDR_PQ,
-  ULTRAHDR_OUTPUT_HDR_HLG,
-  ULTRAHDR_OUTPUT_HDR_LINEAR_RGB_10BIT,
-  ULTRAHDR_OUTPUT_MAX = ULTRAHDR_OUTPUT_HDR_LINEAR_RGB_10BIT,
-} ultrahdr_output_format;
-
-typedef enum {
-  ULTRAHDR_PIX_FMT_UNSPECIFIED = -1,
-  ULTRAHDR_PIX_FMT_P010,
-  ULTRAHDR_PIX_FMT_YUV420,
-  ULTRAHDR_PIX_FMT_MONOCHROME,
-  ULTRAHDR_PIX_FMT_RGBA8888,
-  ULTRAHDR_PIX_FMT_RGBAF16,
-  ULTRAHDR_PIX_FMT_RGBA1010102,
-} ultrahdr_pixel_format;
-
-// only the codes the pixel path can return are listed; values are the reference's
-typedef enum {
-  ULTRAHDR_NO_ERROR = 0,
-  ULTRAHDR_UNKNOWN_ERROR = -1,
-  ERROR_ULTRAHDR_BAD_PTR = -10001,
-  ERROR_ULTRAHDR_INVALID_COLORGAMUT = -10003,
-  ERROR_ULTRAHDR_INVALID_TRANS_FUNC = -10005,
-  ERROR_ULTRAHDR_RESOLUTION_MISMATCH = -10006,
-  ERROR_ULTRAHDR_BAD_METADATA = -10010,
-  ERROR_ULTRAHDR_UNSUPPORTED_MAP_SCALE_FACTOR = -20008,
-  ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE = -20009,
-} status_t;
-
+// ultrahdr_metadata_struct / ultrahdr_uncompressed_struct: same members, order and defaults as the reference
+// (ultrahdr.h:129-147,152-181): linear boosts, strides in pixels, chroma_data == nullptr meaning "right after luma"
+// is resolved by the CALLER (jpegr.cpp:265-278) before these functions are entered.
 struct ultrahdr_metadata_struct {
   std::string version;
-  float maxContentBoost;
-  float minContentBoost;
-  float gamma;
-  float offsetSdr;
-  float offsetHdr;
-  float hdrCapacityMin;
-  float hdrCapacityMax;
+  float maxContentBoost, minContentBoost, gamma, offsetSdr, offsetHdr, hdrCapacityMin, hdrCapacityMax;
 };
-typedef struct ultrahdr_metadata_struct* ultrahdr_metadata_ptr;
+using ultrahdr_metadata_ptr = ultrahdr_metadata_struct*;
 
 struct ultrahdr_uncompressed_struct {
   void* data;
-  size_t width;
-  size_t height;
+  size_t width, height;
   ultrahdr_color_gamut colorGamut;
   void* chroma_data = nullptr;
-  size_t luma_stride = 0;
-  size_t chroma_stride = 0;
+  size_t luma_stride = 0, chroma_stride = 0;
   ultrahdr_pixel_format pixelFormat = ULTRAHDR_PIX_FMT_UNSPECIFIED;
 };
-typedef struct ultrahdr_uncompressed_struct* uhdr_uncompressed_ptr;
+using uhdr_uncompressed_ptr = ultrahdr_uncompressed_struct*;
 
 static const char* const kGainMapVersion = "1.0";
 static const size_t kMapDimensionScaleFactor = 4;
@@ -131,4 +102,4 @@ class UltraHdrHip {
 
 }  // namespace ultrahdr
 
-#endif  // ULTRAHDR_HIP_ULTRAHDR_H
+#endif  // ULTRAHDR_HIP_SHIM_H

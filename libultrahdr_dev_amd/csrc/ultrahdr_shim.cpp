@@ -1,7 +1,7 @@
 // ultrahdr_shim.cpp -- ultrahdr::UltraHdrHip: the reference's C++ member signatures on top of the
 // C-ABI (include/uhdr_hip.h).  Pure host glue: descriptor translation + the new[] ownership contract
 // of generateGainMap (ref lib/src/ultrahdr.cpp:209,217-218,356).
-#include "ultrahdr_hip/ultrahdr.h"
+#include "ultrahdr_hip/ultrahdr_hip.h"
 
 #include <cstring>
 #include <memory>

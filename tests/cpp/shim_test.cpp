@@ -9,7 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "ultrahdr_hip/ultrahdr.h"
+#include "ultrahdr_hip/ultrahdr_hip.h"
 
 using namespace ultrahdr;
 

@@ -1,4 +1,4 @@
-"""-m gpu: the C++ host shim (ultrahdr::UltraHdrHip, include/ultrahdr_hip/ultrahdr.h) driven by a C++ program
+"""-m gpu: the C++ host shim (ultrahdr::UltraHdrHip, include/ultrahdr_hip/ultrahdr_hip.h) driven by a C++ program
 shaped like the reference's own harness, and the HBM-side synthetic frame generator used by bench.py."""
 import ctypes as C
 import hashlib

@@ -235,6 +235,7 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   c.width = (uint32_t)w; c.height = (uint32_t)h;
   c.map_w = (uint32_t)(w / 4); c.map_h = (uint32_t)(h / 4);
   c.stat_keys = nullptr;
+  c.bias4096 = 4096.0f;
   return c;
 }
 

@@ -15,6 +15,7 @@ struct GenConsts {
   float gm[9];                             // HDR->SDR gamut matrix
   int gm_identity;
   float hdr_white_nits;
+  float bias4096;                          // == 4096.0f (kept opaque to the optimizer, see gen_pair)
   float min_boost, max_boost, log2_min, log2_max;
   // encode_gain_guarded: 255/(double)(log2_max - log2_min) and the bytes of gain == min / gain == max
   double enc_scale;

@@ -64,6 +64,19 @@ __device__ __forceinline__ float hdr_inv_oetf(float e) {
 // 16 bits; huv[k][r][0|1]: (U,V) of chroma col 0|1 of chroma row r; y8[k][r]: 4 luma bytes; u8/v8[k][r]:
 // 2 chroma bytes in bits 0-15.  Accumulation order is samplePixels' (gainmapmath.cpp:605-615): dy outer,
 // dx inner, one running float sum per channel.
+// float of the low / high 16-bit word of w in ONE instruction (SDWA operand select); hipcc emits an extract
+// (v_and_b32_sdwa / v_lshrrev_b32) followed by v_cvt_f32_u32 for the plain C expression
+__device__ __forceinline__ float cvt_word0(uint32_t w) {
+  float r;
+  asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(w));
+  return r;
+}
+__device__ __forceinline__ float cvt_word1(uint32_t w) {
+  float r;
+  asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(w));
+  return r;
+}
+
 __device__ __forceinline__ float clampf(float v) { return (v < 0.0f) ? 0.0f : (v > 1.0f) ? 1.0f : v; }
 __device__ __forceinline__ f2 clamp2(f2 v) { return (f2){clampf(v.x), clampf(v.y)}; }
 
@@ -84,11 +97,17 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
       const f2 vb = (f2){(float)((v8[0][r] >> (8 * k)) & 0xffu), (float)((v8[1][r] >> (8 * k)) & 0xffu)};
       uf[k] = (ub - splat(128.0f)) * splat(k255);
       vf[k] = (vb - splat(128.0f)) * splat(k255);
-      // float((x >> 6) - 64) * (1/896) - 0.5                            gainmapmath.cpp:593-600
-      const f2 hu = (f2){(float)((huv[0][r][k] & 0xffffu) >> 6), (float)((huv[1][r][k] & 0xffffu) >> 6)};
-      const f2 hv = (f2){(float)(huv[0][r][k] >> 22), (float)(huv[1][r][k] >> 22)};
-      huf[k] = (hu - splat(64.0f)) * splat(k896) - splat(0.5f);
-      hvf[k] = (hv - splat(64.0f)) * splat(k896) - splat(0.5f);
+      // float((x >> 6) - 64) * (1/896) - 0.5   (gainmapmath.cpp:593-600), evaluated as
+      // (float(x & 0xFFC0) - 4096) * (1/896/64) - 0.5: the masked 16-bit word is 64 * (x >> 6), so one mask per
+      // two samples and one SDWA word->float conversion per sample replace shift + mask + subtract + convert;
+      // scaling by 2^-6 commutes with the rounding of the product, so the float is the same.  The bias comes from a
+      // kernel argument (always 4096.0f) so that hipcc keeps it a packed float subtract instead of folding it back
+      // into an integer add in front of every conversion.
+      const uint32_t m0 = huv[0][r][k] & 0xFFC0FFC0u, m1 = huv[1][r][k] & 0xFFC0FFC0u;
+      const f2 hu = (f2){cvt_word0(m0), cvt_word0(m1)};
+      const f2 hv = (f2){cvt_word1(m0), cvt_word1(m1)};
+      huf[k] = (hu - splat(c.bias4096)) * splat(k896 * 0.015625f) - splat(0.5f);
+      hvf[k] = (hv - splat(c.bias4096)) * splat(k896 * 0.015625f) - splat(0.5f);
     }
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
@@ -99,9 +118,9 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
         sy += yb * splat(k255);
         su += uf[dx >> 1];
         sv += vf[dx >> 1];
-        const f2 hb = (f2){(float)(((hy[0][dy][dx >> 1] >> (16 * (dx & 1))) & 0xffffu) >> 6),
-                           (float)(((hy[1][dy][dx >> 1] >> (16 * (dx & 1))) & 0xffffu) >> 6)};
-        hsy += (hb - splat(64.0f)) * splat(k876);
+        const uint32_t w0 = hy[0][dy][dx >> 1] & 0xFFC0FFC0u, w1 = hy[1][dy][dx >> 1] & 0xFFC0FFC0u;
+        const f2 hb = (dx & 1) ? (f2){cvt_word1(w0), cvt_word1(w1)} : (f2){cvt_word0(w0), cvt_word0(w1)};
+        hsy += (hb - splat(c.bias4096)) * splat(k876 * 0.015625f);
         hsu += huf[dx >> 1];
         hsv += hvf[dx >> 1];
       }

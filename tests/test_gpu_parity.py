@@ -191,6 +191,27 @@ def test_generate_ragged_sizes(hip, orc, dims):
     assert np.array_equal(gmap, omap)
 
 
+@pytest.mark.parametrize("tf", [1, 2])
+def test_generate_p010_words_with_nonzero_low_bits(hip, orc, tf):
+    """P010 keeps the sample in the 10 MSBs; the reference discards the low 6 bits with >> 6 and accepts values
+    outside the narrow range (gainmapmath.cpp:593-600).  Random 16-bit words exercise both."""
+    from tests.gpu_util import gpu_generate
+    lib = hip.load()
+    w, h = 256, 96
+    rng = np.random.RandomState(17)
+    p010 = rng.randint(0, 65536, w * h * 3 // 2).astype(np.uint16)
+    yuv = rng.randint(0, 256, w * h * 3 // 2).astype(np.uint8)
+    for off_aligned in (True, False):
+        ww = w if off_aligned else w - 4      # w % 8 != 0 takes the element-wise path
+        pp = np.ascontiguousarray(np.concatenate([p010[:w * h].reshape(h, w)[:, :ww].reshape(-1), p010[w * h:].reshape(h // 2, w)[:, :ww].reshape(-1)]))
+        yy = np.ascontiguousarray(np.concatenate([yuv[:w * h].reshape(h, w)[:, :ww].reshape(-1), yuv[w * h:w * h * 5 // 4].reshape(h // 2, w // 2)[:, :ww // 2].reshape(-1),
+                                                  yuv[w * h * 5 // 4:].reshape(h // 2, w // 2)[:, :ww // 2].reshape(-1)]))
+        keep, yi, pi = dev_pair(hip, pp, yy, ww, h, hip.CG_BT709, hip.CG_BT2100)
+        st, gmap, md, _ = gpu_generate(lib, yi, pi, tf)
+        st2, omap, _ = orc.generate("orc_", orc.yuv420_image(yy, ww, h, 0), orc.p010_image(pp, ww, h, 2), tf)
+        assert st == 0 and st2 == 0 and np.array_equal(gmap, omap), int((gmap != omap).sum())
+
+
 def _strided_copy(plane, w, h, stride, esz_dtype):
     out = np.zeros(stride * h, esz_dtype)
     out.reshape(h, stride)[:, :w] = plane.reshape(h, w)

@@ -95,8 +95,8 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
       // float(u - 128) == float(u) - 128.0f exactly (small integers)   gainmapmath.cpp:579-580
       const f2 ub = (f2){(float)((u8[0][r] >> (8 * k)) & 0xffu), (float)((u8[1][r] >> (8 * k)) & 0xffu)};
       const f2 vb = (f2){(float)((v8[0][r] >> (8 * k)) & 0xffu), (float)((v8[1][r] >> (8 * k)) & 0xffu)};
-      uf[k] = (ub - splat(128.0f)) * splat(k255);
-      vf[k] = (vb - splat(128.0f)) * splat(k255);
+      uf[k] = (ub - splat(c.bias4096 * 0.03125f)) * splat(k255);   // 128.0f, opaque like the P010 bias below
+      vf[k] = (vb - splat(c.bias4096 * 0.03125f)) * splat(k255);
       // float((x >> 6) - 64) * (1/896) - 0.5   (gainmapmath.cpp:593-600), evaluated as
       // (float(x & 0xFFC0) - 4096) * (1/896/64) - 0.5: the masked 16-bit word is 64 * (x >> 6), so one mask per
       // two samples and one SDWA word->float conversion per sample replace shift + mask + subtract + convert;

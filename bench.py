@@ -161,6 +161,14 @@ def other_configs(lib, stream):
     ms = (time.perf_counter() - t0) / 5 * 1e3
     out["host-staged 4K pair (UHDR_HIP_MEM_HOST, pageable memory, PCIe both ways)"] = {
         "ms": round(ms, 3), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1)}
+    # editorhelper effects on one 4K YUV420 frame: byte gathers, read + write 12.4 MB each
+    fx_out = torch.zeros(W * H * 3 // 2 + 64, dtype=torch.uint8, device="cuda")
+    fin = api.Image(y.data_ptr(), W, H, api.CG_BT709, None, 0, 0, api.PIX_FMT_YUV420)
+    fo = api.out_image(fx_out.data_ptr())
+    for name, fn, fargs, obytes in (("rotate 90", lib.uhdr_hip_rotate, (90,), W * H * 3 // 2), ("mirror horizontal", lib.uhdr_hip_mirror, (1,), W * H * 3 // 2),
+                                    ("resize to 1920x1080", lib.uhdr_hip_resize, (1920, 1080), 1920 * 1080 * 3 // 2)):
+        ms = timed(lambda: fn(C.byref(fin), *fargs, C.byref(fo), api.MEM_DEVICE, stream), 10)
+        out["4K YUV420 " + name] = {"ms": round(ms, 4), "GB/s (bytes written + bytes they come from)": round(2 * obytes / (ms * 1e-3) / 1e9, 1)}
     # configs[4]: 7680x4320 decode-side apply
     w8, h8 = 7680, 4320
     _, y8 = synth.lcg_frame(w8, h8, 1234)

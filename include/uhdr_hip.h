@@ -76,6 +76,8 @@ extern "C" {
 #define UHDR_HIP_ERROR_INVALID_TRANS_FUNC (-10005)
 #define UHDR_HIP_ERROR_RESOLUTION_MISMATCH (-10006)
 #define UHDR_HIP_ERROR_BAD_METADATA (-10010)
+#define UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS (-10011)
+#define UHDR_HIP_ERROR_UNSUPPORTED_FEATURE (-30000)
 #define UHDR_HIP_ERROR_UNSUPPORTED_MAP_SCALE_FACTOR (-20008)
 #define UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE (-20009)
 
@@ -155,6 +157,22 @@ int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int me
  * BT.709 / BT.601(P3) / BT.2100 encodings. */
 int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_encoding, int mem_space,
                          void* stream);
+
+/* ---- editing effects (SURVEY.md 8(f) "next", rank 3) -------------------------------------------------
+ * crop / mirror / rotate / resize of lib/src/editorhelper.cpp:26-360 (lib/include/ultrahdr/editorhelper.h:49-63)
+ * on YUV420 or MONOCHROME images, byte-identical to the reference including its layout rules: the output is
+ * tightly packed (luma then U then V at out->data) except mirror and rotate-180, whose output strides follow
+ * the INPUT luma stride; crop's chroma copy runs over the full output height (:72).  out->data is
+ * caller-allocated; the call fills the other fields of *out.  in->chroma_data == NULL means "right after luma",
+ * strides of 0 mean "width" / "luma stride / 2", as in the reference. */
+int uhdr_hip_crop(const uhdr_hip_image_t* in_img, int left, int right, int top, int bottom, uhdr_hip_image_t* out_img,
+                  int mem_space, void* stream);
+/* mirror_dir: 0 = ULTRAHDR_MIRROR_VERTICAL, 1 = ULTRAHDR_MIRROR_HORIZONTAL */
+int uhdr_hip_mirror(const uhdr_hip_image_t* in_img, int mirror_dir, uhdr_hip_image_t* out_img, int mem_space, void* stream);
+int uhdr_hip_rotate(const uhdr_hip_image_t* in_img, int clockwise_degree, uhdr_hip_image_t* out_img, int mem_space,
+                    void* stream);
+int uhdr_hip_resize(const uhdr_hip_image_t* in_img, int out_width, int out_height, uhdr_hip_image_t* out_img,
+                    int mem_space, void* stream);
 
 /* ---- batches (device memory only, asynchronous on `stream`) ------------------------------ */
 /* The reference processes one image per call; a batch is n independent calls with identical

@@ -47,6 +47,7 @@ enum status_t : int {
   ULTRAHDR_NO_ERROR = 0, ULTRAHDR_UNKNOWN_ERROR = -1, ERROR_ULTRAHDR_BAD_PTR = -10001,
   ERROR_ULTRAHDR_INVALID_COLORGAMUT = -10003, ERROR_ULTRAHDR_INVALID_TRANS_FUNC = -10005,
   ERROR_ULTRAHDR_RESOLUTION_MISMATCH = -10006, ERROR_ULTRAHDR_BAD_METADATA = -10010,
+  ERROR_ULTRAHDR_INVALID_CROPPING_PARAMETERS = -10011, ERROR_ULTRAHDR_UNSUPPORTED_FEATURE = -30000,
   ERROR_ULTRAHDR_UNSUPPORTED_MAP_SCALE_FACTOR = -20008, ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE = -20009
 };
 
@@ -99,6 +100,15 @@ class UltraHdrHip {
   bool mReady = false;
   int mApplyMode = 0;
 };
+
+// ---- editing effects: the free functions of lib/include/ultrahdr/editorhelper.h:49-63, same signatures ----------
+enum ultrahdr_mirroring_direction : int { ULTRAHDR_MIRROR_VERTICAL = 0, ULTRAHDR_MIRROR_HORIZONTAL = 1 };
+
+// host images in, host images out (out_img->data caller-allocated), executed on HIP device 0
+status_t crop(uhdr_uncompressed_ptr const in_img, int left, int right, int top, int bottom, uhdr_uncompressed_ptr out_img);
+status_t mirror(uhdr_uncompressed_ptr const in_img, ultrahdr_mirroring_direction mirror_dir, uhdr_uncompressed_ptr out_img);
+status_t rotate(uhdr_uncompressed_ptr const in_img, int clockwise_degree, uhdr_uncompressed_ptr out_img);
+status_t resize(uhdr_uncompressed_ptr const in_img, int out_width, int out_height, uhdr_uncompressed_ptr out_img);
 
 }  // namespace ultrahdr
 

@@ -17,6 +17,7 @@ PIX_FMT_P010, PIX_FMT_YUV420, PIX_FMT_MONOCHROME = 0, 1, 2
 NO_ERROR, UNKNOWN_ERROR = 0, -1
 ERROR_BAD_PTR, ERROR_INVALID_COLORGAMUT, ERROR_INVALID_TRANS_FUNC = -10001, -10003, -10005
 ERROR_RESOLUTION_MISMATCH, ERROR_BAD_METADATA = -10006, -10010
+ERROR_INVALID_CROPPING_PARAMETERS, ERROR_UNSUPPORTED_FEATURE = -10011, -30000
 ERROR_UNSUPPORTED_MAP_SCALE_FACTOR, ERROR_INSUFFICIENT_RESOURCE = -20008, -20009
 MEM_HOST, MEM_DEVICE = 0, 1
 APPLY_FAST, APPLY_EXACT = 0, 1
@@ -53,6 +54,10 @@ SIGNATURES = {
     "uhdr_hip_convert_yuv": (C.c_int, [_IP, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_generate_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_void_p, C.c_void_p]),
     "uhdr_hip_apply_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_crop": (C.c_int, [_IP, C.c_int, C.c_int, C.c_int, C.c_int, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_mirror": (C.c_int, [_IP, C.c_int, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_rotate": (C.c_int, [_IP, C.c_int, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_resize": (C.c_int, [_IP, C.c_int, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_idw_tables": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "uhdr_hip_eval_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]),
 }

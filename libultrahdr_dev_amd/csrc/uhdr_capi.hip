@@ -734,4 +734,152 @@ int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_enc
   return UHDR_HIP_NO_ERROR;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// editorhelper effects.  fx_plan() restates the layout rules of editorhelper.cpp (output dims / strides /
+// chroma placement, plane-by-plane index maps); the bytes are moved by k_effect.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+enum { FXK_CROP, FXK_MIRROR, FXK_ROTATE, FXK_RESIZE };
+
+FxJob fx_job(const uint8_t* src, uint8_t* dst, size_t rows, size_t cols, size_t dst_stride, size_t src_stride, size_t in_w,
+             size_t in_h, int op) {
+  FxJob j;
+  j.src = src; j.dst = dst; j.rows = (uint32_t)rows; j.cols = (uint32_t)cols;
+  j.dst_stride = (uint32_t)dst_stride; j.src_stride = (uint32_t)src_stride;
+  j.in_w = (uint32_t)in_w; j.in_h = (uint32_t)in_h;
+  j.row_num = j.row_den = j.col_num = j.col_den = 1; j.op = op;
+  return j;
+}
+
+// in/out hold pointers valid in the memory space the kernel will run in
+int fx_plan(int kind, const uhdr_hip_image_t& in, int a, int b, int c, int d, uhdr_hip_image_t* out, FxJobs* jobs) {
+  const bool mono = in.pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
+  const size_t iw = in.width, ih = in.height;
+  const size_t ls = in.luma_stride != 0 ? in.luma_stride : iw;                 // editorhelper.cpp:44
+  const size_t cs = in.chroma_stride != 0 ? in.chroma_stride : (ls >> 1);      // :60-61
+  const uint8_t* sy = static_cast<const uint8_t*>(in.data);
+  const uint8_t* sc = in.chroma_data ? static_cast<const uint8_t*>(in.chroma_data) : sy + ls * ih;  // :66-69
+  uint8_t* dy = static_cast<uint8_t*>(out->data);
+  out->colorGamut = in.colorGamut;
+  out->pixelFormat = in.pixelFormat;
+  jobs->n = 0;
+  size_t ow, oh, ols;
+  if (kind == FXK_CROP) {           // a=left b=right c=top d=bottom   (:26-76)
+    ow = (size_t)(b - a + 1); oh = (size_t)(d - c + 1); ols = ow;
+    jobs->job[jobs->n++] = fx_job(sy + ls * c + a, dy, oh, ow, ols, ls, iw, ih, FX_COPY);
+  } else if (kind == FXK_MIRROR) {  // a=direction                      (:78-170)
+    ow = iw; oh = ih; ols = ls;
+    jobs->job[jobs->n++] = fx_job(sy, dy, oh, ow, ols, ls, iw, ih, a == 0 ? FX_FLIP_V : FX_FLIP_H);
+  } else if (kind == FXK_ROTATE) {  // a=degrees                        (:172-306)
+    if (a == 180) { ow = iw; oh = ih; ols = ls; } else { ow = ih; oh = iw; ols = ow; }
+    jobs->job[jobs->n++] = fx_job(sy, dy, oh, ow, ols, ls, iw, ih, a == 90 ? FX_ROT90 : a == 180 ? FX_ROT180 : FX_ROT270);
+  } else {                          // a=out_width b=out_height         (:308-360)
+    ow = (size_t)a; oh = (size_t)b; ols = ow;
+    FxJob j = fx_job(sy, dy, oh, ow, ols, ls, iw, ih, FX_RESIZE);
+    j.row_num = (uint32_t)ih; j.row_den = (uint32_t)oh; j.col_num = (uint32_t)iw; j.col_den = (uint32_t)ow;
+    jobs->job[jobs->n++] = j;
+  }
+  out->width = ow; out->height = oh; out->luma_stride = ols;
+  if (mono) return UHDR_HIP_NO_ERROR;
+  const size_t ocs = ols / 2;
+  uint8_t* dc = dy + ols * oh;
+  out->chroma_stride = ocs;
+  out->chroma_data = dc;
+  if (kind == FXK_CROP) {           // one copy of `oh` rows starting in the U plane (:70-73)
+    jobs->job[jobs->n++] = fx_job(sc + cs * (c / 2) + (a / 2), dc, oh, ow / 2, ocs, cs, iw / 2, ih, FX_COPY);
+  } else if (kind == FXK_RESIZE) {  // one pass over U and V (:350-357): rows and columns use the LUMA ratios
+    FxJob j = fx_job(sc, dc, oh, ow / 2, ocs, cs, iw / 2, ih, FX_RESIZE);
+    j.row_num = (uint32_t)ih; j.row_den = (uint32_t)oh; j.col_num = (uint32_t)iw; j.col_den = (uint32_t)ow;
+    jobs->job[jobs->n++] = j;
+  } else {                          // U then V, each (ih/2) x (iw/2)
+    const int op = jobs->job[0].op;
+    for (int p = 0; p < 2; ++p)
+      jobs->job[jobs->n++] = fx_job(sc + (p ? cs * (ih / 2) : 0), dc + (p ? ocs * (oh / 2) : 0), oh / 2, ow / 2, ocs, cs, iw / 2,
+                                    ih / 2, op);
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
+int fx_run(int kind, const uhdr_hip_image_t* in, int a, int b, int c, int d, uhdr_hip_image_t* out, int mem_space, void* stream) {
+  // argument checks in the reference's order (editorhelper.cpp:29-39, 81-88, 174-185, 310-317)
+  if (in == nullptr || in->data == nullptr || out == nullptr || out->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (kind == FXK_CROP && (a < 0 || (size_t)b >= in->width || c < 0 || (size_t)d >= in->height))
+    return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS;
+  if (kind == FXK_ROTATE && a != 90 && a != 180 && a != 270) return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS;
+  if (in->pixelFormat != UHDR_HIP_PIX_FMT_YUV420 && in->pixelFormat != UHDR_HIP_PIX_FMT_MONOCHROME)
+    return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  if (kind == FXK_RESIZE && (a <= 0 || b <= 0)) return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS;  // (ref: division by zero)
+  if (kind == FXK_CROP && (b < a || d < c)) return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS;      // (ref: negative memcpy size)
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FxJobs jobs;
+  if (mem_space == UHDR_HIP_MEM_DEVICE) {
+    if ((rc = fx_plan(kind, *in, a, b, c, d, out, &jobs)) != 0) return rc;
+    HIP_TRY(launch_effect(jobs, s));
+    return UHDR_HIP_NO_ERROR;
+  }
+  // host memory: stage exactly the bytes the reference touches
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  const bool mono = in->pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
+  const size_t iw = in->width, ih = in->height;
+  const size_t ls = in->luma_stride != 0 ? in->luma_stride : iw;
+  const size_t cs = in->chroma_stride != 0 ? in->chroma_stride : (ls >> 1);
+  const size_t luma_bytes = ih ? ls * (ih - 1) + iw : 0;
+  const size_t chroma_rows = mono ? 0 : ih;  // U and V stacked (crop / resize walk them as one plane)
+  const size_t chroma_bytes = chroma_rows ? cs * (chroma_rows - 1) + iw / 2 : 0;
+  if ((rc = stage_reserve(st, 0, luma_bytes)) != 0) return rc;
+  if ((rc = stage_reserve(st, 1, chroma_bytes)) != 0) return rc;
+  if (luma_bytes) HIP_TRY(hipMemcpyAsync(st->stage[0], in->data, luma_bytes, hipMemcpyHostToDevice, s));
+  const uint8_t* hc = in->chroma_data ? static_cast<const uint8_t*>(in->chroma_data)
+                                      : static_cast<const uint8_t*>(in->data) + ls * ih;
+  if (chroma_bytes) HIP_TRY(hipMemcpyAsync(st->stage[1], hc, chroma_bytes, hipMemcpyHostToDevice, s));
+  uhdr_hip_image_t din = *in, dout = *out;
+  din.data = st->stage[0];
+  din.chroma_data = mono ? nullptr : st->stage[1];
+  din.luma_stride = ls; din.chroma_stride = cs;
+  // upper bound of the output extent: every layout rule yields <= max(ls, ow) * oh * 3/2 bytes
+  uhdr_hip_image_t probe = *out;
+  uint8_t dummy = 0;
+  probe.data = &dummy;
+  FxJobs pj;
+  fx_plan(kind, *in, a, b, c, d, &probe, &pj);
+  const size_t out_luma = probe.luma_stride * probe.height;
+  const size_t out_chroma_rows = mono ? 0 : ((kind == FXK_CROP || kind == FXK_RESIZE) ? probe.height : 2 * (probe.height / 2));
+  const size_t out_bytes = out_luma + (out_chroma_rows ? probe.chroma_stride * (out_chroma_rows - 1) + probe.width / 2 : 0);
+  if ((rc = stage_reserve(st, 5, out_bytes)) != 0) return rc;
+  dout.data = st->stage[5];
+  if ((rc = fx_plan(kind, din, a, b, c, d, &dout, &jobs)) != 0) return rc;
+  // bytes the kernel does not write (stride padding of mirror / rotate-180) must keep the caller's content
+  if (out_bytes) HIP_TRY(hipMemcpyAsync(st->stage[5], out->data, out_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_effect(jobs, s));
+  if (out_bytes) HIP_TRY(hipMemcpyAsync(out->data, st->stage[5], out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  out->width = dout.width; out->height = dout.height; out->colorGamut = dout.colorGamut; out->pixelFormat = dout.pixelFormat;
+  out->luma_stride = dout.luma_stride;
+  if (!mono) {
+    out->chroma_stride = dout.chroma_stride;
+    out->chroma_data = static_cast<uint8_t*>(out->data) + out->luma_stride * out->height;
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+}  // namespace
+
+int uhdr_hip_crop(const uhdr_hip_image_t* in_img, int left, int right, int top, int bottom, uhdr_hip_image_t* out_img,
+                  int mem_space, void* stream) {
+  return fx_run(FXK_CROP, in_img, left, right, top, bottom, out_img, mem_space, stream);
+}
+int uhdr_hip_mirror(const uhdr_hip_image_t* in_img, int mirror_dir, uhdr_hip_image_t* out_img, int mem_space, void* stream) {
+  return fx_run(FXK_MIRROR, in_img, mirror_dir, 0, 0, 0, out_img, mem_space, stream);
+}
+int uhdr_hip_rotate(const uhdr_hip_image_t* in_img, int clockwise_degree, uhdr_hip_image_t* out_img, int mem_space,
+                    void* stream) {
+  return fx_run(FXK_ROTATE, in_img, clockwise_degree, 0, 0, 0, out_img, mem_space, stream);
+}
+int uhdr_hip_resize(const uhdr_hip_image_t* in_img, int out_width, int out_height, uhdr_hip_image_t* out_img, int mem_space,
+                    void* stream) {
+  return fx_run(FXK_RESIZE, in_img, out_width, out_height, 0, 0, out_img, mem_space, stream);
+}
+
 }  // extern "C"

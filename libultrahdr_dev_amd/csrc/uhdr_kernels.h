@@ -83,6 +83,21 @@ struct CvtImage {
   float m[9];
 };
 
+// ---- editorhelper effects (crop / mirror / rotate / resize): byte gathers over planes ---------------
+enum FxOp : int { FX_COPY = 0, FX_FLIP_V, FX_FLIP_H, FX_ROT90, FX_ROT180, FX_ROT270, FX_RESIZE };
+struct FxJob {            // dst[i][j] = src[f(i, j)] for i < rows, j < cols
+  const uint8_t* src;
+  uint8_t* dst;
+  uint32_t rows, cols, dst_stride, src_stride;
+  uint32_t in_w, in_h;    // extent of the source plane the index maps refer to
+  uint32_t row_num, row_den, col_num, col_den;  // FX_RESIZE: src row = i*row_num/row_den, src col = j*col_num/col_den
+  int op;
+};
+struct FxJobs {
+  FxJob job[3];
+  int n;
+};
+
 static_assert(sizeof(GenConsts) + sizeof(GenBatch) <= 4096, "generate kernel arguments exceed the kernarg segment");
 static_assert(sizeof(AppConsts) + sizeof(AppBatch) <= 4096, "apply kernel arguments exceed the kernarg segment");
 
@@ -96,6 +111,7 @@ hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, b
 hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s);
 hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s);
 hipError_t upload_idw4(const float* tables /* 4*64 floats */);
+hipError_t launch_effect(const FxJobs& j, hipStream_t s);
 hipError_t launch_eval_transfer(int fn, const float* in, float* out, size_t n, const EvalConsts& ec, hipStream_t s);
 
 }  // namespace uhdr

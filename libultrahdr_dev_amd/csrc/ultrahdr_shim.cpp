@@ -151,4 +151,40 @@ status_t UltraHdrHip::convertYuv(uhdr_uncompressed_ptr image, ultrahdr_color_gam
                                                     UHDR_HIP_MEM_HOST, nullptr));
 }
 
+// ---- editing effects (lib/src/editorhelper.cpp) ---------------------------------------------------------------
+namespace {
+template <typename Fn>
+status_t run_effect(uhdr_uncompressed_ptr const in_img, uhdr_uncompressed_ptr out_img, Fn&& call) {
+  if (in_img == nullptr || out_img == nullptr) return ERROR_ULTRAHDR_BAD_PTR;
+  static const int init_rc = uhdr_hip_init(0);
+  uhdr_hip_image_t i = to_c(*in_img), o = to_c(*out_img);
+  int rc = call(&i, &o);
+  if (rc == UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE && init_rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(init_rc);
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  from_c(o, out_img);
+  return ULTRAHDR_NO_ERROR;
+}
+}  // namespace
+
+status_t crop(uhdr_uncompressed_ptr const in_img, int left, int right, int top, int bottom, uhdr_uncompressed_ptr out_img) {
+  return run_effect(in_img, out_img, [&](uhdr_hip_image_t* i, uhdr_hip_image_t* o) {
+    return uhdr_hip_crop(i, left, right, top, bottom, o, UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+status_t mirror(uhdr_uncompressed_ptr const in_img, ultrahdr_mirroring_direction mirror_dir, uhdr_uncompressed_ptr out_img) {
+  return run_effect(in_img, out_img, [&](uhdr_hip_image_t* i, uhdr_hip_image_t* o) {
+    return uhdr_hip_mirror(i, static_cast<int>(mirror_dir), o, UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+status_t rotate(uhdr_uncompressed_ptr const in_img, int clockwise_degree, uhdr_uncompressed_ptr out_img) {
+  return run_effect(in_img, out_img, [&](uhdr_hip_image_t* i, uhdr_hip_image_t* o) {
+    return uhdr_hip_rotate(i, clockwise_degree, o, UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+status_t resize(uhdr_uncompressed_ptr const in_img, int out_width, int out_height, uhdr_uncompressed_ptr out_img) {
+  return run_effect(in_img, out_img, [&](uhdr_hip_image_t* i, uhdr_hip_image_t* o) {
+    return uhdr_hip_resize(i, out_width, out_height, o, UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+
 }  // namespace ultrahdr

@@ -76,6 +76,10 @@ def _declare(lib, p):
     d("generateGainMap", i32, IP, IP, i32, MP, C.c_void_p, i32, i32)
     d("applyGainMap", i32, IP, IP, MP, i32, f32, IP, i32)
     d("convertYuv", i32, IP, i32, i32)
+    d("crop", i32, IP, i32, i32, i32, i32, IP)
+    d("mirror", i32, IP, i32, IP)
+    d("rotate", i32, IP, i32, IP)
+    d("resize", i32, IP, i32, i32, IP)
     if p == "orc_":
         d("generateGainMapStats", i32, IP, IP, i32, MP, C.c_void_p, i32, i32, C.POINTER(f32))
         d("toneMap", i32, IP, IP)

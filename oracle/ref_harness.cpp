@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstring>
 
+#include "ultrahdr/editorhelper.h"
 #include "ultrahdr/gainmapmath.h"
 #include "uhdr_oracle.h"
 
@@ -161,6 +162,40 @@ void ref_transformYuv420(orc_image* i, size_t xc, size_t yc, int s, int d) {
   auto r = to_ref(i);
   ColorTransformFn f = yuv2yuv(s, d);
   if (f) transformYuv420(&r, xc, yc, f);
+}
+
+/* the reference's editorhelper.cpp, compiled in place */
+static void fx_back(const ultrahdr_uncompressed_struct& r, orc_image* o) {
+  o->width = r.width; o->height = r.height; o->colorGamut = r.colorGamut; o->chroma_data = r.chroma_data;
+  o->luma_stride = r.luma_stride; o->chroma_stride = r.chroma_stride; o->pixelFormat = r.pixelFormat;
+}
+int ref_crop(const orc_image* in, int l, int r, int t, int b, orc_image* out) {
+  if (!in || !out) return crop(nullptr, l, r, t, b, nullptr);
+  auto i = to_ref(in); auto o = to_ref(out);
+  int rc = crop(&i, l, r, t, b, &o);
+  if (rc == 0) fx_back(o, out);
+  return rc;
+}
+int ref_mirror(const orc_image* in, int dir, orc_image* out) {
+  if (!in || !out) return mirror(nullptr, ULTRAHDR_MIRROR_VERTICAL, nullptr);
+  auto i = to_ref(in); auto o = to_ref(out);
+  int rc = mirror(&i, dir == 0 ? ULTRAHDR_MIRROR_VERTICAL : ULTRAHDR_MIRROR_HORIZONTAL, &o);
+  if (rc == 0) fx_back(o, out);
+  return rc;
+}
+int ref_rotate(const orc_image* in, int deg, orc_image* out) {
+  if (!in || !out) return rotate(nullptr, deg, nullptr);
+  auto i = to_ref(in); auto o = to_ref(out);
+  int rc = rotate(&i, deg, &o);
+  if (rc == 0) fx_back(o, out);
+  return rc;
+}
+int ref_resize(const orc_image* in, int w, int h, orc_image* out) {
+  if (!in || !out) return resize(nullptr, w, h, nullptr);
+  auto i = to_ref(in); auto o = to_ref(out);
+  int rc = resize(&i, w, h, &o);
+  if (rc == 0) fx_back(o, out);
+  return rc;
 }
 
 /* jpegr.cpp:1199-1203 loop order over the reference's transformYuv420 */

@@ -710,6 +710,140 @@ int orc_toneMap(const orc_image* src, orc_image* dest) {
   return ORC_OK;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * editorhelper effects: lib/src/editorhelper.cpp:26-360, quirks included
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_ERR_INVALID_CROPPING_PARAMETERS (-10011)
+#define ORC_ERR_UNSUPPORTED_FEATURE (-30000)
+static int fx_check(const orc_image* in, orc_image* out) {
+  if (in == NULL || in->data == NULL || out == NULL || out->data == NULL) return ORC_ERR_BAD_PTR;
+  return ORC_OK;
+}
+static int fx_fmt_ok(const orc_image* in) { return in->pixelFormat == 1 || in->pixelFormat == 2; } /* YUV420 | MONO */
+static const uint8_t* fx_chroma(const orc_image* in, int ls) { /* :66-69 */
+  return in->chroma_data ? (const uint8_t*)in->chroma_data : (const uint8_t*)in->data + (size_t)ls * in->height;
+}
+
+/* editorhelper.cpp:26-76.  NOTE the chroma loop runs over out->height rows (:72): the V plane of the result is
+ * only the cropped V when nothing is cropped vertically -- kept as is */
+int orc_crop(const orc_image* in, int left, int right, int top, int bottom, orc_image* out) {
+  int rc = fx_check(in, out);
+  if (rc) return rc;
+  if (left < 0 || (size_t)right >= in->width || top < 0 || (size_t)bottom >= in->height)
+    return ORC_ERR_INVALID_CROPPING_PARAMETERS;
+  if (!fx_fmt_ok(in)) return ORC_ERR_UNSUPPORTED_FEATURE;
+  out->colorGamut = in->colorGamut; out->pixelFormat = in->pixelFormat;
+  int ls = in->luma_stride != 0 ? (int)in->luma_stride : (int)in->width;
+  out->width = right - left + 1; out->height = bottom - top + 1; out->luma_stride = out->width;
+  const uint8_t* src = (const uint8_t*)in->data + ls * top + left;
+  uint8_t* dst = (uint8_t*)out->data;
+  for (int i = 0; i < (int)out->height; i++) memcpy(dst + i * out->luma_stride, src + i * ls, out->width);
+  if (in->pixelFormat == 2) return ORC_OK;
+  int cs = in->chroma_stride != 0 ? (int)in->chroma_stride : (ls >> 1);
+  out->chroma_stride = out->luma_stride / 2;
+  out->chroma_data = (uint8_t*)out->data + out->luma_stride * out->height;
+  src = fx_chroma(in, ls) + cs * (top / 2) + (left / 2);
+  dst = (uint8_t*)out->chroma_data;
+  for (int i = 0; i < (int)out->height; i++) memcpy(dst + i * out->chroma_stride, src + i * cs, out->width / 2);
+  return ORC_OK;
+}
+
+/* editorhelper.cpp:78-170; dir 0 = vertical, 1 = horizontal.  Output strides follow the INPUT luma stride (:92) */
+int orc_mirror(const orc_image* in, int dir, orc_image* out) {
+  int rc = fx_check(in, out);
+  if (rc) return rc;
+  if (!fx_fmt_ok(in)) return ORC_ERR_UNSUPPORTED_FEATURE;
+  out->colorGamut = in->colorGamut; out->pixelFormat = in->pixelFormat;
+  int ls = in->luma_stride != 0 ? (int)in->luma_stride : (int)in->width;
+  out->width = in->width; out->height = in->height; out->luma_stride = ls;
+  int w = (int)out->width, h = (int)out->height;
+  const uint8_t* sy = (const uint8_t*)in->data;
+  uint8_t* dy = (uint8_t*)out->data;
+  for (int i = 0; i < h; i++)
+    for (int j = 0; j < w; j++)
+      dy[(dir == 0 ? (h - i - 1) : i) * ls + (dir == 0 ? j : j)] =
+          dir == 0 ? sy[i * ls + j] : sy[i * ls + (w - j - 1)];
+  if (dir != 0) { /* horizontal written as dest-indexed loop in the reference: same bytes */ }
+  if (in->pixelFormat == 2) return ORC_OK;
+  int cs = in->chroma_stride != 0 ? (int)in->chroma_stride : (ls >> 1);
+  out->chroma_stride = out->luma_stride / 2;
+  out->chroma_data = (uint8_t*)out->data + out->luma_stride * out->height;
+  int ocs = (int)out->chroma_stride;
+  const uint8_t* su = fx_chroma(in, ls);
+  uint8_t* du = (uint8_t*)out->chroma_data;
+  for (int p = 0; p < 2; p++) {
+    const uint8_t* sp = su + (p ? cs * ((int)in->height / 2) : 0);
+    uint8_t* dp = du + (p ? ocs * (h / 2) : 0);
+    for (int i = 0; i < h / 2; i++)
+      for (int j = 0; j < w / 2; j++) {
+        if (dir == 0) dp[(h / 2 - i - 1) * ocs + j] = sp[i * cs + j];
+        else dp[i * ocs + j] = sp[i * cs + ((int)in->width / 2 - j - 1)];
+      }
+  }
+  return ORC_OK;
+}
+
+/* editorhelper.cpp:172-306 */
+int orc_rotate(const orc_image* in, int deg, orc_image* out) {
+  int rc = fx_check(in, out);
+  if (rc) return rc;
+  if (deg != 90 && deg != 180 && deg != 270) return ORC_ERR_INVALID_CROPPING_PARAMETERS;
+  if (!fx_fmt_ok(in)) return ORC_ERR_UNSUPPORTED_FEATURE;
+  out->colorGamut = in->colorGamut; out->pixelFormat = in->pixelFormat;
+  int ls = in->luma_stride != 0 ? (int)in->luma_stride : (int)in->width;
+  int iw = (int)in->width, ih = (int)in->height;
+  if (deg == 180) { out->width = iw; out->height = ih; out->luma_stride = ls; }
+  else { out->width = ih; out->height = iw; out->luma_stride = out->width; }
+  int ow = (int)out->width, oh = (int)out->height, ols = (int)out->luma_stride;
+  const uint8_t* sy = (const uint8_t*)in->data;
+  uint8_t* dy = (uint8_t*)out->data;
+  for (int i = 0; i < oh; i++)
+    for (int j = 0; j < ow; j++)
+      dy[i * ols + j] = deg == 90 ? sy[(ih - j - 1) * ls + i]
+                      : deg == 180 ? sy[(ih - i - 1) * ls + (iw - j - 1)] : sy[j * ls + (iw - i - 1)];
+  if (in->pixelFormat == 2) return ORC_OK;
+  int cs = in->chroma_stride != 0 ? (int)in->chroma_stride : (ls >> 1);
+  out->chroma_stride = out->luma_stride / 2;
+  out->chroma_data = (uint8_t*)out->data + out->luma_stride * out->height;
+  int ocs = (int)out->chroma_stride;
+  const uint8_t* su = fx_chroma(in, ls);
+  uint8_t* du = (uint8_t*)out->chroma_data;
+  for (int p = 0; p < 2; p++) {
+    const uint8_t* sp = su + (p ? cs * (ih / 2) : 0);
+    uint8_t* dp = du + (p ? ocs * (oh / 2) : 0);
+    for (int i = 0; i < oh / 2; i++)
+      for (int j = 0; j < ow / 2; j++)
+        dp[i * ocs + j] = deg == 90 ? sp[(ih / 2 - j - 1) * cs + i]
+                        : deg == 180 ? sp[(ih / 2 - i - 1) * cs + (iw / 2 - j - 1)] : sp[j * cs + (iw / 2 - i - 1)];
+  }
+  return ORC_OK;
+}
+
+/* editorhelper.cpp:308-360: nearest neighbour; the chroma loop covers U and V in one go (rows < out height, :350) */
+int orc_resize(const orc_image* in, int ow, int oh, orc_image* out) {
+  int rc = fx_check(in, out);
+  if (rc) return rc;
+  if (!fx_fmt_ok(in)) return ORC_ERR_UNSUPPORTED_FEATURE;
+  out->colorGamut = in->colorGamut; out->pixelFormat = in->pixelFormat;
+  int ls = in->luma_stride != 0 ? (int)in->luma_stride : (int)in->width;
+  out->width = ow; out->height = oh; out->luma_stride = out->width;
+  const uint8_t* sy = (const uint8_t*)in->data;
+  uint8_t* dy = (uint8_t*)out->data;
+  for (int i = 0; i < oh; i++)
+    for (int j = 0; j < ow; j++)
+      dy[i * out->luma_stride + j] = sy[(size_t)i * in->height / out->height * ls + (size_t)j * in->width / out->width];
+  if (in->pixelFormat == 2) return ORC_OK;
+  int cs = in->chroma_stride != 0 ? (int)in->chroma_stride : (ls >> 1);
+  out->chroma_stride = out->luma_stride / 2;
+  out->chroma_data = (uint8_t*)out->data + out->luma_stride * out->height;
+  const uint8_t* sc = fx_chroma(in, ls);
+  uint8_t* dc = (uint8_t*)out->chroma_data;
+  for (int i = 0; i < oh; i++)
+    for (int j = 0; j < ow / 2; j++)
+      dc[i * out->chroma_stride + j] = sc[(size_t)i * in->height / out->height * cs + (size_t)j * in->width / out->width];
+  return ORC_OK;
+}
+
 /* batch evaluation of the scalar functions (tests compare the device functions against these) */
 void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost) {
   float l2min = (float)log2((double)minBoost), l2max = (float)log2((double)maxBoost);

@@ -99,6 +99,12 @@ int orc_applyGainMap(const orc_image* yuv420, const orc_image* gainmap,
 int orc_toneMap(const orc_image* src, orc_image* dest);
 int orc_convertYuv(orc_image* image, int src_encoding, int dest_encoding);
 
+/* editorhelper effects (lib/src/editorhelper.cpp); out->data is caller-allocated; mirror dir: 0 vertical, 1 horizontal */
+int orc_crop(const orc_image* in, int left, int right, int top, int bottom, orc_image* out);
+int orc_mirror(const orc_image* in, int dir, orc_image* out);
+int orc_rotate(const orc_image* in, int clockwise_degree, orc_image* out);
+int orc_resize(const orc_image* in, int out_width, int out_height, orc_image* out);
+
 /* fn: 0 srgbInvOetf 1 hlgInvOetf 2 pqInvOetf 3 encodeGain(y_sdr=1,y_hdr=x) 4 hlgOetf 5 pqOetf */
 void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost);
 

@@ -91,6 +91,20 @@ int main(int argc, char** argv) {
   CHECK(uhdr.convertYuv(&ci, ULTRAHDR_COLORGAMUT_BT709, ULTRAHDR_COLORGAMUT_P3) == ULTRAHDR_NO_ERROR);
   CHECK(uhdr.convertYuv(&ci, ULTRAHDR_COLORGAMUT_UNSPECIFIED, ULTRAHDR_COLORGAMUT_P3) == ERROR_ULTRAHDR_INVALID_COLORGAMUT);
   dump(out + "/convert_709_601.bin", cv.data(), cv.size());
+  // editorhelper free functions on the 1280x720 SDR frame (tests/editorhelper_test.cpp shape: status + dims)
+  std::vector<uint8_t> fx(w * h * 3 / 2 + 64);
+  ultrahdr_uncompressed_struct fin = yuv420, fout{};
+  fin.pixelFormat = ULTRAHDR_PIX_FMT_YUV420;
+  fout.data = fx.data();
+  CHECK(rotate(&fin, 90, &fout) == ULTRAHDR_NO_ERROR && fout.width == h && fout.height == w && fout.pixelFormat == ULTRAHDR_PIX_FMT_YUV420);
+  dump(out + "/rotate90.bin", fx.data(), w * h * 3 / 2);
+  CHECK(crop(&fin, 100, 739, 40, 519, &fout) == ULTRAHDR_NO_ERROR && fout.width == 640 && fout.height == 480);
+  dump(out + "/crop.bin", fx.data(), 640 * 480 * 3 / 2);
+  CHECK(mirror(&fin, ULTRAHDR_MIRROR_HORIZONTAL, &fout) == ULTRAHDR_NO_ERROR && fout.width == w);
+  dump(out + "/mirror_h.bin", fx.data(), w * h * 3 / 2);
+  CHECK(resize(&fin, 640, 360, &fout) == ULTRAHDR_NO_ERROR && fout.width == 640 && fout.height == 360);
+  dump(out + "/resize.bin", fx.data(), 640 * 360 * 3 / 2);
+  CHECK(rotate(&fin, 45, &fout) == ERROR_ULTRAHDR_INVALID_CROPPING_PARAMETERS);
   printf("shim_test ok\n");
   return 0;
 }

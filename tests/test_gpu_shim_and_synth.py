@@ -49,6 +49,15 @@ def test_cpp_shim_on_reference_fixture(hip, orc, tmp_path):
     img = orc.yuv420_image(cv, w, h, 0)
     assert orc.load().orc_convertYuv(C.byref(img), 0, 1) == 0
     assert np.array_equal(np.fromfile(tmp_path / "convert_709_601.bin", np.uint8), cv)
+    # editorhelper free functions against the oracle (itself checked against the reference's editorhelper.cpp)
+    L = orc.load()
+    src = orc.Image(yuv.ctypes.data, w, h, 0, yuv.ctypes.data + w * h, w, w // 2, orc.FMT_YUV420)
+    for fname, fn, args, nbytes in (("rotate90.bin", L.orc_rotate, (90,), w * h * 3 // 2), ("crop.bin", L.orc_crop, (100, 739, 40, 519), 640 * 480 * 3 // 2),
+                                    ("mirror_h.bin", L.orc_mirror, (1,), w * h * 3 // 2), ("resize.bin", L.orc_resize, (640, 360), 640 * 360 * 3 // 2)):
+        o = np.zeros(w * h * 3 // 2 + 64, np.uint8)
+        oi = orc.Image(o.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+        assert fn(C.byref(src), *args, C.byref(oi)) == 0
+        assert np.array_equal(np.fromfile(tmp_path / fname, np.uint8), o[:nbytes]), fname
 
 
 def test_hbm_synthetic_frames_match_the_survey_lcg(hip, orc):

@@ -394,3 +394,72 @@ def test_error_codes_follow_the_reference_order(orc):                           
     assert orc.apply("orc_", yi, m, bad, 2, 4.0)[0] == -10010
     assert orc.apply("orc_", yi, np.zeros((2, 3), np.uint8), good, 2, 4.0)[0] == -20008
     assert orc.apply("orc_", yi, np.zeros((4, 4), np.uint8), good, 2, 4.0)[0] == -20008
+
+
+# ---------------------------------------------------------------------------------------------------
+# editorhelper effects against the reference's own editorhelper.cpp object code
+# ---------------------------------------------------------------------------------------------------
+def _fx_image(orc, rng, w, h, mono, ls=None, cs=None, sep_chroma=False):
+    ls = ls or w
+    cs = cs or ls // 2
+    luma = rng.randint(0, 256, ls * h).astype(np.uint8)
+    if mono:
+        return (luma,), orc.Image(luma.ctypes.data, w, h, 0, None, ls, 0, orc.FMT_MONOCHROME)
+    if sep_chroma:
+        chroma = rng.randint(0, 256, cs * h).astype(np.uint8)
+        return (luma, chroma), orc.Image(luma.ctypes.data, w, h, 1, chroma.ctypes.data, ls, cs, orc.FMT_YUV420)
+    buf = rng.randint(0, 256, ls * h + cs * h).astype(np.uint8)
+    return (buf,), orc.Image(buf.ctypes.data, w, h, 1, None, ls, cs if cs != ls // 2 else 0, orc.FMT_YUV420)
+
+
+def _fx_cases():
+    cases = []
+    for mono in (False, True):
+        cases += [("crop", mono, (10, 53, 4, 31)), ("crop", mono, (0, 63, 0, 39)), ("crop", mono, (2, 2, 6, 7)),
+                  ("mirror", mono, (0,)), ("mirror", mono, (1,)), ("rotate", mono, (90,)), ("rotate", mono, (180,)),
+                  ("rotate", mono, (270,)), ("resize", mono, (128, 80)), ("resize", mono, (32, 20)), ("resize", mono, (50, 34))]
+    return cases
+
+
+def _fx_run(orc, lib, prefix, name, img, args, out_bytes):
+    out = np.full(out_bytes, 0xCC, np.uint8)
+    oimg = orc.Image(out.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+    rc = getattr(lib, prefix + name)(C.byref(img), *args, C.byref(oimg))
+    return rc, out, (oimg.width, oimg.height, oimg.colorGamut, oimg.luma_stride, oimg.chroma_stride, oimg.pixelFormat,
+                     (oimg.chroma_data or 0) - out.ctypes.data if oimg.chroma_data else None)
+
+
+@pytest.mark.parametrize("layout", ["tight", "strided", "separate_chroma"])
+def test_effects_restatement_equals_reference_object_code(orc, layout):
+    R = orc.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    L = orc.load()
+    rng = np.random.RandomState(5)
+    w, h = 64, 40
+    for name, mono, args in _fx_cases():
+        ls = w + 6 if layout != "tight" else None
+        cs = (w + 6) // 2 + 3 if layout == "separate_chroma" else None
+        keep, img = _fx_image(orc, rng, w, h, mono, ls, cs, sep_chroma=(layout == "separate_chroma"))
+        nbytes = 4 * (max(w, 128) + 8) * (max(h, 80) + 8)
+        a = _fx_run(orc, L, "orc_", name, img, args, nbytes)
+        b = _fx_run(orc, R, "ref_", name, img, args, nbytes)
+        assert a[0] == b[0] == 0, (name, args, a[0], b[0])
+        assert a[2] == b[2], (name, mono, args, a[2], b[2])
+        assert np.array_equal(a[1], b[1]), (name, mono, args)
+
+
+def test_effects_error_codes(orc):                                              # editorhelper.cpp:29-39,175-185
+    L = orc.load()
+    rng = np.random.RandomState(1)
+    keep, img = _fx_image(orc, rng, 32, 16, False)
+    out = np.zeros(4096, np.uint8)
+    o = orc.Image(out.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+    assert L.orc_crop(None, 0, 1, 0, 1, C.byref(o)) == -10001
+    assert L.orc_crop(C.byref(img), -1, 5, 0, 5, C.byref(o)) == -10011
+    assert L.orc_crop(C.byref(img), 0, 32, 0, 5, C.byref(o)) == -10011
+    assert L.orc_crop(C.byref(img), 0, 5, 0, 16, C.byref(o)) == -10011
+    assert L.orc_rotate(C.byref(img), 45, C.byref(o)) == -10011
+    p010 = orc.Image(img.data, 32, 16, 0, None, 0, 0, orc.FMT_P010)
+    assert L.orc_mirror(C.byref(p010), 0, C.byref(o)) == -30000
+    assert L.orc_resize(C.byref(p010), 8, 8, C.byref(o)) == -30000

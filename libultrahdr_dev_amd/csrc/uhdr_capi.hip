@@ -160,11 +160,6 @@ bool valid_gamut(int g) { return g >= UHDR_HIP_CG_BT709 && g <= UHDR_HIP_CG_BT21
 bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // ---- generate ------------------------------------------------------------------------------------
-struct GenPlan {
-  GenConsts c;
-  int hdr_tf;
-};
-
 // checks of ultrahdr.cpp:189-202 + the switch defaults of :222-302, in the reference's order
 int validate_generate(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* p010, int hdr_tf,
                       const uhdr_hip_metadata_t* md, const uhdr_hip_image_t* dest) {

@@ -1,13 +1,16 @@
 // uhdr_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the Ultra HDR gain-map path.
 //
 //   k_generate<TF,ALIGNED>   UltraHdr::generateGainMap hot loop   (ref lib/src/ultrahdr.cpp:308-338)
-//   k_apply_s4<FMT>          UltraHdr::applyGainMap hot loop, scale 4, FAST arithmetic (:427-496)
+//   k_apply_s4<FMT,MASK>     UltraHdr::applyGainMap hot loop, scale 4, FAST arithmetic (:427-496)
 //   k_apply_px<FMT,EXACT>    same loop, any integer scale / any alignment / EXACT arithmetic
 //   k_tonemap_*              UltraHdr::toneMap                    (:517-558)
 //   k_convert_yuv<ALIGNED>   JpegR::convertYuv + transformYuv420  (lib/src/jpegr.cpp:1199-1203,
 //                                                                  lib/src/gainmapmath.cpp:483-520)
+//   k_effect, k_effect_rot   crop / mirror / rotate / resize      (lib/src/editorhelper.cpp:26-360)
+//   k_eval_transfer          scalar transfer functions over arrays (diagnostics for the exhaustive tests)
 //
-// All of it is pointwise, HBM-bound byte/float work: no MFMA.  Design rules followed here:
+// All of it is pointwise byte/float work: no MFMA.  Measured, generate and apply are bound by VALU /
+// special-function issue rather than by HBM.  Design rules followed here:
 //   * one wave64 reads whole contiguous row segments (16 B/lane for P010, 8 B/lane for 8-bit luma),
 //     stores are 16 B/lane; no LDS round trip is needed because every input byte is consumed by
 //     exactly one lane;
@@ -414,7 +417,6 @@ __device__ __forceinline__ float map_to_float(uint32_t v) { return (float)v / 25
 //     with the products w_i*A pre-multiplied on the host (AppFast::wA, SGPR operands);
 //   * the *1023 of the 10-bit pack is folded into the OETF constants;
 //   * clamps are written as min(max()) so that they fold into the producing add's clamp modifier.
-__device__ __forceinline__ float sat01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 __device__ __forceinline__ f2 log2_2(f2 v) { return (f2){__builtin_amdgcn_logf(v.x), __builtin_amdgcn_logf(v.y)}; }
 __device__ __forceinline__ f2 exp2_2(f2 v) { return (f2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
 __device__ __forceinline__ f2 sqrt_2(f2 v) { return (f2){__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)}; }

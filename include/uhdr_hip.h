@@ -205,6 +205,7 @@ int uhdr_hip_idw_tables(int scale, float* out);
  *   fn 3      encodeGain byte (as float) of gain in[i] for (min_boost, max_boost), generate's version
  *   fn 10..13 the same four through the exact (ocml f64) path;  14/15 HLG / PQ OETF exact
  *   fn 20/24/25 apply-FAST sRGB EOTF / HLG OETF / PQ OETF
+ *   fn 30/31   gain-map byte -> float through the constant division / the IEEE division (in[i] = byte as float)
  *   fn 100/101 1.0 where the lean path of fn 0/1 passed its rounding test, else 0.0
  * Used by the exhaustive transfer-function tests. */
 int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float min_boost, float max_boost,

@@ -402,6 +402,9 @@ __device__ __forceinline__ F3 hdr_oetf(F3 e) {
 }
 
 __device__ __forceinline__ float map_to_float(uint32_t v) { return (float)v / 255.0f; }  // gainmapmath.cpp:632
+// the same value in 3 issue slots instead of the ~10 of an IEEE division: exact for all 256 map bytes
+// (tests/test_gpu_transfer_exhaustive.py::test_map_byte_to_float_is_exact)
+__device__ __forceinline__ float map_to_float_fast(uint32_t v) { return div_const((float)v, 255.0f, 1.0f / 255.0f); }
 
 // ---- FAST path, scale factor 4 ---------------------------------------------------------------
 // Thread = one gain-map cell = a 4x4 pixel block.  The four map taps and the four 2x2 chroma samples
@@ -549,7 +552,7 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
       const f2 yf = (f2){(float)(yw & 0xffu), (float)((yw >> 8) & 0xffu)} * splat(k255);
       po[pr] = apply_pair<FMT, MASK>(yf, crv[oy >> 1][pr], gsum[oy >> 1][pr], cbu[oy >> 1][pr], E);
     }
-    const size_t pix0 = (size_t)(4u * cy + oy) * c.width + 4u * cx;
+    const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
     if (FMT == 2 || FMT == 3) {
       uint4 o;
       o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
@@ -584,22 +587,25 @@ __global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBa
   const uint32_t cy = idx / c.map_w;
   const uint32_t cx = idx - cy * c.map_w;
 
+  // 32-bit offsets (an image plane is < 4 GiB): one 64-bit add per address instead of 64-bit multiply-adds
   uint32_t yrow[4];
+  const uint32_t yoff = 4u * cy * im.y_stride + 4u * cx;
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    yrow[r] = *reinterpret_cast<const uint32_t*>(im.y + (size_t)(4u * cy + r) * im.y_stride + 4u * cx);
+  for (int r = 0; r < 4; ++r) yrow[r] = *reinterpret_cast<const uint32_t*>(im.y + (yoff + r * im.y_stride));
   uint32_t uu[2], vv[2];
+  const uint32_t coff = 2u * cy * im.c_stride + 2u * cx;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    uu[r] = *reinterpret_cast<const uint16_t*>(im.u + (size_t)(2u * cy + r) * im.c_stride + 2u * cx);
-    vv[r] = *reinterpret_cast<const uint16_t*>(im.v + (size_t)(2u * cy + r) * im.c_stride + 2u * cx);
+    uu[r] = *reinterpret_cast<const uint16_t*>(im.u + (coff + r * im.c_stride));
+    vv[r] = *reinterpret_cast<const uint16_t*>(im.v + (coff + r * im.c_stride));
   }
   // sampleMap taps (gainmapmath.cpp:690-703): the reference indexes the map with map->width
   const uint32_t xu = min(cx + 1u, c.map_w - 1u), yu = min(cy + 1u, c.map_h - 1u);
-  const float e1 = map_to_float(im.map[(size_t)cy * c.map_w + cx]);
-  const float e2 = map_to_float(im.map[(size_t)yu * c.map_w + cx]);
-  const float e3 = map_to_float(im.map[(size_t)cy * c.map_w + xu]);
-  const float e4 = map_to_float(im.map[(size_t)yu * c.map_w + xu]);
+  const uint32_t m0 = cy * c.map_w, m1 = yu * c.map_w;
+  const float e1 = map_to_float_fast(im.map[m0 + cx]);
+  const float e2 = map_to_float_fast(im.map[m1 + cx]);
+  const float e3 = map_to_float_fast(im.map[m0 + xu]);
+  const float e4 = map_to_float_fast(im.map[m1 + xu]);
   const bool edge_x = (xu == cx), edge_y = (yu == cy);
   const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
   // all waves but those touching the last column/row of cells take the SGPR-weight path
@@ -960,6 +966,8 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 24: y = hlg_oetf_fast(x); break;
     case 25: y = pq_oetf_fast(x); break;
     case 20: y = srgb_inv_oetf_fast(x); break;
+    case 30: y = map_to_float_fast((uint32_t)x); break;
+    case 31: y = map_to_float((uint32_t)x); break;
     // 1.0 where the lean f64 path was accepted by the rounding test, 0.0 where the exact path ran
     case 100: { const float t = div_const(x + 0.055f, 1.055f, 1.0f / 1.055f);
                 float v1[1] = {x};

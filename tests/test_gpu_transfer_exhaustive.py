@@ -91,3 +91,13 @@ def test_guarded_encode_gain_equals_glibc_oracle(hip, orc):
         got = _eval(lib, hip, 3, torch.from_numpy(xs).cuda(), mn, mx).cpu().numpy()
         want = orc.eval_transfer(3, xs, mn, mx, threads=16)
         assert np.array_equal(got, want)
+
+
+def test_map_byte_to_float_is_exact(hip):
+    """gain-map byte / 255.0f (gainmapmath.cpp:632) through the 3-instruction constant division used by the FAST
+    apply kernel equals the IEEE division for all 256 bytes"""
+    lib = hip.load()
+    x = torch.arange(256, dtype=torch.float32, device="cuda")
+    assert torch.equal(_eval(lib, hip, 30, x).view(torch.int32), _eval(lib, hip, 31, x).view(torch.int32))
+    want = (np.arange(256, dtype=np.float32) / np.float32(255.0)).view(np.uint32)
+    assert np.array_equal(_eval(lib, hip, 31, x).cpu().numpy().view(np.uint32), want)

@@ -249,6 +249,7 @@ GenImage gen_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& p010, vo
 }
 bool gen_aligned(const GenImage& g, uint32_t w, uint32_t h) {
   const uint8_t* v = g.u + (size_t)g.c_stride * (h / 2u);
+  if ((uint64_t)g.hy_stride * h >= (1ull << 31) || (uint64_t)g.y_stride * h >= (1ull << 32)) return false;  // 32-bit offsets
   return (w % 8u == 0) && al(g.hy, 16) && g.hy_stride % 8u == 0 && al(g.huv, 16) && g.huv_stride % 8u == 0 &&
          al(g.y, 8) && g.y_stride % 8u == 0 && al(g.u, 4) && al(v, 4) && g.c_stride % 4u == 0 && al(g.map, 2);
 }

@@ -202,11 +202,14 @@ __device__ __forceinline__ double fast_exp2(double P) {
 }
 
 // Ziv test: may y (relative error < 2^-38) be rounded to float without knowing its last bits?
+// NORMAL_RANGE: the caller guarantees y rounds to a normal float (otherwise the midpoint pattern differs and
+// the test must fail, which the y >= 2^-126 comparison ensures).
+template <bool NORMAL_RANGE = false>
 __device__ __forceinline__ bool ziv_safe(double y) {
   const uint32_t lo = (uint32_t)__double2loint(y);
   const int32_t dist = (int32_t)(lo & 0x1FFFFFFFu) - 0x10000000;  // low 29 bits vs the float midpoint
   const uint32_t ad = (uint32_t)(dist < 0 ? -dist : dist);
-  return ad > (1u << 16) && y >= 0x1p-126;  // 2^-38 relative = 2^15 double ulps; 2x margin
+  return ad > (1u << 16) && (NORMAL_RANGE || y >= 0x1p-126);  // 2^-38 relative = 2^15 double ulps; 2x margin
 }
 
 // x / a for a compile-time constant a, as q + fma(-q, a, x) * (1/a).  Not correctly rounded for
@@ -250,7 +253,7 @@ __device__ __forceinline__ void srgb_inv_oetf_guarded_n(float (&e)[N]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     float p = (float)y[j];
-    if (e[j] > 0.04045f && !ziv_safe(y[j])) p = srgb_inv_oetf_slow(e[j]);
+    if (e[j] > 0.04045f && !ziv_safe<true>(y[j])) p = srgb_inv_oetf_slow(e[j]);   // p >= 0.0031 here
     e[j] = (e[j] <= 0.04045f) ? lin[j] : p;
   }
 }
@@ -278,7 +281,7 @@ __device__ __forceinline__ void hlg_inv_oetf_guarded_n(float (&e)[N]) {
   for (int j = 0; j < N; ++j) {
     const double yy = (y[j] + (double)UHDR_HLG_B) * (1.0 / 12.0);
     float hi = (float)yy;
-    if (e[j] > 0.5f && !ziv_safe(yy)) hi = hlg_inv_oetf_slow(e[j]);
+    if (e[j] > 0.5f && !ziv_safe<true>(yy)) hi = hlg_inv_oetf_slow(e[j]);         // hi >= 1/12 here
     e[j] = (e[j] <= 0.5f) ? lo[j] : hi;
   }
 }

@@ -258,19 +258,22 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
 
     uint32_t hy[2][4][2], huv[2][2][2], y8[2][4], u8[2][2], v8[2][2];
     if (ALIGNED) {
+      // 32-bit element offsets (every plane is < 4 GiB on this path): one 64-bit add per address
+      const uint32_t hoff = 4u * my * im.hy_stride + 8u * pr, yoff = 4u * my * im.y_stride + 8u * pr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint4 q = *reinterpret_cast<const uint4*>(im.hy + (size_t)(4u * my + r) * im.hy_stride + 8u * pr);
+        const uint4 q = *reinterpret_cast<const uint4*>(im.hy + (hoff + r * im.hy_stride));
         hy[0][r][0] = q.x; hy[0][r][1] = q.y; hy[1][r][0] = q.z; hy[1][r][1] = q.w;
-        const uint2 p = *reinterpret_cast<const uint2*>(im.y + (size_t)(4u * my + r) * im.y_stride + 8u * pr);
+        const uint2 p = *reinterpret_cast<const uint2*>(im.y + (yoff + r * im.y_stride));
         y8[0][r] = p.x; y8[1][r] = p.y;
       }
+      const uint32_t huvoff = 2u * my * im.huv_stride + 8u * pr, coff = 2u * my * im.c_stride + 4u * pr;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        const uint4 q = *reinterpret_cast<const uint4*>(im.huv + (size_t)(2u * my + r) * im.huv_stride + 8u * pr);
+        const uint4 q = *reinterpret_cast<const uint4*>(im.huv + (huvoff + r * im.huv_stride));
         huv[0][r][0] = q.x; huv[0][r][1] = q.y; huv[1][r][0] = q.z; huv[1][r][1] = q.w;
-        const uint32_t uu = *reinterpret_cast<const uint32_t*>(im.u + (size_t)(2u * my + r) * im.c_stride + 4u * pr);
-        const uint32_t vv = *reinterpret_cast<const uint32_t*>(im_v + (size_t)(2u * my + r) * im.c_stride + 4u * pr);
+        const uint32_t uu = *reinterpret_cast<const uint32_t*>(im.u + (coff + r * im.c_stride));
+        const uint32_t vv = *reinterpret_cast<const uint32_t*>(im_v + (coff + r * im.c_stride));
         u8[0][r] = uu & 0xffffu; u8[1][r] = uu >> 16;
         v8[0][r] = vv & 0xffffu; v8[1][r] = vv >> 16;
       }

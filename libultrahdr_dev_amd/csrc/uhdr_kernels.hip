@@ -443,6 +443,11 @@ __device__ __forceinline__ f2 pk_mul_sat(f2 a, f2 b) {
   asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ f2 pk_fma_sat(f2 a, f2 b, f2 c) {
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 // The piecewise transfer functions are evaluated WITHOUT per-lane selects (v_cmp + v_cndmask cost 2 issue
 // slots per value and cannot be packed).  For a function  f(e) = A(e) for e <= j,  B(e) for e > j :
@@ -474,11 +479,10 @@ __device__ __forceinline__ f2 oetf2_scaled(f2 e) {
     return sel_le(e, 1.0f / 12.0f, lo, hi);
   } else if (FMT == 3) {  // HLG (gainmapmath.cpp:259-265): sqrt(3e) | a ln(12e-b)+c, times 1023
     constexpr float K = 1023.0f;
-    const f2 lo = sqrt_2(pk_mul_sat(e, splat(12.0f))) * splat(0.5f * K);               // K sqrt(3 min(e, 1/12))
     const f2 d = pk_add_sat(e, splat(-1.0f / 12.0f));                                  // max(e, 1/12) - 1/12
     const f2 arg = pk_fma(d, splat(12.0f), splat(1.0f - UHDR_HLG_B));
     const f2 hi = pk_fma(log2_2(arg), splat(UHDR_HLG_A * 0.693147180559945f * K), splat(UHDR_HLG_C * K - 0.5f * K));
-    return lo + hi;
+    return pk_fma(sqrt_2(pk_mul_sat(e, splat(12.0f))), splat(0.5f * K), hi);           // K sqrt(3 min(e, 1/12)) + hi
   } else if (FMT == 2) {  // PQ (gainmapmath.cpp:309-312): ((c1 + c2 e^m1) / (1 + c3 e^m1))^m2, times 1023
     // e == 0: log2 -> -inf, e^m1 -> 0, result c1^m2 * 1023 = 7e-4, which truncates to the reference's 0
     const f2 p = exp2_2(log2_2(e) * splat(UHDR_PQ_M1));
@@ -488,6 +492,16 @@ __device__ __forceinline__ f2 oetf2_scaled(f2 e) {
     return e * splat(1023.0f);
   }
   return e;
+}
+
+// HLG OETF of lin * factor for bounded inputs, without forming the product: min(12 e, 1) = sat(lin * 12F) and
+// max(e, 1/12) - 1/12 = sat(lin * F - 1/12) are one packed op each
+__device__ __forceinline__ f2 hlg_oetf2_of_product(f2 lin, f2 factor, f2 factor12) {
+  constexpr float K = 1023.0f;
+  const f2 d = pk_fma_sat(lin, factor, splat(-1.0f / 12.0f));
+  const f2 arg = pk_fma(d, splat(12.0f), splat(1.0f - UHDR_HLG_B));
+  const f2 hi = pk_fma(log2_2(arg), splat(UHDR_HLG_A * 0.693147180559945f * K), splat(UHDR_HLG_C * K - 0.5f * K));
+  return pk_fma(sqrt_2(pk_mul_sat(lin, factor12)), splat(0.5f * K), hi);
 }
 
 struct PairOut { f2 r, g, b; };
@@ -501,9 +515,16 @@ __device__ __forceinline__ PairOut apply_pair(f2 yf, float crv, float gsum, floa
   const f2 b = pk_add_sat(yf, splat(cbu));
   const f2 factor = exp2_2(E);  // applyGain's 2^(logBoost*displayBoost/max) / displayBoost
   PairOut o;
-  o.r = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(r) * factor);
-  o.g = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(g) * factor);
-  o.b = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(b) * factor);
+  if (FMT == 3 && !UNBOUNDED) {
+    const f2 factor12 = factor * splat(12.0f);
+    o.r = hlg_oetf2_of_product(srgb_eotf2(r), factor, factor12);
+    o.g = hlg_oetf2_of_product(srgb_eotf2(g), factor, factor12);
+    o.b = hlg_oetf2_of_product(srgb_eotf2(b), factor, factor12);
+  } else {
+    o.r = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(r) * factor);
+    o.g = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(g) * factor);
+    o.b = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(b) * factor);
+  }
   return o;
 }
 

@@ -140,6 +140,20 @@ def other_configs(lib, stream):
     ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch(nb, ya, pa, api.TF_PQ, C.byref(md), ma, 0, None, stream), 10)
     out["4K PQ generate, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
                                              "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    # opt-in LUT mode (upstream libultrahdr's USE_*_LUT configuration; bit-exact against the reference's LUT functions)
+    ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch_ex(nb, ya, pa, api.TF_HLG, C.byref(md), ma, 0, api.GENERATE_LUT, None, stream), 10)
+    out["LUT mode: 4K HLG generate, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+                                                        "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    louts = [torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+    mia = api.image_array([api.mono_image(t.data_ptr(), W // 4, H // 4) for t in pmaps])
+    loa = api.image_array([api.out_image(t.data_ptr()) for t in louts])
+    ms = timed(lambda: lib.uhdr_hip_apply_gainmap_batch(nb, ya, mia, C.byref(md), api.OUTPUT_HDR_HLG, api.FLT_MAX, loa, api.APPLY_LUT, stream), 10)
+    out["LUT mode: 4K apply -> HLG RGBA1010102, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+                                                                    "GB/s": round(nb * APP_BYTES / (ms * 1e-3) / 1e9, 1)}
+    ms = timed(lambda: lib.uhdr_hip_apply_gainmap_batch(nb, ya, mia, C.byref(md), api.OUTPUT_HDR_HLG, api.FLT_MAX, loa, api.APPLY_EXACT, stream), 3)
+    out["EXACT mode: 4K apply -> HLG RGBA1010102, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+                                                                      "GB/s": round(nb * APP_BYTES / (ms * 1e-3) / 1e9, 1)}
+    del louts
     # the drop-in form a CPU caller uses: host planes in, host bytes out (PCIe Gen5 both ways; never `value`)
     hp, hy = p.cpu().numpy(), y.cpu().numpy()
     hmap = np.zeros((W // 4) * (H // 4), np.uint8)

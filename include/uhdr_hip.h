@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define UHDR_HIP_ABI_VERSION 1
+#define UHDR_HIP_ABI_VERSION 2
 
 /* ultrahdr_color_gamut, ultrahdr.h:36-42 */
 #define UHDR_HIP_CG_UNSPECIFIED (-1)
@@ -92,6 +92,16 @@ extern "C" {
  * generate/tonemap/convert_yuv have a single, bit-exact mode. */
 #define UHDR_HIP_APPLY_FAST 0
 #define UHDR_HIP_APPLY_EXACT 1
+/* LUT mode (opt-in): the loops as a build that sees jpegr.cpp:33-38's
+ * USE_*_LUT = 1 compiles them (upstream libultrahdr's configuration; dead code in this fork, whose
+ * ultrahdr.cpp never sees those macros).  apply: srgbInvOetfLUT + applyGainLUT(GainLUT(metadata,
+ * display_boost)) + hlgOetfLUT / pqOetfLUT (ultrahdr.cpp:433,446,470,481); generate: srgbInvOetfLUT +
+ * hlgInvOetfLUT / pqInvOetfLUT (:230,238,319).  Tables are built on the device by the exact functions
+ * (gainmapmath.cpp:21-64); with them the LUT pipelines are pure float/integer work and BIT-EXACT against
+ * the reference's LUT functions. */
+#define UHDR_HIP_APPLY_LUT 2
+#define UHDR_HIP_GENERATE_EXACT 0
+#define UHDR_HIP_GENERATE_LUT 1
 
 /* POD mirror of ultrahdr_uncompressed_struct (ultrahdr.h:152-181) */
 typedef struct uhdr_hip_image {
@@ -142,6 +152,11 @@ int uhdr_hip_generate_gainmap(const uhdr_hip_image_t* yuv420_image, const uhdr_h
                               int hdr_tf, uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dest,
                               int sdr_is_601, int mem_space, void* stream);
 
+/* the same with an arithmetic mode: UHDR_HIP_GENERATE_EXACT (what uhdr_hip_generate_gainmap runs) or _LUT */
+int uhdr_hip_generate_gainmap_ex(const uhdr_hip_image_t* yuv420_image, const uhdr_hip_image_t* p010_image,
+                                 int hdr_tf, uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dest,
+                                 int sdr_is_601, int generate_mode, int mem_space, void* stream);
+
 /* UltraHdr::applyGainMap (ultrahdr.cpp:360-515).  dest->data is caller-allocated:
  * width*height*{8|4|6} bytes for HDR_LINEAR | HDR_PQ,HDR_HLG | HDR_LINEAR_RGB_10BIT; any other
  * output_format writes nothing and returns NO_ERROR, like the reference (ultrahdr.cpp:491-493). */
@@ -189,6 +204,11 @@ int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuv420_images
                                     uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dests,
                                     int sdr_is_601, float* content_minmax, void* stream);
 
+int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuv420_images,
+                                       const uhdr_hip_image_t* p010_images, int hdr_tf,
+                                       uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dests,
+                                       int sdr_is_601, int generate_mode, float* content_minmax, void* stream);
+
 int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuv420_images,
                                  const uhdr_hip_image_t* gainmap_images,
                                  const uhdr_hip_metadata_t* metadata, int output_format,
@@ -200,11 +220,20 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuv420_images,
  * scale*scale*4 floats; gainmapmath.h:184-228) the apply kernels use for `scale` into out[] */
 int uhdr_hip_idw_tables(int scale, float* out);
 
+/* copies static LUT `which` (0 kSrgbInvOETF[1024], 1 kHlgInvOETF[4096], 2 kPqInvOETF[4096], 4 kHlgOETF[65536],
+ * 5 kPqOETF[65536]; gainmapmath.cpp:21-64) from the device into out[capacity] (HOST); *count = its length */
+int uhdr_hip_lut_table(int which, float* out, size_t capacity, size_t* count);
+/* GainLUT::mGainTable (gainmapmath.h:151-182) as LUT-mode apply builds it: 1024 floats into out (HOST);
+ * with_display_boost == 0 is GainLUT(metadata), otherwise GainLUT(metadata, display_boost) */
+int uhdr_hip_gain_lut(const uhdr_hip_metadata_t* metadata, int with_display_boost, float display_boost, float* out);
+
 /* evaluates one scalar device function over n floats (DEVICE pointers), out[i] = f(in[i]):
  *   fn 0/1/2  sRGB / HLG / PQ inverse OETF as generate computes them (lean f64 + rounding test + exact fallback)
  *   fn 3      encodeGain byte (as float) of gain in[i] for (min_boost, max_boost), generate's version
  *   fn 10..13 the same four through the exact (ocml f64) path;  14/15 HLG / PQ OETF exact
  *   fn 20/24/25 apply-FAST sRGB EOTF / HLG OETF / PQ OETF
+ *   fn 40/41/42/44/45 srgbInvOetfLUT / hlgInvOetfLUT / pqInvOetfLUT / hlgOetfLUT / pqOetfLUT; 46 GainLUT(min, max,
+ *              displayBoost = max).getGainFactor(in[i])
  *   fn 30/31   gain-map byte -> float through the constant division / the IEEE division (in[i] = byte as float)
  *   fn 100/101 1.0 where the lean path of fn 0/1 passed its rounding test, else 0.0
  * Used by the exhaustive transfer-function tests. */

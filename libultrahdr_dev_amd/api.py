@@ -20,7 +20,9 @@ ERROR_RESOLUTION_MISMATCH, ERROR_BAD_METADATA = -10006, -10010
 ERROR_INVALID_CROPPING_PARAMETERS, ERROR_UNSUPPORTED_FEATURE = -10011, -30000
 ERROR_UNSUPPORTED_MAP_SCALE_FACTOR, ERROR_INSUFFICIENT_RESOURCE = -20008, -20009
 MEM_HOST, MEM_DEVICE = 0, 1
-APPLY_FAST, APPLY_EXACT = 0, 1
+APPLY_FAST, APPLY_EXACT, APPLY_LUT = 0, 1, 2
+GENERATE_EXACT, GENERATE_LUT = 0, 1
+ABI_VERSION = 2
 FLT_MAX = 3.4028234663852886e38
 
 
@@ -58,6 +60,10 @@ SIGNATURES = {
     "uhdr_hip_mirror": (C.c_int, [_IP, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_rotate": (C.c_int, [_IP, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_resize": (C.c_int, [_IP, C.c_int, C.c_int, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_generate_gainmap_ex": (C.c_int, [_IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uhdr_hip_generate_gainmap_batch_ex": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uhdr_hip_lut_table": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "uhdr_hip_gain_lut": (C.c_int, [_MP, C.c_int, C.c_float, C.POINTER(C.c_float)]),
     "uhdr_hip_idw_tables": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "uhdr_hip_eval_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]),
 }
@@ -86,7 +92,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.uhdr_hip_abi_version() != 1:
+        if lib.uhdr_hip_abi_version() != ABI_VERSION:
             raise ImportError("libuhdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -38,6 +38,7 @@ void set_err(const char* where, hipError_t e) {
 struct DeviceState {
   bool ready = false;
   std::map<int, float*> idw;  // scale -> device tables (4 * scale*scale*4 floats)
+  float* lut = nullptr;       // the five static transfer-function tables (kLutTotal floats), built at init
   // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
   void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -230,6 +231,7 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   c.width = (uint32_t)w; c.height = (uint32_t)h;
   c.map_w = (uint32_t)(w / 4); c.map_h = (uint32_t)(h / 4);
   c.stat_keys = nullptr;
+  c.lut = nullptr;
   c.bias4096 = 4096.0f;
   return c;
 }
@@ -292,6 +294,8 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
   c.log2_min_d = std::log2((double)md.minContentBoost);                           // gainmapmath.cpp:551-552
   c.log2_max_d = std::log2((double)md.maxContentBoost);
   c.idw = idw;
+  c.lut = nullptr;
+  c.lut_boost_factor = c.display_boost > 0 ? c.display_boost / md.maxContentBoost : 1.0f;  // gainmapmath.h:162
   // FAST scale-4 kernel: factor/display_boost = 2^(gain*A + B); weights pre-multiplied by A (k_apply_s4)
   const double ratio = (double)c.display_boost / (double)md.maxContentBoost;
   c.fast.A = (float)((c.log2_max_d - c.log2_min_d) * ratio);
@@ -428,6 +432,10 @@ int uhdr_hip_init(int device) {
     std::vector<float> t;
     build_idw_tables(4, t);
     HIP_TRY(upload_idw4(t.data()));
+    // the reference fills its LUTs at static-initialisation time (gainmapmath.cpp:21-64); here: once per device
+    HIP_TRY(hipMalloc(&st.lut, sizeof(float) * kLutTotal));
+    HIP_TRY(launch_build_luts(st.lut, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     st.ready = true;
   }
   return UHDR_HIP_NO_ERROR;
@@ -441,6 +449,7 @@ int uhdr_hip_shutdown(void) {
     if (hipSetDevice(kv.first) != hipSuccess) continue;
     (void)hipDeviceSynchronize();
     for (auto& t : kv.second.idw) (void)hipFree(t.second);
+    if (kv.second.lut) (void)hipFree(kv.second.lut);
     for (int i = 0; i < 8; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
   }
@@ -461,7 +470,46 @@ int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float 
   ec.log2_min = (float)std::log2((double)min_boost);
   ec.log2_max = (float)std::log2((double)max_boost);
   encode_constants(min_boost, max_boost, ec.log2_min, ec.log2_max, &ec.enc_scale, &ec.enc_byte_min, &ec.enc_byte_max);
+  ec.lut = st->lut;
+  ec.log2_min_d = std::log2((double)min_boost);
+  ec.log2_max_d = std::log2((double)max_boost);
   HIP_TRY(launch_eval_transfer(fn, in, out, n, ec, static_cast<hipStream_t>(stream)));
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_lut_table(int which, float* out, size_t capacity, size_t* count) {
+  if (out == nullptr || count == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  DeviceState* st = nullptr;
+  const int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  uint32_t off = 0, n = 0;
+  switch (which) {
+    case 0: off = kLutSrgbInv; n = kLutSrgbInvN; break;
+    case 1: off = kLutHlgInv; n = kLutHlgInvN; break;
+    case 2: off = kLutPqInv; n = kLutPqInvN; break;
+    case 4: off = kLutHlg; n = kLutHlgN; break;
+    case 5: off = kLutPq; n = kLutPqN; break;
+    default: return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  }
+  *count = n;
+  if (capacity < n) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  HIP_TRY(hipMemcpy(out, st->lut + off, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_gain_lut(const uhdr_hip_metadata_t* metadata, int with_display_boost, float display_boost, float* out) {
+  if (metadata == nullptr || out == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  float factor = 1.0f;  // gainmapmath.h:152-159 (no display boost) | :161-169
+  if (with_display_boost) factor = display_boost > 0 ? display_boost / metadata->maxContentBoost : 1.0f;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  if ((rc = stage_reserve(st, 6, sizeof(float) * kGainLutN)) != 0) return rc;
+  float* d = static_cast<float*>(st->stage[6]);
+  HIP_TRY(launch_build_gain_lut(d, std::log2((double)metadata->minContentBoost), std::log2((double)metadata->maxContentBoost),
+                                factor, nullptr));
+  HIP_TRY(hipMemcpy(out, d, sizeof(float) * kGainLutN, hipMemcpyDeviceToHost));
   return UHDR_HIP_NO_ERROR;
 }
 
@@ -477,6 +525,15 @@ int uhdr_hip_idw_tables(int scale, float* out) {
 int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr_hip_image_t* p010s, int hdr_tf,
                                     uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dests, int sdr_is_601,
                                     float* content_minmax, void* stream) {
+  return uhdr_hip_generate_gainmap_batch_ex(n, yuvs, p010s, hdr_tf, metadata, dests, sdr_is_601, UHDR_HIP_GENERATE_EXACT,
+                                            content_minmax, stream);
+}
+
+int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, const uhdr_hip_image_t* p010s, int hdr_tf,
+                                       uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dests, int sdr_is_601,
+                                       int generate_mode, float* content_minmax, void* stream) {
+  if (generate_mode != UHDR_HIP_GENERATE_EXACT && generate_mode != UHDR_HIP_GENERATE_LUT) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  const bool lut = generate_mode == UHDR_HIP_GENERATE_LUT;
   if (n < 0 || (n > 0 && (yuvs == nullptr || p010s == nullptr || dests == nullptr)) || metadata == nullptr)
     return UHDR_HIP_ERROR_BAD_PTR;
   for (int i = 0; i < n; ++i) {
@@ -501,6 +558,7 @@ int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const u
     const uhdr_hip_image_t& y0 = yuvs[i];
     GenConsts c = generate_consts(y0.colorGamut, p010s[i].colorGamut, hdr_tf, sdr_is_601, y0.width, y0.height, *metadata);
     c.stat_keys = keys ? keys + 2 * i : nullptr;
+    c.lut = lut ? st->lut : nullptr;
     GenBatch b;
     int m = 0;
     bool aligned = true;
@@ -516,7 +574,7 @@ int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const u
       fill_generate_dest(&y, &dests[i + m]);
       ++m;
     }
-    HIP_TRY(launch_generate(c, b, m, hdr_tf, aligned, s));
+    HIP_TRY(launch_generate(c, b, m, hdr_tf, aligned, lut, s));
     i += m;
   }
   if (keys && n > 0) HIP_TRY(launch_stats_finalize(keys, n, s));
@@ -532,6 +590,8 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
     const int rc = validate_apply(&yuvs[i], &maps[i], metadata, &dests[i]);
     if (rc != UHDR_HIP_NO_ERROR) return rc;
   }
+  if (apply_mode != UHDR_HIP_APPLY_FAST && apply_mode != UHDR_HIP_APPLY_EXACT && apply_mode != UHDR_HIP_APPLY_LUT)
+    return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
   DeviceState* st = nullptr;
   int rc = current_state(&st);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
@@ -547,7 +607,8 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
     const int scale = (int)(y0.width / m0.width);
     const float* idw = nullptr;
     if ((rc = idw_for_scale(st, scale, &idw)) != UHDR_HIP_NO_ERROR) return rc;
-    const AppConsts c = apply_consts(y0, m0, *metadata, max_display_boost, idw);
+    AppConsts c = apply_consts(y0, m0, *metadata, max_display_boost, idw);
+    c.lut = apply_mode == UHDR_HIP_APPLY_LUT ? st->lut : nullptr;
     AppBatch b;
     int m = 0;
     bool fast = true;
@@ -562,7 +623,7 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
       fill_apply_dest(&y, &dests[i + m]);
       ++m;
     }
-    if (writes) HIP_TRY(launch_apply(c, b, m, output_format, apply_mode == UHDR_HIP_APPLY_EXACT, fast, s));
+    if (writes) HIP_TRY(launch_apply(c, b, m, output_format, apply_mode, fast, s));
     i += m;
   }
   return UHDR_HIP_NO_ERROR;
@@ -572,11 +633,17 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
 int uhdr_hip_generate_gainmap(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* p010, int hdr_tf,
                               uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dest, int sdr_is_601, int mem_space,
                               void* stream) {
+  return uhdr_hip_generate_gainmap_ex(yuv, p010, hdr_tf, metadata, dest, sdr_is_601, UHDR_HIP_GENERATE_EXACT, mem_space, stream);
+}
+
+int uhdr_hip_generate_gainmap_ex(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* p010, int hdr_tf,
+                                 uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dest, int sdr_is_601, int generate_mode,
+                                 int mem_space, void* stream) {
   int rc = validate_generate(yuv, p010, hdr_tf, metadata, dest);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   if (dest->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   if (mem_space == UHDR_HIP_MEM_DEVICE)
-    return uhdr_hip_generate_gainmap_batch(1, yuv, p010, hdr_tf, metadata, dest, sdr_is_601, nullptr, stream);
+    return uhdr_hip_generate_gainmap_batch_ex(1, yuv, p010, hdr_tf, metadata, dest, sdr_is_601, generate_mode, nullptr, stream);
 
   DeviceState* st = nullptr;
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
@@ -588,7 +655,7 @@ int uhdr_hip_generate_gainmap(const uhdr_hip_image_t* yuv, const uhdr_hip_image_
   const size_t mw = yuv->width / 4, mh = yuv->height / 4;
   if ((rc = stage_reserve(st, 4, mw * mh)) != 0) return rc;
   dm.data = st->stage[4];
-  rc = uhdr_hip_generate_gainmap_batch(1, &dy, &dp, hdr_tf, metadata, &dm, sdr_is_601, nullptr, stream);
+  rc = uhdr_hip_generate_gainmap_batch_ex(1, &dy, &dp, hdr_tf, metadata, &dm, sdr_is_601, generate_mode, nullptr, stream);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   if (mw * mh) HIP_TRY(hipMemcpyAsync(dest->data, dm.data, mw * mh, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

@@ -7,6 +7,13 @@ namespace uhdr {
 
 constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4 KiB kernarg segment: 64 x 56 B + consts)
 
+// ---- LUT mode (gainmapmath.cpp:21-64 static tables; opt-in) --------------------
+// one device buffer per device, filled once at uhdr_hip_init() by k_build_luts: table[i] = f((float)i / (float)(N - 1))
+constexpr uint32_t kLutSrgbInvN = 1024, kLutHlgInvN = 4096, kLutPqInvN = 4096, kLutHlgN = 65536, kLutPqN = 65536;
+constexpr uint32_t kLutSrgbInv = 0, kLutHlgInv = kLutSrgbInv + kLutSrgbInvN, kLutPqInv = kLutHlgInv + kLutHlgInvN,
+                   kLutHlg = kLutPqInv + kLutPqInvN, kLutPq = kLutHlg + kLutHlgN, kLutTotal = kLutPq + kLutPqN;
+constexpr uint32_t kGainLutN = 1024;  // kGainFactorNumEntries, gainmapmath.h:149-150
+
 // ---- generate ----------------------------------------------------------------------------------
 struct GenConsts {
   float sdr_cr, sdr_gcb, sdr_gcr, sdr_cb;  // SDR YUV->RGB (gamut of the SDR image, or 601)
@@ -22,11 +29,14 @@ struct GenConsts {
   uint32_t enc_byte_min, enc_byte_max;
   uint32_t width, height, map_w, map_h;
   uint32_t* stat_keys;  // 2 words per image of the launch (min key, max key), or nullptr
+  const float* lut;     // device LUT buffer (LUT mode only)
 };
 struct EvalConsts {
   float min_boost, max_boost, log2_min, log2_max;
   double enc_scale;
   uint32_t enc_byte_min, enc_byte_max;
+  const float* lut;
+  double log2_min_d, log2_max_d;
 };
 struct GenImage {  // 56 bytes; the V plane is u + c_stride * (height / 2) (gainmapmath.cpp:568)
   const uint8_t* y;
@@ -51,6 +61,8 @@ struct AppConsts {
   float display_boost, inv_display_boost, max_boost, inv_max_boost;
   double log2_min_d, log2_max_d;  // log2((double)minContentBoost), log2((double)maxContentBoost)
   const float* idw;               // device: 4 tables (std, NR, NB, C) of scale*scale*4 floats
+  const float* lut;               // device LUT buffer (LUT mode only)
+  float lut_boost_factor;         // GainLUT(metadata, displayBoost): displayBoost > 0 ? displayBoost / max : 1 (gainmapmath.h:162)
   AppFast fast;
 };
 struct AppImage {
@@ -102,12 +114,16 @@ static_assert(sizeof(GenConsts) + sizeof(GenBatch) <= 4096, "generate kernel arg
 static_assert(sizeof(AppConsts) + sizeof(AppBatch) <= 4096, "apply kernel arguments exceed the kernarg segment");
 
 // launchers (enqueue only; return hipError_t of the launch)
-hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned,
+hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, bool lut,
                            hipStream_t s);
 hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s);
 hipError_t launch_stats_finalize(uint32_t* keys, int n, hipStream_t s);
-hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, bool exact,
+// mode: 0 FAST, 1 EXACT, 2 LUT
+hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, int mode,
                         bool fast_s4, hipStream_t s);
+hipError_t launch_build_luts(float* lut /* kLutTotal floats */, hipStream_t s);
+// GainLUT table (kGainLutN floats, device) for (log2 min, log2 max, boost factor)
+hipError_t launch_build_gain_lut(float* table, double log2_min, double log2_max, float boost_factor, hipStream_t s);
 hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s);
 hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s);
 hipError_t upload_idw4(const float* tables /* 4*64 floats */);

@@ -50,6 +50,80 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
 
+// packed add / mul with the VOP3P clamp modifier: both lanes saturate to [0, 1] for free (hipcc only
+// folds clamps into scalar ops, so these two are spelled out)
+__device__ __forceinline__ f2 pk_add_sat(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_mul_sat(f2 a, f2 b) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_fma_sat(f2 a, f2 b, f2 c) {
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// =================================================================================================
+// LUT mode: the reference's table accessors (gainmapmath.cpp:162-171,269-277,292-302,316-324,344-354) and
+// GainLUT (gainmapmath.h:151-182).  Everything here is float/integer arithmetic plus table reads, so the
+// LUT pipelines are bit-exact by construction once the tables are (they are built by the exact functions).
+// =================================================================================================
+// `uint32_t value = static_cast<uint32_t>(e * (N - 1) + 0.5); value = CLIP3(value, 0, N - 1);`
+// float product, double sum, truncation.  Outside [0, 2^32) the C++ conversion is undefined; the oracle pins
+// what the reference's x86-64 build does (64-bit cvttsd2si, low word kept) and this restates it.
+__device__ __attribute__((noinline)) uint32_t lut_index_wild(float t) {
+  const double pos = (double)t + 0.5;
+  uint32_t v = 0u;  // NaN, inf and |pos| >= 2^63 convert to 0x8000000000000000: low word 0
+  if (__builtin_fabs(pos) < 9223372036854775808.0) v = (uint32_t)(long long)pos;
+  return v;
+}
+__device__ __forceinline__ uint32_t lut_index(float e, uint32_t n) {
+  const float t = e * (float)(n - 1u);
+  uint32_t v;
+  if (__builtin_expect(__float_as_uint(t) < 0x4F800000u, 1)) v = (uint32_t)((double)t + 0.5);  // +0 <= t < 2^32
+  else v = lut_index_wild(t);
+  return min(v, n - 1u);
+}
+// e in [0, 1]: no clip can bite
+__device__ __forceinline__ uint32_t lut_index_unit(float e, uint32_t n) {
+  return (uint32_t)((double)(e * (float)(n - 1u)) + 0.5);
+}
+// GainLUT::mGainTable[idx] (gainmapmath.h:153-168); boost_factor == 1.0f reproduces the one-argument constructor
+__device__ __forceinline__ float gain_lut_entry(uint32_t idx, double log2_min, double log2_max, float boost_factor) {
+  const float value = (float)idx / (float)(kGainLutN - 1u);
+  const float log_boost = (float)(log2_min * (double)(1.0f - value) + log2_max * (double)value);
+  return (float)exp2((double)(log_boost * boost_factor));
+}
+
+__global__ void __launch_bounds__(256) k_build_luts(float* lut) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= kLutTotal) return;
+  float y;
+  if (i < kLutHlgInv) y = srgb_inv_oetf_exact((float)(i - kLutSrgbInv) / (float)(kLutSrgbInvN - 1u));
+  else if (i < kLutPqInv) y = hlg_inv_oetf_exact((float)(i - kLutHlgInv) / (float)(kLutHlgInvN - 1u));
+  else if (i < kLutHlg) y = pq_inv_oetf_exact((float)(i - kLutPqInv) / (float)(kLutPqInvN - 1u));
+  else if (i < kLutPq) y = hlg_oetf_exact((float)(i - kLutHlg) / (float)(kLutHlgN - 1u));
+  else y = pq_oetf_exact((float)(i - kLutPq) / (float)(kLutPqN - 1u));
+  lut[i] = y;
+}
+hipError_t launch_build_luts(float* lut, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_luts, dim3((kLutTotal + 255u) / 256u), dim3(256), 0, s, lut);
+  return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) k_build_gain_lut(float* table, double log2_min, double log2_max, float boost_factor) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < kGainLutN) table[i] = gain_lut_entry(i, log2_min, log2_max, boost_factor);
+}
+hipError_t launch_build_gain_lut(float* table, double log2_min, double log2_max, float boost_factor, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_gain_lut, dim3(kGainLutN / 256u), dim3(256), 0, s, table, log2_min, log2_max, boost_factor);
+  return hipGetLastError();
+}
+
 // =================================================================================================
 // generate
 // =================================================================================================
@@ -80,14 +154,14 @@ __device__ __forceinline__ float cvt_word1(uint32_t w) {
   return r;
 }
 
-__device__ __forceinline__ float clampf(float v) { return (v < 0.0f) ? 0.0f : (v > 1.0f) ? 1.0f : v; }
-__device__ __forceinline__ f2 clamp2(f2 v) { return (f2){clampf(v.x), clampf(v.y)}; }
 
-template <int TF>
+// LUT: the inverse OETFs are the reference's table accessors (ultrahdr.cpp:230,238,319 with USE_*_LUT = 1), read
+// from the LDS copies s_srgb (1024 entries) / s_hdr (4096 entries of the HLG or PQ table)
+template <int TF, bool LUT>
 __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy)[2][4][2],
                                          const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
                                          const uint32_t (&u8)[2][2], const uint32_t (&v8)[2][2],
-                                         uint8_t (&out)[2], float (&gain)[2]) {
+                                         uint8_t (&out)[2], float (&gain)[2], const float* s_srgb, const float* s_hdr) {
   f2 sy = splat(0.0f), su = splat(0.0f), sv = splat(0.0f);
   f2 hsy = splat(0.0f), hsu = splat(0.0f), hsv = splat(0.0f);
 #pragma unroll
@@ -134,16 +208,23 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
   hsy *= splat(0.0625f); hsu *= splat(0.0625f); hsv *= splat(0.0625f);
 
   // SDR: YUV->RGB (gainmapmath.cpp:142-146 shape), sRGB EOTF, luminance * 203 (ultrahdr.cpp:316-324)
-  f2 r = clamp2(sy + splat(c.sdr_cr) * sv);
-  f2 g = clamp2(sy - splat(c.sdr_gcb) * su - splat(c.sdr_gcr) * sv);
-  f2 b = clamp2(sy + splat(c.sdr_cb) * su);
+  // clampPixelFloat (gainmapmath.cpp:115-118) rides on the last add of each expression: the sum is the same IEEE
+  // operation, and min(max(x,0),1) differs from the reference's compare chain only in the sign of a zero,
+  // which no later step can observe
+  f2 r = pk_add_sat(sy, splat(c.sdr_cr) * sv);
+  f2 g = pk_add_sat(sy - splat(c.sdr_gcb) * su, -(splat(c.sdr_gcr) * sv));
+  f2 b = pk_add_sat(sy, splat(c.sdr_cb) * su);
   // independent f64 evaluations advanced in lock step: 6 = 3 channels x 2 pixels.  Measured on MI355X
   // (scripts/ab): 6 -> 0.388 ms per 32-frame launch, 3 -> 0.432, 2 -> 0.490 although the narrower forms
   // need fewer VGPRs (98 / 84 / 78): exposed f64 FMA latency costs more than the lost occupancy.
 #ifndef UHDR_LOCKSTEP
 #define UHDR_LOCKSTEP 6
 #endif
-  {
+  if (LUT) {
+    r = (f2){s_srgb[lut_index_unit(r.x, kLutSrgbInvN)], s_srgb[lut_index_unit(r.y, kLutSrgbInvN)]};
+    g = (f2){s_srgb[lut_index_unit(g.x, kLutSrgbInvN)], s_srgb[lut_index_unit(g.y, kLutSrgbInvN)]};
+    b = (f2){s_srgb[lut_index_unit(b.x, kLutSrgbInvN)], s_srgb[lut_index_unit(b.y, kLutSrgbInvN)]};
+  } else {
     float ch[6] = {r.x, r.y, g.x, g.y, b.x, b.y};
 #pragma unroll
     for (int i = 0; i < 6; i += UHDR_LOCKSTEP) {
@@ -159,10 +240,14 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
   const f2 sdr_nits = (splat(c.lum_r) * r + splat(c.lum_g) * g + splat(c.lum_b) * b) * splat(203.0f);
 
   // HDR: YUV->RGB, inverse OETF, gamut conversion, luminance * white (ultrahdr.cpp:326-330)
-  f2 hr = clamp2(hsy + splat(c.hdr_cr) * hsv);
-  f2 hg = clamp2(hsy - splat(c.hdr_gcb) * hsu - splat(c.hdr_gcr) * hsv);
-  f2 hb = clamp2(hsy + splat(c.hdr_cb) * hsu);
-  if (TF != 0) {  // ULTRAHDR_TF_LINEAR: identityConversion (ultrahdr.cpp:223-228)
+  f2 hr = pk_add_sat(hsy, splat(c.hdr_cr) * hsv);
+  f2 hg = pk_add_sat(hsy - splat(c.hdr_gcb) * hsu, -(splat(c.hdr_gcr) * hsv));
+  f2 hb = pk_add_sat(hsy, splat(c.hdr_cb) * hsu);
+  if (TF != 0 && LUT) {  // both HDR tables have 4096 entries (gainmapmath.h:342-343,368-369)
+    hr = (f2){s_hdr[lut_index_unit(hr.x, kLutHlgInvN)], s_hdr[lut_index_unit(hr.y, kLutHlgInvN)]};
+    hg = (f2){s_hdr[lut_index_unit(hg.x, kLutHlgInvN)], s_hdr[lut_index_unit(hg.y, kLutHlgInvN)]};
+    hb = (f2){s_hdr[lut_index_unit(hb.x, kLutHlgInvN)], s_hdr[lut_index_unit(hb.y, kLutHlgInvN)]};
+  } else if (TF != 0) {  // ULTRAHDR_TF_LINEAR: identityConversion (ultrahdr.cpp:223-228)
     float ch[6] = {hr.x, hr.y, hg.x, hg.y, hb.x, hb.y};
 #pragma unroll
     for (int i = 0; i < 6; i += UHDR_LOCKSTEP) {
@@ -237,8 +322,20 @@ __device__ __forceinline__ void block_minmax_to_keys(float gmin, float gmax, uin
 // Thread = 2 horizontally adjacent map pixels = an 8x4 pixel block of both images.
 // A wave64 therefore consumes 1 KiB contiguous per P010 row (dwordx4/lane), 512 B per 8-bit luma
 // row (dwordx2/lane) and 256 B per chroma row (dword/lane).
-template <int TF, bool ALIGNED>
+template <int TF, bool ALIGNED, bool LUT>
 __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(const GenConsts c, const GenBatch b) {
+  // LUT mode: block-private copies of the two tables (4 KiB + 16 KiB), so every lookup is an LDS gather
+  __shared__ float s_srgb[LUT ? kLutSrgbInvN : 1];
+  __shared__ float s_hdr[(LUT && TF != 0) ? kLutHlgInvN : 1];
+  if (LUT) {
+    for (uint32_t i = threadIdx.x; i < kLutSrgbInvN / 4u; i += UHDR_GEN_BLOCK)
+      reinterpret_cast<float4*>(s_srgb)[i] = reinterpret_cast<const float4*>(c.lut + kLutSrgbInv)[i];
+    if (TF != 0) {
+      const float4* src = reinterpret_cast<const float4*>(c.lut + (TF == 1 ? kLutHlgInv : kLutPqInv));
+      for (uint32_t i = threadIdx.x; i < kLutHlgInvN / 4u; i += UHDR_GEN_BLOCK) reinterpret_cast<float4*>(s_hdr)[i] = src[i];
+    }
+    __syncthreads();
+  }
   const GenImage& im = b.img[blockIdx.y];
   const uint8_t* im_v = im.u + (size_t)im.c_stride * (c.height / 2u);
   const uint32_t pairs_per_row = (c.map_w + 1u) >> 1;
@@ -305,7 +402,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
 
     uint8_t o[2];
     float gn[2];
-    gen_pair<TF>(c, hy, huv, y8, u8, v8, o, gn);   // a missing second pixel is computed on zeros and dropped
+    gen_pair<TF, LUT>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);   // a missing second pixel is computed on zeros and dropped
     const uint8_t o0 = o[0], o1 = o[1];
     gmin = fminf(gmin, gn[0]); gmax = fmaxf(gmax, gn[0]);
     if (two) { gmin = fminf(gmin, gn[1]); gmax = fmaxf(gmax, gn[1]); }
@@ -330,22 +427,28 @@ __global__ void k_stats_finalize(uint32_t* keys, int n) {
   keys[2 * i + 1] = __float_as_uint(mx);
 }
 
-template <int TF, bool ALIGNED>
+template <int TF, bool ALIGNED, bool LUT>
 static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   if (total == 0 || n == 0) return hipSuccess;
   constexpr uint32_t kSpan = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
   dim3 grid((total + kSpan - 1u) / kSpan, (unsigned)n, 1), block(UHDR_GEN_BLOCK, 1, 1);
-  hipLaunchKernelGGL((k_generate<TF, ALIGNED>), grid, block, 0, s, c, b);
+  hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT>), grid, block, 0, s, c, b);
   return hipGetLastError();
 }
 
-hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned,
+template <int TF>
+static hipError_t launch_generate_tf(const GenConsts& c, const GenBatch& b, int n, bool aligned, bool lut, hipStream_t s) {
+  if (lut) return aligned ? launch_generate_t<TF, true, true>(c, b, n, s) : launch_generate_t<TF, false, true>(c, b, n, s);
+  return aligned ? launch_generate_t<TF, true, false>(c, b, n, s) : launch_generate_t<TF, false, false>(c, b, n, s);
+}
+hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, bool lut,
                            hipStream_t s) {
+  if (lut && c.lut == nullptr) return hipErrorInvalidValue;
   switch (hdr_tf) {
-    case 0: return aligned ? launch_generate_t<0, true>(c, b, n, s) : launch_generate_t<0, false>(c, b, n, s);
-    case 1: return aligned ? launch_generate_t<1, true>(c, b, n, s) : launch_generate_t<1, false>(c, b, n, s);
-    case 2: return aligned ? launch_generate_t<2, true>(c, b, n, s) : launch_generate_t<2, false>(c, b, n, s);
+    case 0: return launch_generate_tf<0>(c, b, n, aligned, lut, s);
+    case 1: return launch_generate_tf<1>(c, b, n, aligned, lut, s);
+    case 2: return launch_generate_tf<2>(c, b, n, aligned, lut, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -429,24 +532,6 @@ __device__ __forceinline__ f2 sqrt_2(f2 v) { return (f2){__builtin_amdgcn_sqrtf(
 __device__ __forceinline__ f2 rcp_2(f2 v) { return (f2){__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
 __device__ __forceinline__ f2 sel_le(f2 x, float thr, f2 a, f2 b) {  // x <= thr ? a : b
   return (f2){x.x <= thr ? a.x : b.x, x.y <= thr ? a.y : b.y};
-}
-
-// packed add / mul with the VOP3P clamp modifier: both lanes saturate to [0, 1] for free (hipcc only
-// folds clamps into scalar ops, so these two are spelled out)
-__device__ __forceinline__ f2 pk_add_sat(f2 a, f2 b) {
-  f2 r;
-  asm("v_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f2 pk_mul_sat(f2 a, f2 b) {
-  f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f2 pk_fma_sat(f2 a, f2 b, f2 c) {
-  f2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
 }
 
 // The piecewise transfer functions are evaluated WITHOUT per-lane selects (v_cmp + v_cndmask cost 2 issue
@@ -688,10 +773,81 @@ __global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBa
   }
 }
 
+// LUT mode (ultrahdr.cpp:433,446,470,481 with USE_*_LUT = 1): srgbInvOetfLUT, applyGainLUT, hlg/pqOetfLUT.
+// One thread per pixel, any integer scale.  Each block first builds its private copies of the sRGB table and of
+// GainLUT(metadata, display_boost) in LDS (the latter costs 4 double exp2 per thread, hence kLutPixelsPerThread
+// pixels per thread); the 65536-entry OETF tables (256 KiB each) are gathered from L2.
+constexpr uint32_t kLutPixelsPerThread = 16;
 template <int FMT>
-static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, bool exact,
+__global__ void __launch_bounds__(256) k_apply_lut(const AppConsts c, const AppBatch b) {
+  __shared__ float s_srgb[kLutSrgbInvN];
+  __shared__ float s_gain[kGainLutN];
+  for (uint32_t i = threadIdx.x; i < kLutSrgbInvN; i += 256u) {
+    s_srgb[i] = c.lut[kLutSrgbInv + i];
+    s_gain[i] = gain_lut_entry(i, c.log2_min_d, c.log2_max_d, c.lut_boost_factor);
+  }
+  __syncthreads();
+  const float* oetf = c.lut + (FMT == 3 ? kLutHlg : kLutPq);
+  const AppImage& im = b.img[blockIdx.y];
+  const size_t total = (size_t)c.width * c.height;
+  const uint32_t s = c.scale;
+  for (size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256u) {
+    const uint32_t y = (uint32_t)(idx / c.width);
+    const uint32_t x = (uint32_t)(idx - (size_t)y * c.width);
+    const float yf = (float)im.y[(size_t)y * im.y_stride + x] * k255;
+    const size_t ci = (size_t)(y >> 1) * im.c_stride + (x >> 1);
+    const float u = (float)((int)im.u[ci] - 128) * k255;
+    const float v = (float)((int)im.v[ci] - 128) * k255;
+    // sampleMap (gainmapmath.cpp:686-720), as in k_apply_px
+    uint32_t xl = x / s, yl = y / s;
+    uint32_t xu = xl + 1u, yu = yl + 1u;
+    xl = min(xl, c.map_w - 1u); xu = min(xu, c.map_w - 1u);
+    yl = min(yl, c.map_h - 1u); yu = min(yu, c.map_h - 1u);
+    const float e1 = map_to_float(im.map[(size_t)yl * c.map_w + xl]);
+    const float e2 = map_to_float(im.map[(size_t)yu * c.map_w + xl]);
+    const float e3 = map_to_float(im.map[(size_t)yl * c.map_w + xu]);
+    const float e4 = map_to_float(im.map[(size_t)yu * c.map_w + xu]);
+    const uint32_t ox = x % s, oy = y % s;
+    int tbl = 0;
+    if (xl == xu && yl == yu) tbl = 3;
+    else if (xl == xu) tbl = 1;
+    else if (yl == yu) tbl = 2;
+    const float* w = c.idw + (size_t)tbl * s * s * 4u + (size_t)oy * s * 4u + ox * 4u;
+    const float gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
+
+    const float r = s_srgb[lut_index(clamp01(yf + kP3Cr * v), kLutSrgbInvN)];
+    const float g = s_srgb[lut_index(clamp01(yf - kP3GCb * u - kP3GCr * v), kLutSrgbInvN)];
+    const float bl = s_srgb[lut_index(clamp01(yf + kP3Cb * u), kLutSrgbInvN)];
+    const float factor = s_gain[lut_index(gain, kGainLutN)];       // GainLUT::getGainFactor, gainmapmath.h:173-178
+    F3 e;
+    e.x = (r * factor) / c.display_boost;                          // applyGainLUT, then ultrahdr.cpp:451
+    e.y = (g * factor) / c.display_boost;
+    e.z = (bl * factor) / c.display_boost;
+    if (FMT == 2 || FMT == 3) {
+      e.x = oetf[lut_index(e.x, kLutHlgN)]; e.y = oetf[lut_index(e.y, kLutHlgN)]; e.z = oetf[lut_index(e.z, kLutHlgN)];
+      static_cast<uint32_t*>(im.dst)[idx] = pack_1010102(e.x, e.y, e.z);
+    } else if (FMT == 1) {
+      static_cast<uint2*>(im.dst)[idx] = pack_f16(e.x, e.y, e.z);
+    } else {
+      uint16_t* base = static_cast<uint16_t*>(im.dst);
+      base[idx] = (uint16_t)(0x3ffu & (uint32_t)(e.x * 1023.0f));
+      base[total + idx] = (uint16_t)(0x3ffu & (uint32_t)(e.y * 1023.0f));
+      base[2 * total + idx] = (uint16_t)(0x3ffu & (uint32_t)(e.z * 1023.0f));
+    }
+  }
+}
+
+template <int FMT>
+static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, int mode,
                                  bool fast_s4, hipStream_t s) {
   if (n == 0 || c.width == 0 || c.height == 0) return hipSuccess;
+  const bool exact = mode == 1;
+  if (mode == 2) {
+    if (c.lut == nullptr) return hipErrorInvalidValue;
+    const size_t total = (size_t)c.width * c.height, per_block = 256u * (size_t)kLutPixelsPerThread;
+    hipLaunchKernelGGL((k_apply_lut<FMT>), dim3((unsigned)((total + per_block - 1u) / per_block), n), dim3(256), 0, s, c, b);
+    return hipGetLastError();
+  }
   if (fast_s4 && !exact) {
     const uint32_t total = c.map_w * c.map_h;
     // channels can only reach 1024 (and wrap through the reference's & 0x3ff) when the display boost is
@@ -707,13 +863,13 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, b
   return hipGetLastError();
 }
 
-hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, bool exact,
+hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, int mode,
                         bool fast_s4, hipStream_t s) {
   switch (fmt) {
-    case 1: return launch_apply_t<1>(c, b, n, exact, fast_s4, s);
-    case 2: return launch_apply_t<2>(c, b, n, exact, fast_s4, s);
-    case 3: return launch_apply_t<3>(c, b, n, exact, fast_s4, s);
-    case 4: return launch_apply_t<4>(c, b, n, exact, fast_s4, s);
+    case 1: return launch_apply_t<1>(c, b, n, mode, fast_s4, s);
+    case 2: return launch_apply_t<2>(c, b, n, mode, fast_s4, s);
+    case 3: return launch_apply_t<3>(c, b, n, mode, fast_s4, s);
+    case 4: return launch_apply_t<4>(c, b, n, mode, fast_s4, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -990,6 +1146,13 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 24: y = hlg_oetf_fast(x); break;
     case 25: y = pq_oetf_fast(x); break;
     case 20: y = srgb_inv_oetf_fast(x); break;
+    // the reference's LUT accessors over the device tables; 46: GainLUT(min, max, displayBoost = max).getGainFactor
+    case 40: y = ec.lut[kLutSrgbInv + lut_index(x, kLutSrgbInvN)]; break;
+    case 41: y = ec.lut[kLutHlgInv + lut_index(x, kLutHlgInvN)]; break;
+    case 42: y = ec.lut[kLutPqInv + lut_index(x, kLutPqInvN)]; break;
+    case 44: y = ec.lut[kLutHlg + lut_index(x, kLutHlgN)]; break;
+    case 45: y = ec.lut[kLutPq + lut_index(x, kLutPqN)]; break;
+    case 46: y = gain_lut_entry(lut_index(x, kGainLutN), ec.log2_min_d, ec.log2_max_d, 1.0f); break;
     case 30: y = map_to_float_fast((uint32_t)x); break;
     case 31: y = map_to_float((uint32_t)x); break;
     // 1.0 where the lean f64 path was accepted by the rounding test, 0.0 where the exact path ran

@@ -75,6 +75,11 @@ def _declare(lib, p):
     d("transformYuv420", None, IP, sz, sz, i32, i32)
     d("generateGainMap", i32, IP, IP, i32, MP, C.c_void_p, i32, i32)
     d("applyGainMap", i32, IP, IP, MP, i32, f32, IP, i32)
+    d("generateGainMapLUT", i32, IP, IP, i32, MP, C.c_void_p, i32, i32)
+    d("applyGainMapLUT", i32, IP, IP, MP, i32, f32, IP, i32)
+    for n in ("srgbInvOetfLUT", "hlgOetfLUT", "hlgInvOetfLUT", "pqOetfLUT", "pqInvOetfLUT"):
+        d(n, f32, f32)
+    d("gainLutBuild", None, f32, f32, i32, f32, C.POINTER(f32))
     d("convertYuv", i32, IP, i32, i32)
     d("crop", i32, IP, i32, i32, i32, i32, IP)
     d("mirror", i32, IP, i32, IP)
@@ -87,10 +92,12 @@ def _declare(lib, p):
         d("checksum_u8", C.c_uint64, C.c_void_p, sz)
         d("checksum_u32", C.c_uint64, C.c_void_p, sz)
         d("eval_transfer", None, i32, C.c_void_p, C.c_void_p, sz, f32, f32)
+        d("lut_table", C.POINTER(f32), i32, C.POINTER(sz))
+        d("gainLutFactor", f32, C.POINTER(f32), f32)
+        d("applyGainLUT", Color, Color, f32, C.POINTER(f32))
     else:
-        for n in ("srgbInvOetfLUT", "hlgOetfLUT", "hlgInvOetfLUT", "pqOetfLUT", "pqInvOetfLUT"):
-            d(n, f32, f32)
         d("applyGainLUT", Color, Color, f32, f32, f32, f32)
+        d("gainLutFactor", f32, f32, f32, f32, f32)
     return lib
 
 
@@ -179,7 +186,23 @@ def eval_transfer(fn, x, min_boost=1.0, max_boost=4.0, threads=8):
     return out
 
 
-def generate(lib_prefix, yuv_img, p010_img, tf, sdr_is_601=False, threads=0, stats=False):
+def lut_table(which):
+    """the oracle's static LUT `which` (0 srgbInv, 1 hlgInv, 2 pqInv, 4 hlg, 5 pq) as a float32 array"""
+    n = C.c_size_t()
+    p = load().orc_lut_table(which, C.byref(n))
+    return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+def gain_lut(lib_prefix, min_boost, max_boost, display_boost=None):
+    """GainLUT(metadata) (display_boost None) or GainLUT(metadata, display_boost) as 1024 floats"""
+    lib = load() if lib_prefix == "orc_" else load_ref()
+    t = (C.c_float * 1024)()
+    getattr(lib, lib_prefix + "gainLutBuild")(min_boost, max_boost, 0 if display_boost is None else 1,
+                                              0.0 if display_boost is None else display_boost, t)
+    return np.frombuffer(t, np.float32).copy()
+
+
+def generate(lib_prefix, yuv_img, p010_img, tf, sdr_is_601=False, threads=0, stats=False, lut=False):
     lib = load() if lib_prefix == "orc_" else load_ref()
     mw, mh = yuv_img.width // 4, yuv_img.height // 4
     out = np.zeros(max(mw * mh, 1), np.uint8)
@@ -189,19 +212,19 @@ def generate(lib_prefix, yuv_img, p010_img, tf, sdr_is_601=False, threads=0, sta
         st = lib.orc_generateGainMapStats(C.byref(yuv_img), C.byref(p010_img), tf, C.byref(md),
                                           out.ctypes.data, int(sdr_is_601), threads, mm)
         return st, out[:mw * mh].reshape(mh, mw), md, (mm[0], mm[1])
-    st = getattr(lib, lib_prefix + "generateGainMap")(C.byref(yuv_img), C.byref(p010_img), tf,
+    st = getattr(lib, lib_prefix + ("generateGainMapLUT" if lut else "generateGainMap"))(C.byref(yuv_img), C.byref(p010_img), tf,
                                                       C.byref(md), out.ctypes.data,
                                                       int(sdr_is_601), threads)
     return st, out[:mw * mh].reshape(mh, mw), md
 
 
-def apply(lib_prefix, yuv_img, map_arr, md, fmt, max_display_boost, threads=0):
+def apply(lib_prefix, yuv_img, map_arr, md, fmt, max_display_boost, threads=0, lut=False):
     lib = load() if lib_prefix == "orc_" else load_ref()
     mh, mw = map_arr.shape
     m = map_image(map_arr, mw, mh)
     w, h = yuv_img.width, yuv_img.height
     out = np.zeros(max(out_bytes_per_image(fmt, w, h), 8), np.uint8)
     dest = Image(out.ctypes.data, 0, 0, CG_UNSPECIFIED, None, 0, 0, -1)
-    st = getattr(lib, lib_prefix + "applyGainMap")(C.byref(yuv_img), C.byref(m), C.byref(md), fmt,
+    st = getattr(lib, lib_prefix + ("applyGainMapLUT" if lut else "applyGainMap"))(C.byref(yuv_img), C.byref(m), C.byref(md), fmt,
                                                    max_display_boost, C.byref(dest), threads)
     return st, out[:out_bytes_per_image(fmt, w, h)], dest

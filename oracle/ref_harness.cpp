@@ -211,8 +211,8 @@ int ref_convertYuv(orc_image* i, int s, int d) {
 }
 
 /* ultrahdr.cpp:220-336 call order, single-threaded */
-int ref_generateGainMap(const orc_image* yuv_, const orc_image* p010_, int hdr_tf, orc_metadata* md,
-                        uint8_t* map_out, int sdr_is_601, int /*threads*/) {
+static int ref_generate_impl(const orc_image* yuv_, const orc_image* p010_, int hdr_tf, orc_metadata* md,
+                             uint8_t* map_out, int sdr_is_601, bool lut) {
   if (!yuv_ || !p010_ || !md || !map_out || !yuv_->data || !yuv_->chroma_data || !p010_->data ||
       !p010_->chroma_data)
     return ORC_ERR_BAD_PTR;
@@ -227,8 +227,8 @@ int ref_generateGainMap(const orc_image* yuv_, const orc_image* p010_, int hdr_t
   float hdr_white_nits;
   switch (hdr_tf) {
     case ORC_TF_LINEAR: hdrInvOetf = identityConversion; hdr_white_nits = kHlgMaxNits; break;
-    case ORC_TF_HLG: hdrInvOetf = hlgInvOetf; hdr_white_nits = kHlgMaxNits; break;
-    case ORC_TF_PQ: hdrInvOetf = pqInvOetf; hdr_white_nits = kPqMaxNits; break;
+    case ORC_TF_HLG: hdrInvOetf = lut ? (ColorTransformFn)hlgInvOetfLUT : (ColorTransformFn)hlgInvOetf; hdr_white_nits = kHlgMaxNits; break;
+    case ORC_TF_PQ: hdrInvOetf = lut ? (ColorTransformFn)pqInvOetfLUT : (ColorTransformFn)pqInvOetf; hdr_white_nits = kPqMaxNits; break;
     default: return ORC_ERR_INVALID_TRANS_FUNC;
   }
   ultrahdr_metadata_struct m;
@@ -252,7 +252,7 @@ int ref_generateGainMap(const orc_image* yuv_, const orc_image* p010_, int hdr_t
     for (size_t x = 0; x < map_w; ++x) {
       Color sdr_yuv_gamma = sampleYuv420(&yuv, kMapDimensionScaleFactor, x, y);
       Color sdr_rgb_gamma = sdrYuvToRgbFn(sdr_yuv_gamma);
-      Color sdr_rgb = srgbInvOetf(sdr_rgb_gamma);
+      Color sdr_rgb = lut ? srgbInvOetfLUT(sdr_rgb_gamma) : srgbInvOetf(sdr_rgb_gamma);
       float sdr_y_nits = luminanceFn(sdr_rgb) * kSdrWhiteNits;
       Color hdr_yuv_gamma = sampleP010(&p010, kMapDimensionScaleFactor, x, y);
       Color hdr_rgb_gamma = hdrYuvToRgbFn(hdr_yuv_gamma);
@@ -272,9 +272,19 @@ int ref_generateGainMap(const orc_image* yuv_, const orc_image* p010_, int hdr_t
   return ORC_OK;
 }
 
+int ref_generateGainMap(const orc_image* yuv, const orc_image* p010, int hdr_tf, orc_metadata* md, uint8_t* map_out,
+                        int sdr_is_601, int /*threads*/) {
+  return ref_generate_impl(yuv, p010, hdr_tf, md, map_out, sdr_is_601, false);
+}
+/* the branches ultrahdr.cpp:230,238,319 take when USE_*_LUT is 1 */
+int ref_generateGainMapLUT(const orc_image* yuv, const orc_image* p010, int hdr_tf, orc_metadata* md, uint8_t* map_out,
+                           int sdr_is_601, int /*threads*/) {
+  return ref_generate_impl(yuv, p010, hdr_tf, md, map_out, sdr_is_601, true);
+}
+
 /* ultrahdr.cpp:364-494 call order, single-threaded */
-int ref_applyGainMap(const orc_image* yuv_, const orc_image* map_, const orc_metadata* md, int fmt,
-                     float max_display_boost, orc_image* dest, int /*threads*/) {
+static int ref_apply_impl(const orc_image* yuv_, const orc_image* map_, const orc_metadata* md, int fmt,
+                          float max_display_boost, orc_image* dest, bool lut) {
   if (!yuv_ || !map_ || !md || !dest || !yuv_->data || !yuv_->chroma_data || !map_->data)
     return ORC_ERR_BAD_PTR;
   ultrahdr_metadata_struct m = to_ref(md);
@@ -295,14 +305,15 @@ int ref_applyGainMap(const orc_image* yuv_, const orc_image* map_, const orc_met
   dest->colorGamut = yuv.colorGamut;
   ShepardsIDW idwTable(static_cast<int>(map_scale_factor));
   float display_boost = (std::min)(max_display_boost, m.maxContentBoost);
+  GainLUT gainLUT(metadata, display_boost);
   size_t width = yuv.width, height = yuv.height;
   for (size_t y = 0; y < height; ++y)
     for (size_t x = 0; x < width; ++x) {
       Color yuv_gamma_sdr = getYuv420Pixel(&yuv, x, y);
       Color rgb_gamma_sdr = p3YuvToRgb(yuv_gamma_sdr);
-      Color rgb_sdr = srgbInvOetf(rgb_gamma_sdr);
+      Color rgb_sdr = lut ? srgbInvOetfLUT(rgb_gamma_sdr) : srgbInvOetf(rgb_gamma_sdr);
       float gain = sampleMap(&map, map_scale_factor, x, y, idwTable);
-      Color rgb_hdr = applyGain(rgb_sdr, gain, metadata, display_boost);
+      Color rgb_hdr = lut ? applyGainLUT(rgb_sdr, gain, gainLUT) : applyGain(rgb_sdr, gain, metadata, display_boost);
       rgb_hdr = rgb_hdr / display_boost;
       size_t pixel_idx = x + y * width;
       switch (fmt) {
@@ -319,15 +330,47 @@ int ref_applyGainMap(const orc_image* yuv_, const orc_image* map_, const orc_met
           break;
         }
         case ORC_OUT_HDR_HLG:
-          reinterpret_cast<uint32_t*>(dest->data)[pixel_idx] = colorToRgba1010102(hlgOetf(rgb_hdr));
+          reinterpret_cast<uint32_t*>(dest->data)[pixel_idx] = colorToRgba1010102(lut ? hlgOetfLUT(rgb_hdr) : hlgOetf(rgb_hdr));
           break;
         case ORC_OUT_HDR_PQ:
-          reinterpret_cast<uint32_t*>(dest->data)[pixel_idx] = colorToRgba1010102(pqOetf(rgb_hdr));
+          reinterpret_cast<uint32_t*>(dest->data)[pixel_idx] = colorToRgba1010102(lut ? pqOetfLUT(rgb_hdr) : pqOetf(rgb_hdr));
           break;
         default: break;
       }
     }
   return ORC_OK;
+}
+int ref_applyGainMap(const orc_image* yuv, const orc_image* map, const orc_metadata* md, int fmt, float max_display_boost,
+                     orc_image* dest, int /*threads*/) {
+  return ref_apply_impl(yuv, map, md, fmt, max_display_boost, dest, false);
+}
+/* the branches ultrahdr.cpp:433,446,470,481 take when USE_*_LUT is 1 */
+int ref_applyGainMapLUT(const orc_image* yuv, const orc_image* map, const orc_metadata* md, int fmt,
+                        float max_display_boost, orc_image* dest, int /*threads*/) {
+  return ref_apply_impl(yuv, map, md, fmt, max_display_boost, dest, true);
+}
+
+/* GainLUT tables as the reference's header builds them (gainmapmath.h:151-182) */
+void ref_gainLutBuild(float minB, float maxB, int with_display_boost, float db, float* table) {
+  ultrahdr_metadata_struct m;
+  m.minContentBoost = minB;
+  m.maxContentBoost = maxB;
+  // the table is private: read it back through getGainFactor at the knots idx/(N-1)... which rounds to idx only
+  // if float(idx/1023f*1023f+0.5) truncates to idx; use the exact inverse instead: (idx)/1023 as the nearest float
+  // whose product lands in [idx-0.5, idx+0.5)
+  GainLUT a(&m), b(&m, db);
+  GainLUT& g = with_display_boost ? b : a;
+  for (size_t idx = 0; idx < kGainFactorNumEntries; ++idx) {
+    float gain = static_cast<float>(idx) / static_cast<float>(kGainFactorNumEntries - 1);
+    table[idx] = g.getGainFactor(gain);
+  }
+}
+float ref_gainLutFactor(float minB, float maxB, float db, float gain) {
+  ultrahdr_metadata_struct m;
+  m.minContentBoost = minB;
+  m.maxContentBoost = maxB;
+  GainLUT g(&m, db);
+  return g.getGainFactor(gain);
 }
 
 }  // extern "C"

@@ -132,6 +132,85 @@ float orc_pqInvOetf(float e) {
 
 static orc_color map3(float (*f)(float), orc_color e) { return c3(f(e.r), f(e.g), f(e.b)); }
 
+/* ------------------------------------------------------------------------------------------
+ * LUT variants (gainmapmath.cpp:21-64 tables, :162-171,269-277,292-302,316-324,344-354 accessors;
+ * GainLUT gainmapmath.h:149-182).  Dead in the fork's live path (its USE_*_LUT macros are only
+ * defined in jpegr.cpp:33-38, after which ultrahdr.cpp never sees them) but exported and tested
+ * (gainmapmath_test.cpp:808-939); upstream libultrahdr runs with them ON.
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_SRGB_INV_N 1024u  /* gainmapmath.h:268-269 */
+#define ORC_HLG_N 65536u      /* :329-330 */
+#define ORC_HLG_INV_N 4096u   /* :342-343 */
+#define ORC_PQ_N 65536u       /* :355-356 */
+#define ORC_PQ_INV_N 4096u    /* :368-369 */
+static float t_srgb_inv[ORC_SRGB_INV_N], t_hlg[ORC_HLG_N], t_hlg_inv[ORC_HLG_INV_N], t_pq[ORC_PQ_N],
+    t_pq_inv[ORC_PQ_INV_N];
+static pthread_once_t lut_once = PTHREAD_ONCE_INIT;
+static void lut_fill(float* t, size_t n, float (*f)(float)) { /* gainmapmath.cpp:21-64 */
+  for (size_t idx = 0; idx < n; idx++) {
+    float value = (float)idx / (float)(n - 1);
+    t[idx] = f(value);
+  }
+}
+static void lut_build(void) {
+  lut_fill(t_pq, ORC_PQ_N, orc_pqOetf);
+  lut_fill(t_pq_inv, ORC_PQ_INV_N, orc_pqInvOetf);
+  lut_fill(t_hlg, ORC_HLG_N, orc_hlgOetf);
+  lut_fill(t_hlg_inv, ORC_HLG_INV_N, orc_hlgInvOetf);
+  lut_fill(t_srgb_inv, ORC_SRGB_INV_N, orc_srgbInvOetf);
+}
+/* `uint32_t value = static_cast<uint32_t>(e * (N - 1) + 0.5); value = CLIP3(value, 0, N - 1);`:
+ * e * size_t -> float product, + 0.5 (double literal) -> double sum, truncated.  A negative or
+ * huge sum is undefined behaviour in C++; on x86-64 the conversion goes through the 64-bit
+ * cvttsd2si and keeps the low 32 bits, which is what this restates (int64 -> uint32). */
+static uint32_t lut_index(float e, uint32_t n) {
+  double pos = (double)(e * (float)(n - 1)) + 0.5;
+  uint32_t value;
+  if (pos != pos || pos >= 9223372036854775808.0 || pos < -9223372036854775808.0) value = 0u; /* "integer indefinite" low word */
+  else value = (uint32_t)(int64_t)pos;
+  return value > n - 1 ? n - 1 : value; /* CLIP3 on an unsigned: only the upper bound can bite */
+}
+float orc_srgbInvOetfLUT(float e) { pthread_once(&lut_once, lut_build); return t_srgb_inv[lut_index(e, ORC_SRGB_INV_N)]; }
+float orc_hlgOetfLUT(float e) { pthread_once(&lut_once, lut_build); return t_hlg[lut_index(e, ORC_HLG_N)]; }
+float orc_hlgInvOetfLUT(float e) { pthread_once(&lut_once, lut_build); return t_hlg_inv[lut_index(e, ORC_HLG_INV_N)]; }
+float orc_pqOetfLUT(float e) { pthread_once(&lut_once, lut_build); return t_pq[lut_index(e, ORC_PQ_N)]; }
+float orc_pqInvOetfLUT(float e) { pthread_once(&lut_once, lut_build); return t_pq_inv[lut_index(e, ORC_PQ_INV_N)]; }
+const float* orc_lut_table(int which, size_t* n) { /* 0 srgbInv 1 hlgInv 2 pqInv 4 hlg 5 pq */
+  pthread_once(&lut_once, lut_build);
+  switch (which) {
+    case 0: *n = ORC_SRGB_INV_N; return t_srgb_inv;
+    case 1: *n = ORC_HLG_INV_N; return t_hlg_inv;
+    case 2: *n = ORC_PQ_INV_N; return t_pq_inv;
+    case 4: *n = ORC_HLG_N; return t_hlg;
+    case 5: *n = ORC_PQ_N; return t_pq;
+    default: *n = 0; return NULL;
+  }
+}
+
+/* GainLUT (gainmapmath.h:151-182).  `log2(float)` / `exp2(float)` there are unqualified calls from
+ * namespace ultrahdr with only <cmath> included: they bind to the C double functions, so the
+ * weighted sum runs in double and is rounded into the float `logBoost`; the product with
+ * boostFactor is a float product.  with_display_boost == 0 is the one-argument constructor. */
+void orc_gainLutBuild(float minBoost, float maxBoost, int with_display_boost, float displayBoost,
+                      float* table) {
+  float boostFactor = 1.0f;
+  if (with_display_boost) boostFactor = displayBoost > 0 ? displayBoost / maxBoost : 1.0f;
+  for (size_t idx = 0; idx < ORC_GAIN_LUT_N; idx++) {
+    float value = (float)idx / (float)(ORC_GAIN_LUT_N - 1);
+    float logBoost = (float)(log2((double)minBoost) * (double)(1.0f - value) +
+                             log2((double)maxBoost) * (double)value);
+    if (with_display_boost) table[idx] = (float)exp2((double)(logBoost * boostFactor));
+    else table[idx] = (float)exp2((double)logBoost);
+  }
+}
+float orc_gainLutFactor(const float* table, float gain) { /* getGainFactor, :173-178 */
+  return table[lut_index(gain, ORC_GAIN_LUT_N)];
+}
+orc_color orc_applyGainLUT(orc_color e, float gain, const float* table) { /* gainmapmath.cpp:557-560 */
+  float f = orc_gainLutFactor(table, gain);
+  return c3(e.r * f, e.g * f, e.b * f);
+}
+
 /* gainmapmath.cpp:359-393 */
 static orc_color mat3(const float m[9], orc_color e) {
   return c3(m[0] * e.r + m[1] * e.g + m[2] * e.b, m[3] * e.r + m[4] * e.g + m[5] * e.b,
@@ -495,7 +574,7 @@ typedef struct {
   const orc_image *yuv, *p010;
   uint8_t* map;
   size_t map_w;
-  int hdr_tf, lum_gamut, sdr_yuv_gamut, hdr_yuv_gamut;
+  int hdr_tf, lum_gamut, sdr_yuv_gamut, hdr_yuv_gamut, lut;
   const float* gamut_m;
   float hdr_white_nits, minBoost, maxBoost, log2Min, log2Max;
   float tmin[ORC_MAX_THREADS], tmax[ORC_MAX_THREADS];
@@ -508,14 +587,14 @@ static void gen_band(void* p, size_t r0, size_t r1, int tid) {
     for (size_t x = 0; x < c->map_w; ++x) { /* ultrahdr.cpp:315-335 */
       orc_color sdr_yuv_gamma = orc_sampleYuv420(c->yuv, 4, x, y);
       orc_color sdr_rgb_gamma = orc_yuvToRgb(c->sdr_yuv_gamut, sdr_yuv_gamma);
-      orc_color sdr_rgb = map3(orc_srgbInvOetf, sdr_rgb_gamma);
+      orc_color sdr_rgb = map3(c->lut ? orc_srgbInvOetfLUT : orc_srgbInvOetf, sdr_rgb_gamma); /* :319-323 */
       float sdr_y_nits = orc_luminance(c->lum_gamut, sdr_rgb) * 203.0f;
 
       orc_color hdr_yuv_gamma = orc_sampleP010(c->p010, 4, x, y);
       orc_color hdr_rgb_gamma = orc_yuvToRgb(c->hdr_yuv_gamut, hdr_yuv_gamma);
       orc_color hdr_rgb = hdr_rgb_gamma;
-      if (c->hdr_tf == ORC_TF_HLG) hdr_rgb = map3(orc_hlgInvOetf, hdr_rgb_gamma);
-      else if (c->hdr_tf == ORC_TF_PQ) hdr_rgb = map3(orc_pqInvOetf, hdr_rgb_gamma);
+      if (c->hdr_tf == ORC_TF_HLG) hdr_rgb = map3(c->lut ? orc_hlgInvOetfLUT : orc_hlgInvOetf, hdr_rgb_gamma); /* :230-234 */
+      else if (c->hdr_tf == ORC_TF_PQ) hdr_rgb = map3(c->lut ? orc_pqInvOetfLUT : orc_pqInvOetf, hdr_rgb_gamma); /* :238-242 */
       if (c->gamut_m) hdr_rgb = mat3(c->gamut_m, hdr_rgb);
       float hdr_y_nits = orc_luminance(c->lum_gamut, hdr_rgb) * c->hdr_white_nits;
 
@@ -532,9 +611,9 @@ static void gen_band(void* p, size_t r0, size_t r1, int tid) {
   c->tmin[tid] = gmin; c->tmax[tid] = gmax;
 }
 
-int orc_generateGainMapStats(const orc_image* yuv, const orc_image* p010, int hdr_tf,
-                             orc_metadata* md, uint8_t* map_out, int sdr_is_601, int threads,
-                             float* minmax_out) {
+static int generate_impl(const orc_image* yuv, const orc_image* p010, int hdr_tf,
+                         orc_metadata* md, uint8_t* map_out, int sdr_is_601, int threads,
+                         float* minmax_out, int lut) {
   /* ultrahdr.cpp:189-202 */
   if (yuv == NULL || p010 == NULL || md == NULL || map_out == NULL || yuv->data == NULL ||
       yuv->chroma_data == NULL || p010->data == NULL || p010->chroma_data == NULL)
@@ -548,6 +627,7 @@ int orc_generateGainMapStats(const orc_image* yuv, const orc_image* p010, int hd
   c.map_w = yuv->width / 4;
   size_t map_h = yuv->height / 4;
   c.hdr_tf = hdr_tf;
+  c.lut = lut;
   switch (hdr_tf) { /* ultrahdr.cpp:222-248 */
     case ORC_TF_LINEAR: c.hdr_white_nits = 1000.0f; break;
     case ORC_TF_HLG: c.hdr_white_nits = 1000.0f; break;
@@ -586,9 +666,20 @@ int orc_generateGainMapStats(const orc_image* yuv, const orc_image* p010, int hd
   }
   return ORC_OK;
 }
+int orc_generateGainMapStats(const orc_image* yuv, const orc_image* p010, int hdr_tf,
+                             orc_metadata* md, uint8_t* map_out, int sdr_is_601, int threads,
+                             float* minmax_out) {
+  return generate_impl(yuv, p010, hdr_tf, md, map_out, sdr_is_601, threads, minmax_out, 0);
+}
 int orc_generateGainMap(const orc_image* yuv, const orc_image* p010, int hdr_tf, orc_metadata* md,
                         uint8_t* map_out, int sdr_is_601, int threads) {
-  return orc_generateGainMapStats(yuv, p010, hdr_tf, md, map_out, sdr_is_601, threads, NULL);
+  return generate_impl(yuv, p010, hdr_tf, md, map_out, sdr_is_601, threads, NULL, 0);
+}
+/* the same loop as upstream builds it: USE_SRGB/HLG/PQ_INVOETF_LUT = 1 (ultrahdr.cpp:230,238,319) */
+int orc_generateGainMapLUT(const orc_image* yuv, const orc_image* p010, int hdr_tf, orc_metadata* md,
+                           uint8_t* map_out, int sdr_is_601, int threads) {
+  pthread_once(&lut_once, lut_build);
+  return generate_impl(yuv, p010, hdr_tf, md, map_out, sdr_is_601, threads, NULL, 1);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -600,8 +691,9 @@ typedef struct {
   const orc_metadata* md;
   idw_tables idw;
   size_t scale;
-  int fmt;
+  int fmt, lut;
   float display_boost;
+  float gain_lut[ORC_GAIN_LUT_N];
 } app_ctx;
 
 static void app_band(void* p, size_t r0, size_t r1, int tid) {
@@ -612,10 +704,12 @@ static void app_band(void* p, size_t r0, size_t r1, int tid) {
     for (size_t x = 0; x < width; ++x) { /* ultrahdr.cpp:428-494 */
       orc_color yuv_gamma_sdr = orc_getYuv420Pixel(c->yuv, x, y);
       orc_color rgb_gamma_sdr = orc_yuvToRgb(ORC_CG_P3, yuv_gamma_sdr); /* always BT.601, :431 */
-      orc_color rgb_sdr = map3(orc_srgbInvOetf, rgb_gamma_sdr);
+      orc_color rgb_sdr = map3(c->lut ? orc_srgbInvOetfLUT : orc_srgbInvOetf, rgb_gamma_sdr); /* :433-437 */
       float gain = sampleMapIdw(c->map, c->scale, x, y, &c->idw);
-      orc_color rgb_hdr = orc_applyGain4(rgb_sdr, gain, c->md->minContentBoost,
-                                         c->md->maxContentBoost, c->display_boost);
+      orc_color rgb_hdr;
+      if (c->lut) rgb_hdr = orc_applyGainLUT(rgb_sdr, gain, c->gain_lut); /* :446-447 */
+      else rgb_hdr = orc_applyGain4(rgb_sdr, gain, c->md->minContentBoost, c->md->maxContentBoost,
+                                    c->display_boost);
       rgb_hdr = c3(rgb_hdr.r / c->display_boost, rgb_hdr.g / c->display_boost,
                    rgb_hdr.b / c->display_boost);
       size_t idx = x + y * width;
@@ -633,10 +727,12 @@ static void app_band(void* p, size_t r0, size_t r1, int tid) {
           break;
         }
         case ORC_OUT_HDR_HLG:
-          ((uint32_t*)c->dest->data)[idx] = orc_colorToRgba1010102(map3(orc_hlgOetf, rgb_hdr));
+          ((uint32_t*)c->dest->data)[idx] =
+              orc_colorToRgba1010102(map3(c->lut ? orc_hlgOetfLUT : orc_hlgOetf, rgb_hdr)); /* :470-474 */
           break;
         case ORC_OUT_HDR_PQ:
-          ((uint32_t*)c->dest->data)[idx] = orc_colorToRgba1010102(map3(orc_pqOetf, rgb_hdr));
+          ((uint32_t*)c->dest->data)[idx] =
+              orc_colorToRgba1010102(map3(c->lut ? orc_pqOetfLUT : orc_pqOetf, rgb_hdr)); /* :481-485 */
           break;
         default: break; /* nothing written, :491-493 */
       }
@@ -644,8 +740,8 @@ static void app_band(void* p, size_t r0, size_t r1, int tid) {
   }
 }
 
-int orc_applyGainMap(const orc_image* yuv, const orc_image* map, const orc_metadata* md, int fmt,
-                     float max_display_boost, orc_image* dest, int threads) {
+static int apply_impl(const orc_image* yuv, const orc_image* map, const orc_metadata* md, int fmt,
+                      float max_display_boost, orc_image* dest, int threads, int lut) {
   /* ultrahdr.cpp:364-406 */
   if (yuv == NULL || map == NULL || md == NULL || dest == NULL || yuv->data == NULL ||
       yuv->chroma_data == NULL || map->data == NULL)
@@ -666,9 +762,21 @@ int orc_applyGainMap(const orc_image* yuv, const orc_image* map, const orc_metad
   idw_init(&c.idw, (int)c.scale);
   c.display_boost = max_display_boost < md->maxContentBoost ? max_display_boost
                                                             : md->maxContentBoost; /* :415 */
+  c.lut = lut;
+  if (lut) orc_gainLutBuild(md->minContentBoost, md->maxContentBoost, 1, c.display_boost, c.gain_lut); /* :416 */
   run_bands(app_band, &c, yuv->height, c.scale, threads); /* jobs of `scale` rows, :505 */
   idw_free(&c.idw);
   return ORC_OK;
+}
+int orc_applyGainMap(const orc_image* yuv, const orc_image* map, const orc_metadata* md, int fmt,
+                     float max_display_boost, orc_image* dest, int threads) {
+  return apply_impl(yuv, map, md, fmt, max_display_boost, dest, threads, 0);
+}
+/* the same loop as upstream builds it: USE_SRGB_INVOETF_LUT, USE_APPLY_GAIN_LUT, USE_HLG/PQ_OETF_LUT = 1 */
+int orc_applyGainMapLUT(const orc_image* yuv, const orc_image* map, const orc_metadata* md, int fmt,
+                        float max_display_boost, orc_image* dest, int threads) {
+  pthread_once(&lut_once, lut_build);
+  return apply_impl(yuv, map, md, fmt, max_display_boost, dest, threads, 1);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -847,9 +955,17 @@ int orc_resize(const orc_image* in, int ow, int oh, orc_image* out) {
 /* batch evaluation of the scalar functions (tests compare the device functions against these) */
 void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost) {
   float l2min = (float)log2((double)minBoost), l2max = (float)log2((double)maxBoost);
+  float gain_lut[ORC_GAIN_LUT_N];
+  if (fn == 46) orc_gainLutBuild(minBoost, maxBoost, 1, maxBoost, gain_lut);
   for (size_t i = 0; i < n; ++i) {
     float x = in[i], y = 0.0f;
     switch (fn) {
+      case 40: y = orc_srgbInvOetfLUT(x); break;
+      case 41: y = orc_hlgInvOetfLUT(x); break;
+      case 42: y = orc_pqInvOetfLUT(x); break;
+      case 44: y = orc_hlgOetfLUT(x); break;
+      case 45: y = orc_pqOetfLUT(x); break;
+      case 46: y = orc_gainLutFactor(gain_lut, x); break;
       case 0: y = orc_srgbInvOetf(x); break;
       case 1: y = orc_hlgInvOetf(x); break;
       case 2: y = orc_pqInvOetf(x); break;

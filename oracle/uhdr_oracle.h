@@ -85,6 +85,21 @@ uint64_t orc_colorToRgbaF16(orc_color e);
 uint16_t orc_floatToHalf(float f);
 void orc_transformYuv420(orc_image* img, size_t x_chroma, size_t y_chroma, int src, int dst);
 
+/* ---- LUT variants (gainmapmath.cpp:21-64,162-171,269-354; GainLUT gainmapmath.h:149-182) ---- */
+#define ORC_GAIN_LUT_N 1024u /* kGainFactorNumEntries, gainmapmath.h:149-150 */
+float orc_srgbInvOetfLUT(float e);
+float orc_hlgOetfLUT(float e);
+float orc_hlgInvOetfLUT(float e);
+float orc_pqOetfLUT(float e);
+float orc_pqInvOetfLUT(float e);
+/* the static tables themselves: which = 0 srgbInv(1024) 1 hlgInv(4096) 2 pqInv(4096) 4 hlg(65536) 5 pq(65536) */
+const float* orc_lut_table(int which, size_t* n);
+/* GainLUT(metadata) when with_display_boost == 0, GainLUT(metadata, displayBoost) otherwise */
+void orc_gainLutBuild(float minBoost, float maxBoost, int with_display_boost, float displayBoost,
+                      float* table /* ORC_GAIN_LUT_N */);
+float orc_gainLutFactor(const float* table, float gain);
+orc_color orc_applyGainLUT(orc_color e, float gain, const float* table);
+
 /* ---- whole-image functions (ultrahdr.cpp / jpegr.cpp) ---- */
 /* map_out: caller-allocated (w/4)*(h/4) bytes.  threads<=0 -> min(ncpu,4) like the reference */
 int orc_generateGainMap(const orc_image* yuv420, const orc_image* p010, int hdr_tf,
@@ -96,6 +111,13 @@ int orc_generateGainMapStats(const orc_image* yuv420, const orc_image* p010, int
 int orc_applyGainMap(const orc_image* yuv420, const orc_image* gainmap,
                      const orc_metadata* metadata, int output_format, float max_display_boost,
                      orc_image* dest, int threads);
+/* the two loops as a build with jpegr.cpp:33-38's USE_*_LUT macros visible to ultrahdr.cpp compiles them
+ * (upstream libultrahdr's configuration; dead code in this fork) */
+int orc_generateGainMapLUT(const orc_image* yuv420, const orc_image* p010, int hdr_tf,
+                           orc_metadata* metadata, uint8_t* map_out, int sdr_is_601, int threads);
+int orc_applyGainMapLUT(const orc_image* yuv420, const orc_image* gainmap,
+                        const orc_metadata* metadata, int output_format, float max_display_boost,
+                        orc_image* dest, int threads);
 int orc_toneMap(const orc_image* src, orc_image* dest);
 int orc_convertYuv(orc_image* image, int src_encoding, int dest_encoding);
 
@@ -105,7 +127,8 @@ int orc_mirror(const orc_image* in, int dir, orc_image* out);
 int orc_rotate(const orc_image* in, int clockwise_degree, orc_image* out);
 int orc_resize(const orc_image* in, int out_width, int out_height, orc_image* out);
 
-/* fn: 0 srgbInvOetf 1 hlgInvOetf 2 pqInvOetf 3 encodeGain(y_sdr=1,y_hdr=x) 4 hlgOetf 5 pqOetf */
+/* fn: 0 srgbInvOetf 1 hlgInvOetf 2 pqInvOetf 3 encodeGain(y_sdr=1,y_hdr=x) 4 hlgOetf 5 pqOetf;
+ * 40/41/42/44/45 the LUT accessors of fn 0/1/2/4/5; 46 GainLUT(min,max,displayBoost=max).getGainFactor */
 void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost);
 
 /* ---- helpers for tests / bench ---- */

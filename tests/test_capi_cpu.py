@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(api):
     for n in names:
         assert hasattr(lib, n), "libuhdr_hip.so does not export %s" % n
         assert n in api.SIGNATURES, "python binding lacks %s" % n
-    assert lib.uhdr_hip_abi_version() == 1
+    assert lib.uhdr_hip_abi_version() == 2
     out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH]).decode()
     exported = set(re.findall(r" T (uhdr_hip_\w+)", out))
     assert exported == set(names), exported ^ set(names)

@@ -463,3 +463,91 @@ def test_effects_error_codes(orc):                                              
     p010 = orc.Image(img.data, 32, 16, 0, None, 0, 0, orc.FMT_P010)
     assert L.orc_mirror(C.byref(p010), 0, C.byref(o)) == -30000
     assert L.orc_resize(C.byref(p010), 8, 8, C.byref(o)) == -30000
+
+
+# ---------------------------------------------------------------------------------------------------
+# LUT variants: restated reference tests + the reference's own object code
+# ---------------------------------------------------------------------------------------------------
+LUTS = (("srgbInvOetf", 0, 1024), ("hlgInvOetf", 1, 4096), ("pqInvOetf", 2, 4096), ("hlgOetf", 4, 65536), ("pqOetf", 5, 65536))
+
+
+def test_known_answers_lut_accessors_at_the_knots(orc):                         # gainmapmath_test.cpp:808-841
+    L = orc.load()
+    for name, which, n in LUTS:
+        knots = (np.arange(n, dtype=np.float32) / np.float32(n - 1)).astype(np.float32)
+        direct = orc.eval_transfer({0: 0, 1: 1, 2: 2, 4: 4, 5: 5}[which], knots)
+        via_lut = orc.eval_transfer(40 + which, knots)
+        assert np.array_equal(direct, via_lut), name                           # EXPECT_FLOAT_EQ holds with equality
+        assert np.array_equal(orc.lut_table(which), direct), name
+        assert getattr(L, "orc_" + name + "LUT")(float(knots[n // 3])) == direct[n // 3]
+
+
+def test_known_answers_apply_gain_lut(orc):                                     # gainmapmath_test.cpp:843-939
+    L = orc.load()
+    colors = [(0, 0, 0), (1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    values = (np.arange(1024, dtype=np.float32) / np.float32(1023)).astype(np.float32)
+    for boost in range(1, 11):
+        for mn in (1.0 / boost, 1.0, 1.0 / float(np.float32(boost) ** np.float32(1.0 / 3.0))):
+            mn, mx = float(np.float32(mn)), float(boost)
+            plain = orc.gain_lut("orc_", mn, mx)
+            with_boost = orc.gain_lut("orc_", mn, mx, mx)
+            assert np.array_equal(plain, with_boost)                           # EXPECT_RGB_EQ
+            tbl = plain.ctypes.data_as(C.POINTER(C.c_float))
+            for v in values[::37]:
+                for c in colors:
+                    col = orc.Color(*[float(t) for t in c])
+                    a = L.orc_applyGain3(col, float(v), mn, mx).tup()
+                    b = L.orc_applyGainLUT(col, float(v), tbl).tup()
+                    assert max(abs(p - q) for p, q in zip(a, b)) <= EPS        # EXPECT_RGB_NEAR
+
+
+def test_lut_restatement_equals_reference_object_code(orc):
+    R = orc.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    L = orc.load()
+    rng = np.random.RandomState(7)
+    xs = np.concatenate([rng.uniform(0, 1, 30000), rng.uniform(0.999, 1.3, 2000), rng.uniform(0, 2e-3, 3000),
+                         [0, 1, 0.5, 2.0, 70000.0, 4.3e9, 1e19, 3e38, -0.0001, -0.3, -5.0, float("nan"), float("inf")]]).astype(np.float32)
+    for name, which, n in LUTS:
+        fo, fr = getattr(L, "orc_" + name + "LUT"), getattr(R, "ref_" + name + "LUT")
+        half = (np.arange(n, dtype=np.float64) + 0.5) / (n - 1)                  # index rounding boundaries
+        pts = np.concatenate([xs, half.astype(np.float32)[:: max(1, n // 4096)],
+                              np.nextafter(half.astype(np.float32), np.float32(0))[:: max(1, n // 4096)]])
+        for x in pts:
+            assert fo(float(x)) == fr(float(x)), (name, float(x))
+    for mn, mx, db in ((1.0, 4.926108, 4.926108), (0.5, 8.0, 3.0), (1.0, 49.26108, 49.26108), (0.25, 4.0, 1.0), (1.0, 1.0, 1.0),
+                       (1.0, 4.926108, FLT_MAX), (2.0, 16.0, 0.0)):
+        assert np.array_equal(orc.gain_lut("orc_", mn, mx), orc.gain_lut("ref_", mn, mx)), (mn, mx)
+        assert np.array_equal(orc.gain_lut("orc_", mn, mx, db), orc.gain_lut("ref_", mn, mx, db)), (mn, mx, db)
+        t = orc.gain_lut("orc_", mn, mx, db)
+        tbl = t.ctypes.data_as(C.POINTER(C.c_float))
+        for g in rng.uniform(0, 1, 500).astype(np.float32):
+            assert L.orc_gainLutFactor(tbl, float(g)) == R.ref_gainLutFactor(mn, mx, db, float(g))
+
+
+def test_lut_pipelines_equal_reference_object_code(orc):
+    """generateGainMap / applyGainMap with the USE_*_LUT branches (ultrahdr.cpp:230,238,319,433,446,470,481) taken,
+    restatement vs the reference's own LUT functions driven in the same order"""
+    R = orc.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    w, h = 96, 64
+    p010, yuv = orc.lcg_frame(w, h, 77)
+    for sg, hg in ((0, 2), (1, 1), (2, 0)):
+        for tf in (0, 1, 2):
+            yi, pi = orc.yuv420_image(yuv, w, h, sg), orc.p010_image(p010, w, h, hg)
+            a = orc.generate("orc_", yi, pi, tf, False, threads=2, lut=True)
+            b = orc.generate("ref_", yi, pi, tf, False, threads=1, lut=True)
+            assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]), (sg, hg, tf)
+            plain = orc.generate("orc_", yi, pi, tf, False, threads=2)
+            assert np.abs(a[1].astype(int) - plain[1].astype(int)).max() <= (3 if tf else 1)   # a LUT is an approximation
+    yi = orc.yuv420_image(yuv, w, h, 0)
+    for scale, mw, mh in ((4, 24, 16), (2, 48, 32), (1, 96, 64)):
+        m = np.random.RandomState(scale).randint(0, 256, (mh, mw)).astype(np.uint8)
+        for md in (orc.Metadata(6.0, 0.5, 1.0, 0.0, 0.0, 0.5, 6.0, 1), orc.Metadata(4.926108, 1.0, 1.0, 0.0, 0.0, 1.0, 4.926108, 1)):
+            for fmt in (1, 2, 3, 4):
+                for boost in (FLT_MAX, 3.0):
+                    a = orc.apply("orc_", yi, m, md, fmt, boost, threads=2, lut=True)
+                    b = orc.apply("ref_", yi, m, md, fmt, boost, threads=1, lut=True)
+                    assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]), (scale, fmt, boost)

@@ -50,6 +50,7 @@ def parse():
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra configs[1]/[4] timings (profiling runs)")
+    ap.add_argument("--no-stats", action="store_true", help="experiment: generate without the per-image content min/max pass")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same batch timed on the host CPU")
     return ap.parse_args()
 
@@ -59,6 +60,7 @@ class Batch:
 
     def __init__(self, lib, frames, rank):
         self.lib, self.n = lib, frames
+        self.stats = True
         self.p010, self.yuv, self.maps, self.outs = [], [], [], []
         for i in range(frames):
             p, y = synth.lcg_frame(W, H, sharding.image_seed(rank * frames + i))   # seed = 1234 + global image index
@@ -84,7 +86,7 @@ class Batch:
                 e0.record()
             rc = self.lib.uhdr_hip_generate_gainmap_batch(
                 m, self._slice(self.yi, lo), self._slice(self.pi, lo), api.TF_HLG, C.byref(self.md),
-                self._slice(self.mi, lo), 0, C.c_void_p(self.minmax.data_ptr() + 8 * lo), stream)
+                self._slice(self.mi, lo), 0, C.c_void_p(self.minmax.data_ptr() + 8 * lo) if self.stats else None, stream)
             assert rc == 0, rc
             if events is not None:
                 e1.record()
@@ -272,6 +274,7 @@ def main():
     fmt = api.OUTPUT_HDR_HLG if a.apply_format == "hlg" else api.OUTPUT_HDR_PQ
 
     batch = Batch(lib, a.frames, rank)
+    batch.stats = not a.no_stats
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     red = torch.zeros(2, dtype=torch.float32, device="cuda")
 

@@ -102,6 +102,10 @@ extern "C" {
 #define UHDR_HIP_APPLY_LUT 2
 #define UHDR_HIP_GENERATE_EXACT 0
 #define UHDR_HIP_GENERATE_LUT 1
+/* EXACT without the f32 pre-filter: every pixel takes the double-precision path.  Same bytes and statistics as
+ * UHDR_HIP_GENERATE_EXACT by construction (the filter only decides which waves can skip that path); kept as a
+ * verification switch for tests. */
+#define UHDR_HIP_GENERATE_UNFILTERED 2
 
 /* POD mirror of ultrahdr_uncompressed_struct (ultrahdr.h:152-181) */
 typedef struct uhdr_hip_image {

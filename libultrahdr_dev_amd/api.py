@@ -21,7 +21,7 @@ ERROR_INVALID_CROPPING_PARAMETERS, ERROR_UNSUPPORTED_FEATURE = -10011, -30000
 ERROR_UNSUPPORTED_MAP_SCALE_FACTOR, ERROR_INSUFFICIENT_RESOURCE = -20008, -20009
 MEM_HOST, MEM_DEVICE = 0, 1
 APPLY_FAST, APPLY_EXACT, APPLY_LUT = 0, 1, 2
-GENERATE_EXACT, GENERATE_LUT = 0, 1
+GENERATE_EXACT, GENERATE_LUT, GENERATE_UNFILTERED = 0, 1, 2
 ABI_VERSION = 2
 FLT_MAX = 3.4028234663852886e38
 

@@ -20,7 +20,7 @@ SOURCES = ["uhdr_kernels.hip", "uhdr_capi.hip"]
 DEPS = SOURCES + ["uhdr_kernels.h", "uhdr_device_math.h", os.path.join(ROOT, "include", "uhdr_hip.h")]
 SHIM_SOURCES = ["ultrahdr_shim.cpp"]
 SHIM_DEPS = SHIM_SOURCES + [os.path.join(ROOT, "include", "uhdr_hip.h"),
-                            os.path.join(ROOT, "include", "ultrahdr_hip", "ultrahdr.h")]
+                            os.path.join(ROOT, "include", "ultrahdr_hip", "ultrahdr_hip.h")]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

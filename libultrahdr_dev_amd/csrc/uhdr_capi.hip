@@ -233,6 +233,14 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   c.stat_keys = nullptr;
   c.lut = nullptr;
   c.bias4096 = 4096.0f;
+  // f32 pre-filter (gen_pair; error budget in DESIGN.md section 5): the fast gain is within kRel of the exact one
+  // (3.3e-6 by analysis on top of the exhaustively measured transfer-function errors), v_log_f32 within kLogAbs of
+  // log2 on [0.25, 64]; the float evaluation of the code value adds < 2.5e-5.  x1.25 on top.
+  const double kRel = 4.0e-6, kLogAbs = 5.0e-7;
+  c.flt_scale = (float)c.enc_scale;
+  c.flt_delta = (float)(1.25 * (c.enc_scale * (kRel * 1.4426950408889634 + kLogAbs) + 4.0e-5));
+  c.flt_lo = (float)((double)c.min_boost * (1.0 - 2.0 * kRel));
+  c.flt_hi = (float)((double)c.max_boost * (1.0 + 2.0 * kRel));
   return c;
 }
 
@@ -532,7 +540,9 @@ int uhdr_hip_generate_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const u
 int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, const uhdr_hip_image_t* p010s, int hdr_tf,
                                        uhdr_hip_metadata_t* metadata, uhdr_hip_image_t* dests, int sdr_is_601,
                                        int generate_mode, float* content_minmax, void* stream) {
-  if (generate_mode != UHDR_HIP_GENERATE_EXACT && generate_mode != UHDR_HIP_GENERATE_LUT) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  if (generate_mode != UHDR_HIP_GENERATE_EXACT && generate_mode != UHDR_HIP_GENERATE_LUT &&
+      generate_mode != UHDR_HIP_GENERATE_UNFILTERED)
+    return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
   const bool lut = generate_mode == UHDR_HIP_GENERATE_LUT;
   if (n < 0 || (n > 0 && (yuvs == nullptr || p010s == nullptr || dests == nullptr)) || metadata == nullptr)
     return UHDR_HIP_ERROR_BAD_PTR;
@@ -574,7 +584,7 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
       fill_generate_dest(&y, &dests[i + m]);
       ++m;
     }
-    HIP_TRY(launch_generate(c, b, m, hdr_tf, aligned, lut, s));
+    HIP_TRY(launch_generate(c, b, m, hdr_tf, aligned, lut, /*filter=*/generate_mode == UHDR_HIP_GENERATE_EXACT && c.flt_delta < 0.25f && c.min_boost >= 0.25f && c.max_boost <= 64.0f, s));
     i += m;
   }
   if (keys && n > 0) HIP_TRY(launch_stats_finalize(keys, n, s));

@@ -56,6 +56,13 @@ __device__ __forceinline__ float hlg_inv_oetf_exact(float e) {
   return (float)((exp((double)((e - UHDR_HLG_C) / UHDR_HLG_A)) + (double)UHDR_HLG_B) / (double)12.0f);
 }
 
+// e <= 0.5: e^2/3;  else (exp((e-c)/a) + b)/12 with exp(x) = 2^(x log2 e)
+__device__ __forceinline__ float hlg_inv_oetf_fast(float e) {
+  const float lo = (e * e) * (1.0f / 3.0f);
+  const float hi = (__builtin_amdgcn_exp2f((e - UHDR_HLG_C) * (1.4426950408889634f / UHDR_HLG_A)) + UHDR_HLG_B) * (1.0f / 12.0f);
+  return (e <= 0.5f) ? lo : hi;
+}
+
 // ---- PQ (gainmapmath.cpp:305-338) --------------------------------------------------------------
 #define UHDR_PQ_M1 (2610.0f / 16384.0f)
 #define UHDR_PQ_M2 (2523.0f / 4096.0f * 128.0f)

@@ -30,6 +30,9 @@ struct GenConsts {
   uint32_t width, height, map_w, map_h;
   uint32_t* stat_keys;  // 2 words per image of the launch (min key, max key), or nullptr
   const float* lut;     // device LUT buffer (LUT mode only)
+  // f32 pre-filter of the exact path (see gen_pair): code-value scale, half-width of the "too close to an integer"
+  // band, and the gains below / above which the clamp certainly applies
+  float flt_scale, flt_delta, flt_lo, flt_hi;
 };
 struct EvalConsts {
   float min_boost, max_boost, log2_min, log2_max;
@@ -115,7 +118,7 @@ static_assert(sizeof(AppConsts) + sizeof(AppBatch) <= 4096, "apply kernel argume
 
 // launchers (enqueue only; return hipError_t of the launch)
 hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, bool lut,
-                           hipStream_t s);
+                           bool filter, hipStream_t s);
 hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s);
 hipError_t launch_stats_finalize(uint32_t* keys, int n, hipStream_t s);
 // mode: 0 FAST, 1 EXACT, 2 LUT

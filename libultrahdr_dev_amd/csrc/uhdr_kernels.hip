@@ -68,6 +68,18 @@ __device__ __forceinline__ f2 pk_fma_sat(f2 a, f2 b, f2 c) {
   return r;
 }
 
+#ifdef UHDR_GEN_COUNT   // instrumentation build only (scripts/dbg_filter_rate.py): how often do waves leave the fast path?
+__device__ unsigned long long g_gen_count[4];   // wave-tiles, wave-tiles on the exact path, exact statistics passes, doubtful pixels
+extern "C" hipError_t uhdr_hip_debug_counters(unsigned long long* out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gen_count), sizeof(unsigned long long) * 4);
+  if (e == hipSuccess && reset) { unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_gen_count), z, sizeof(z)); }
+  return e;
+}
+#define UHDR_COUNT(i, v) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_gen_count[i], (unsigned long long)(v)); } while (0)
+#else
+#define UHDR_COUNT(i, v) do { } while (0)
+#endif
+
 // =================================================================================================
 // LUT mode: the reference's table accessors (gainmapmath.cpp:162-171,269-277,292-302,316-324,344-354) and
 // GainLUT (gainmapmath.h:151-182).  Everything here is float/integer arithmetic plus table reads, so the
@@ -157,11 +169,25 @@ __device__ __forceinline__ float cvt_word1(uint32_t w) {
 
 // LUT: the inverse OETFs are the reference's table accessors (ultrahdr.cpp:230,238,319 with USE_*_LUT = 1), read
 // from the LDS copies s_srgb (1024 entries) / s_hdr (4096 entries of the HLG or PQ table)
-template <int TF, bool LUT>
-__device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy)[2][4][2],
-                                         const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
-                                         const uint32_t (&u8)[2][2], const uint32_t (&v8)[2][2],
-                                         uint8_t (&out)[2], float (&gain)[2], const float* s_srgb, const float* s_hdr) {
+// FILTER: before the exact (f64) evaluation, the same chain is run with the f32 special-function unit.  Its gain is
+// within kFilterRelErr of the exact one (bounds measured exhaustively per function), so the
+// truncated code value can only differ when it lies within flt_delta of an integer; only waves holding such a
+// pixel (or one whose clamp decision is in doubt) pay for the exact path.  Bytes are identical either way.
+// Returns a 2-bit mask: bit k set <=> gain[k] is the exact (reference) unclamped gain; a clear bit means gain[k] is the
+// filter's estimate, within kGainRelErr of it.
+template <int TF, bool LUT, bool FILTER>
+__device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t (&hy)[2][4][2],
+                                             const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
+                                             const uint32_t (&u8)[2][2], const uint32_t (&v8)[2][2],
+                                             uint8_t (&out)[2], float (&gain)[2], const float* s_srgb, const float* s_hdr) {
+#if UHDR_GEN_EXPERIMENT == 1   // memory floor: loads + one store, no arithmetic to speak of
+  {
+    uint32_t x = 0;
+    for (int k = 0; k < 2; ++k) { for (int r = 0; r < 4; ++r) x ^= hy[k][r][0] ^ hy[k][r][1] ^ y8[k][r]; for (int r = 0; r < 2; ++r) x ^= huv[k][r][0] ^ huv[k][r][1] ^ u8[k][r] ^ v8[k][r]; }
+    out[0] = (uint8_t)x; out[1] = (uint8_t)(x >> 8); gain[0] = gain[1] = 1.0f;
+    return 3u;
+  }
+#endif
   f2 sy = splat(0.0f), su = splat(0.0f), sv = splat(0.0f);
   f2 hsy = splat(0.0f), hsu = splat(0.0f), hsv = splat(0.0f);
 #pragma unroll
@@ -214,6 +240,69 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
   f2 r = pk_add_sat(sy, splat(c.sdr_cr) * sv);
   f2 g = pk_add_sat(sy - splat(c.sdr_gcb) * su, -(splat(c.sdr_gcr) * sv));
   f2 b = pk_add_sat(sy, splat(c.sdr_cb) * su);
+  // HDR: YUV->RGB (ultrahdr.cpp:326-327)
+  f2 hr = pk_add_sat(hsy, splat(c.hdr_cr) * hsv);
+  f2 hg = pk_add_sat(hsy - splat(c.hdr_gcb) * hsu, -(splat(c.hdr_gcr) * hsv));
+  f2 hb = pk_add_sat(hsy, splat(c.hdr_cb) * hsu);
+
+#if UHDR_GEN_EXPERIMENT == 2   // sampling + YUV->RGB only
+  {
+    const f2 t = r + g + b + hr + hg + hb;
+    out[0] = (uint8_t)(int)(t.x * 40.0f); out[1] = (uint8_t)(int)(t.y * 40.0f); gain[0] = gain[1] = 1.0f;
+    return 3u;
+  }
+#endif
+  if (FILTER && !LUT && TF != 2) {
+    const f2 fr = (f2){srgb_inv_oetf_fast(r.x), srgb_inv_oetf_fast(r.y)};
+    const f2 fg = (f2){srgb_inv_oetf_fast(g.x), srgb_inv_oetf_fast(g.y)};
+    const f2 fb = (f2){srgb_inv_oetf_fast(b.x), srgb_inv_oetf_fast(b.y)};
+    const f2 fs = (splat(c.lum_r) * fr + splat(c.lum_g) * fg + splat(c.lum_b) * fb) * splat(203.0f);
+    f2 qr = hr, qg = hg, qb = hb;
+    if (TF == 1) {
+      qr = (f2){hlg_inv_oetf_fast(hr.x), hlg_inv_oetf_fast(hr.y)};
+      qg = (f2){hlg_inv_oetf_fast(hg.x), hlg_inv_oetf_fast(hg.y)};
+      qb = (f2){hlg_inv_oetf_fast(hb.x), hlg_inv_oetf_fast(hb.y)};
+    }
+    if (!c.gm_identity) {
+      const f2 t0 = splat(c.gm[0]) * qr + splat(c.gm[1]) * qg + splat(c.gm[2]) * qb;
+      const f2 t1 = splat(c.gm[3]) * qr + splat(c.gm[4]) * qg + splat(c.gm[5]) * qb;
+      const f2 t2 = splat(c.gm[6]) * qr + splat(c.gm[7]) * qg + splat(c.gm[8]) * qb;
+      qr = t0; qg = t1; qb = t2;
+    }
+    const f2 fh = (splat(c.lum_r) * qr + splat(c.lum_g) * qg + splat(c.lum_b) * qb) * splat(c.hdr_white_nits);
+    bool doubt = false;
+    uint32_t fbyte[2], fexact = 0u;
+    float fgain[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float ys = k ? fs.y : fs.x, yh = k ? fh.y : fh.x;
+      const float gf = (ys > 0.0f) ? yh * __builtin_amdgcn_rcpf(ys) : 1.0f;
+      const float gc = __builtin_amdgcn_fmed3f(gf, c.min_boost, c.max_boost);
+      const float v = (__builtin_amdgcn_logf(gc) - c.log2_min) * c.flt_scale;
+      const float fl = __builtin_floorf(v), fr2 = v - fl;
+      const bool lo = gf < c.flt_lo, hi = gf > c.flt_hi;
+      const bool mid = (fr2 >= c.flt_delta) && (fr2 <= 1.0f - c.flt_delta);
+      // luminances below 1e-10 leave the relative-error regime of the fast functions (denormal intermediates)
+      const bool sane = !(ys > 0.0f && ys < 1e-10f) && !(yh != 0.0f && __builtin_fabsf(yh) < 1e-10f);
+      doubt |= !((lo || hi || mid) && sane);
+      fbyte[k] = lo ? c.enc_byte_min : hi ? c.enc_byte_max : (uint32_t)fl;
+      fgain[k] = gf;
+      // the fast and the exact sRGB EOTF are zero for the same inputs only, so "SDR luminance is zero" (gain := 1,
+      // gainmapmath.cpp:531) is decided identically on both paths
+      if (!(ys > 0.0f)) fexact |= 1u << k;
+    }
+#if UHDR_GEN_EXPERIMENT == 3   // filter without fallback
+    doubt = false;
+#endif
+    UHDR_COUNT(0, 1);
+    UHDR_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(doubt)));
+    if (__builtin_amdgcn_ballot_w64(doubt) != 0ull) UHDR_COUNT(1, 1);
+    if (__builtin_amdgcn_ballot_w64(doubt) == 0ull) {
+      out[0] = (uint8_t)fbyte[0]; out[1] = (uint8_t)fbyte[1];
+      gain[0] = fgain[0]; gain[1] = fgain[1];
+      return fexact;
+    }
+  }
   // independent f64 evaluations advanced in lock step: 6 = 3 channels x 2 pixels.  Measured on MI355X
   // (scripts/ab): 6 -> 0.388 ms per 32-frame launch, 3 -> 0.432, 2 -> 0.490 although the narrower forms
   // need fewer VGPRs (98 / 84 / 78): exposed f64 FMA latency costs more than the lost occupancy.
@@ -239,10 +328,7 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
   }
   const f2 sdr_nits = (splat(c.lum_r) * r + splat(c.lum_g) * g + splat(c.lum_b) * b) * splat(203.0f);
 
-  // HDR: YUV->RGB, inverse OETF, gamut conversion, luminance * white (ultrahdr.cpp:326-330)
-  f2 hr = pk_add_sat(hsy, splat(c.hdr_cr) * hsv);
-  f2 hg = pk_add_sat(hsy - splat(c.hdr_gcb) * hsu, -(splat(c.hdr_gcr) * hsv));
-  f2 hb = pk_add_sat(hsy, splat(c.hdr_cb) * hsu);
+  // HDR: inverse OETF, gamut conversion, luminance * white (ultrahdr.cpp:328-330)
   if (TF != 0 && LUT) {  // both HDR tables have 4096 entries (gainmapmath.h:342-343,368-369)
     hr = (f2){s_hdr[lut_index_unit(hr.x, kLutHlgInvN)], s_hdr[lut_index_unit(hr.y, kLutHlgInvN)]};
     hg = (f2){s_hdr[lut_index_unit(hg.x, kLutHlgInvN)], s_hdr[lut_index_unit(hg.y, kLutHlgInvN)]};
@@ -275,11 +361,54 @@ __device__ __forceinline__ void gen_pair(const GenConsts& c, const uint32_t (&hy
   for (int k = 0; k < 2; ++k)
     out[k] = encode_gain_guarded(gain[k], c.min_boost, c.max_boost, c.log2_min, c.log2_max, c.enc_scale, c.enc_byte_min,
                                  c.enc_byte_max);
+  return 3u;
 }
 
+// Frames are read once and outputs written once: the aligned fast paths use non-temporal loads (bit 0) and stores
+// (bit 1) so that 2 GB of apply output do not sit dirty in L2 / Infinity Cache when the next kernel starts reading.
+// Same-box A/B (scripts/ab, 64 x 4K, ms per launch): generate 0.484 -> 0.444 with either bit, 0.394 with both;
+// apply 0.98 -> 0.996.
+#ifndef UHDR_NT
+#define UHDR_NT 3
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+#if UHDR_NT & 1
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ uint2 ld_stream(const uint2* p) {
+#if UHDR_NT & 1
+  const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+  return make_uint2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) {
+#if UHDR_NT & 1
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
+#if UHDR_NT & 2
+  __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p));
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
 __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *p; }
 
+#ifndef UHDR_GEN_EXPERIMENT
+#define UHDR_GEN_EXPERIMENT 0   // 1..3: timing experiments only (scripts/ab), never shipped
+#endif
 #ifndef UHDR_GEN_BLOCK
 #define UHDR_GEN_BLOCK 256
 #endif
@@ -292,41 +421,106 @@ __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *p; }
 #define UHDR_GEN_MINWAVES 1
 #endif
 
-// wave64 butterfly min/max, then one LDS slot per wave, then (rarely) one atomic pair per block
-__device__ __forceinline__ void block_minmax_to_keys(float gmin, float gmax, uint32_t* keys) {
+// inputs of pair `idx` (two horizontally adjacent map pixels = an 8x4 pixel block of both images) -> registers
+template <bool ALIGNED>
+__device__ __forceinline__ void load_pair(const GenConsts& c, const GenImage& im, const uint8_t* im_v, uint32_t my, uint32_t pr,
+                                          bool two, uint32_t (&hy)[2][4][2], uint32_t (&huv)[2][2][2], uint32_t (&y8)[2][4],
+                                          uint32_t (&u8)[2][2], uint32_t (&v8)[2][2]) {
+  const uint32_t mx = pr * 2u;
+  if (ALIGNED) {
+    // 32-bit element offsets (every plane is < 4 GiB on this path): one 64-bit add per address
+    const uint32_t hoff = 4u * my * im.hy_stride + 8u * pr, yoff = 4u * my * im.y_stride + 8u * pr;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    gmin = fminf(gmin, __shfl_xor(gmin, off, 64));
-    gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
-  }
-  constexpr int kWaves = UHDR_GEN_BLOCK / 64;
-  __shared__ float s_min[kWaves], s_max[kWaves];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { s_min[wave] = gmin; s_max[wave] = gmax; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
+    for (int r = 0; r < 4; ++r) {
+      const uint4 q = ld_stream(reinterpret_cast<const uint4*>(im.hy + (hoff + r * im.hy_stride)));
+      hy[0][r][0] = q.x; hy[0][r][1] = q.y; hy[1][r][0] = q.z; hy[1][r][1] = q.w;
+      const uint2 p = ld_stream(reinterpret_cast<const uint2*>(im.y + (yoff + r * im.y_stride)));
+      y8[0][r] = p.x; y8[1][r] = p.y;
+    }
+    const uint32_t huvoff = 2u * my * im.huv_stride + 8u * pr, coff = 2u * my * im.c_stride + 4u * pr;
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) { gmin = fminf(gmin, s_min[w]); gmax = fmaxf(gmax, s_max[w]); }
-    if (gmin <= gmax) {  // block saw at least one pixel
-      // keys[0] holds ~key(min), keys[1] holds key(max); both only grow, both start at 0.
-      const uint32_t kmin = ~float_to_key(gmin), kmax = float_to_key(gmax);
-      // a stale (smaller) value read here only costs an unnecessary atomic, never a lost update
-      if (__hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kmin)
-        atomicMax(&keys[0], kmin);
-      if (__hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kmax)
-        atomicMax(&keys[1], kmax);
+    for (int r = 0; r < 2; ++r) {
+      const uint4 q = ld_stream(reinterpret_cast<const uint4*>(im.huv + (huvoff + r * im.huv_stride)));
+      huv[0][r][0] = q.x; huv[0][r][1] = q.y; huv[1][r][0] = q.z; huv[1][r][1] = q.w;
+      const uint32_t uu = ld_stream(reinterpret_cast<const uint32_t*>(im.u + (coff + r * im.c_stride)));
+      const uint32_t vv = ld_stream(reinterpret_cast<const uint32_t*>(im_v + (coff + r * im.c_stride)));
+      u8[0][r] = uu & 0xffffu; u8[1][r] = uu >> 16;
+      v8[0][r] = vv & 0xffffu; v8[1][r] = vv >> 16;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool on = (k == 0) || two;
+      const uint32_t x0 = 4u * (mx + k);  // first image column of this map pixel
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint16_t* hrow = im.hy + (size_t)(4u * my + r) * im.hy_stride + x0;
+        const uint8_t* yrow = im.y + (size_t)(4u * my + r) * im.y_stride + x0;
+        hy[k][r][0] = on ? (ld16(hrow) | (ld16(hrow + 1) << 16)) : 0u;
+        hy[k][r][1] = on ? (ld16(hrow + 2) | (ld16(hrow + 3) << 16)) : 0u;
+        y8[k][r] = on ? (ld8(yrow) | (ld8(yrow + 1) << 8) | (ld8(yrow + 2) << 16) | (ld8(yrow + 3) << 24)) : 0u;
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const uint16_t* crow = im.huv + (size_t)(2u * my + r) * im.huv_stride + x0;  // (x & ~1)
+        const uint8_t* urow = im.u + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
+        const uint8_t* vrow = im_v + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
+        huv[k][r][0] = on ? (ld16(crow) | (ld16(crow + 1) << 16)) : 0u;
+        huv[k][r][1] = on ? (ld16(crow + 2) | (ld16(crow + 3) << 16)) : 0u;
+        u8[k][r] = on ? (ld8(urow) | (ld8(urow + 1) << 8)) : 0u;
+        v8[k][r] = on ? (ld8(vrow) | (ld8(vrow + 1) << 8)) : 0u;
+      }
     }
   }
 }
 
+// wave64 butterfly: every lane ends up with the wave's min / max
+__device__ __forceinline__ void wave_minmax(float& vmin, float& vmax) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    vmin = fminf(vmin, __shfl_xor(vmin, off, 64));
+    vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+  }
+}
+// one lane per wave publishes; keys[0] holds ~key(min), keys[1] holds key(max); both only grow, both start at 0
+__device__ __forceinline__ void publish_minmax(float gmin, float gmax, uint32_t* keys) {
+  if ((threadIdx.x & 63u) == 0u && gmin <= gmax) {  // wave saw at least one pixel
+    const uint32_t kmin = ~float_to_key(gmin), kmax = float_to_key(gmax);
+    // a stale (smaller) value read here only costs an unnecessary atomic, never a lost update
+    if (__hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kmin) atomicMax(&keys[0], kmin);
+    if (__hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kmax) atomicMax(&keys[1], kmax);
+  }
+}
+
+// exact unclamped gains of pair (my, pr): the statistics pass re-evaluates a handful of pixels with this
+// (inlined: as an out-of-line call it needs 168 VGPRs and 3.7 KB of scratch for the argument arrays)
+template <int TF, bool ALIGNED, bool LUT>
+__device__ __forceinline__ void exact_pair_gains(const GenConsts& c, const GenImage& im, const uint8_t* im_v, uint32_t my,
+                                                 uint32_t pr, bool two, const float* s_srgb, const float* s_hdr, float (&gn)[2]) {
+  uint32_t hy[2][4][2], huv[2][2][2], y8[2][4], u8[2][2], v8[2][2];
+  load_pair<ALIGNED>(c, im, im_v, my, pr, two, hy, huv, y8, u8, v8);
+  uint8_t o[2];
+  gen_pair<TF, LUT, false>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);
+}
+
+// relative distance within which a filter estimate may sit from the exact gain (kRel of generate_consts, doubled)
+constexpr float kGainRelErr = 8.0e-6f;
+
 // Thread = 2 horizontally adjacent map pixels = an 8x4 pixel block of both images.
 // A wave64 therefore consumes 1 KiB contiguous per P010 row (dwordx4/lane), 512 B per 8-bit luma
 // row (dwordx2/lane) and 256 B per chroma row (dword/lane).
-template <int TF, bool ALIGNED, bool LUT>
+//
+// Statistics (content min / max of the unclamped gain) stay EXACT under the filter: every thread keeps the gains of its
+// pixels with an "exact" bit; when a wave has finished its tiles, only pixels whose estimate could be the wave's exact
+// extreme -- and could still beat the extreme already published for the image -- are re-evaluated on the exact path
+// (typically none).  Waves never wait for each other: a block-wide reduction here measured +25 % on the whole kernel,
+// because one wave in seven takes the exact path in some tile and its three siblings would idle at the barrier.
+template <int TF, bool ALIGNED, bool LUT, bool FILTER>
 __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(const GenConsts c, const GenBatch b) {
   // LUT mode: block-private copies of the two tables (4 KiB + 16 KiB), so every lookup is an LDS gather
   __shared__ float s_srgb[LUT ? kLutSrgbInvN : 1];
   __shared__ float s_hdr[(LUT && TF != 0) ? kLutHlgInvN : 1];
+  __shared__ float s_kept[FILTER ? UHDR_GEN_TILES * 2 * UHDR_GEN_BLOCK : 1];  // FILTER: every thread's gains, for the candidate pass
   if (LUT) {
     for (uint32_t i = threadIdx.x; i < kLutSrgbInvN / 4u; i += UHDR_GEN_BLOCK)
       reinterpret_cast<float4*>(s_srgb)[i] = reinterpret_cast<const float4*>(c.lut + kLutSrgbInv)[i];
@@ -336,17 +530,23 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
     }
     __syncthreads();
   }
-  const GenImage& im = b.img[blockIdx.y];
+  // consecutive workgroups belong to different images (grid.x = image): the images of a launch progress together, so
+  // the extremes a finished wave publishes prune the statistics candidates of the image's later waves
+  const uint32_t img_i = blockIdx.x, blk = blockIdx.y;
+  const GenImage& im = b.img[img_i];
   const uint8_t* im_v = im.u + (size_t)im.c_stride * (c.height / 2u);
   const uint32_t pairs_per_row = (c.map_w + 1u) >> 1;
   const uint32_t total = pairs_per_row * c.map_h;
-  float gmin = __builtin_inff(), gmax = -__builtin_inff();
+  const bool stats = c.stat_keys != nullptr;
+  float emin = __builtin_inff(), emax = -__builtin_inff();   // over gains known exactly
+  float amin = __builtin_inff(), amax = -__builtin_inff();   // over all gains (estimates included)
+  uint32_t kept_exact = 0u, kept_valid = 0u;                 // 2 bits per tile
 
   // each block walks UHDR_GEN_TILES consecutive spans of UHDR_GEN_BLOCK pairs: fewer, longer-lived waves
   // (wave launch + descriptor fetch is a measurable share of a ~10 us wave)
 #pragma unroll 1
   for (uint32_t t = 0; t < (uint32_t)UHDR_GEN_TILES; ++t) {
-    const uint32_t idx = (blockIdx.x * (uint32_t)UHDR_GEN_TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
+    const uint32_t idx = (blk * (uint32_t)UHDR_GEN_TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
     if (idx >= total) break;
     const uint32_t my = idx / pairs_per_row;
     const uint32_t pr = idx - my * pairs_per_row;
@@ -354,58 +554,28 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
     const bool two = ALIGNED || (mx + 1u < c.map_w);
 
     uint32_t hy[2][4][2], huv[2][2][2], y8[2][4], u8[2][2], v8[2][2];
-    if (ALIGNED) {
-      // 32-bit element offsets (every plane is < 4 GiB on this path): one 64-bit add per address
-      const uint32_t hoff = 4u * my * im.hy_stride + 8u * pr, yoff = 4u * my * im.y_stride + 8u * pr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint4 q = *reinterpret_cast<const uint4*>(im.hy + (hoff + r * im.hy_stride));
-        hy[0][r][0] = q.x; hy[0][r][1] = q.y; hy[1][r][0] = q.z; hy[1][r][1] = q.w;
-        const uint2 p = *reinterpret_cast<const uint2*>(im.y + (yoff + r * im.y_stride));
-        y8[0][r] = p.x; y8[1][r] = p.y;
-      }
-      const uint32_t huvoff = 2u * my * im.huv_stride + 8u * pr, coff = 2u * my * im.c_stride + 4u * pr;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const uint4 q = *reinterpret_cast<const uint4*>(im.huv + (huvoff + r * im.huv_stride));
-        huv[0][r][0] = q.x; huv[0][r][1] = q.y; huv[1][r][0] = q.z; huv[1][r][1] = q.w;
-        const uint32_t uu = *reinterpret_cast<const uint32_t*>(im.u + (coff + r * im.c_stride));
-        const uint32_t vv = *reinterpret_cast<const uint32_t*>(im_v + (coff + r * im.c_stride));
-        u8[0][r] = uu & 0xffffu; u8[1][r] = uu >> 16;
-        v8[0][r] = vv & 0xffffu; v8[1][r] = vv >> 16;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const bool on = (k == 0) || two;
-        const uint32_t x0 = 4u * (mx + k);  // first image column of this map pixel
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint16_t* hrow = im.hy + (size_t)(4u * my + r) * im.hy_stride + x0;
-          const uint8_t* yrow = im.y + (size_t)(4u * my + r) * im.y_stride + x0;
-          hy[k][r][0] = on ? (ld16(hrow) | (ld16(hrow + 1) << 16)) : 0u;
-          hy[k][r][1] = on ? (ld16(hrow + 2) | (ld16(hrow + 3) << 16)) : 0u;
-          y8[k][r] = on ? (ld8(yrow) | (ld8(yrow + 1) << 8) | (ld8(yrow + 2) << 16) | (ld8(yrow + 3) << 24)) : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const uint16_t* crow = im.huv + (size_t)(2u * my + r) * im.huv_stride + x0;  // (x & ~1)
-          const uint8_t* urow = im.u + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
-          const uint8_t* vrow = im_v + (size_t)(2u * my + r) * im.c_stride + (x0 >> 1);
-          huv[k][r][0] = on ? (ld16(crow) | (ld16(crow + 1) << 16)) : 0u;
-          huv[k][r][1] = on ? (ld16(crow + 2) | (ld16(crow + 3) << 16)) : 0u;
-          u8[k][r] = on ? (ld8(urow) | (ld8(urow + 1) << 8)) : 0u;
-          v8[k][r] = on ? (ld8(vrow) | (ld8(vrow + 1) << 8)) : 0u;
-        }
-      }
-    }
+    load_pair<ALIGNED>(c, im, im_v, my, pr, two, hy, huv, y8, u8, v8);
 
     uint8_t o[2];
     float gn[2];
-    gen_pair<TF, LUT>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);   // a missing second pixel is computed on zeros and dropped
+    // a missing second pixel is computed on zeros and dropped
+    const uint32_t ex = gen_pair<TF, LUT, FILTER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);
     const uint8_t o0 = o[0], o1 = o[1];
-    gmin = fminf(gmin, gn[0]); gmax = fmaxf(gmax, gn[0]);
-    if (two) { gmin = fminf(gmin, gn[1]); gmax = fmaxf(gmax, gn[1]); }
+    if (FILTER) {
+      if (stats) {
+        s_kept[(2u * t) * UHDR_GEN_BLOCK + threadIdx.x] = gn[0];
+        s_kept[(2u * t + 1u) * UHDR_GEN_BLOCK + threadIdx.x] = gn[1];
+      }
+      kept_exact |= ex << (2u * t);
+      kept_valid |= (two ? 3u : 1u) << (2u * t);
+      amin = fminf(amin, gn[0]); amax = fmaxf(amax, gn[0]);
+      if (two) { amin = fminf(amin, gn[1]); amax = fmaxf(amax, gn[1]); }
+      if (ex & 1u) { emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]); }
+      if (two && (ex & 2u)) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
+    } else {
+      emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]);
+      if (two) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
+    }
     uint8_t* mp = im.map + (size_t)my * c.map_w + mx;
     if (ALIGNED) {
       *reinterpret_cast<uint16_t*>(mp) = (uint16_t)(o0 | ((uint32_t)o1 << 8));
@@ -414,7 +584,52 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
       if (two) mp[1] = o1;
     }
   }
-  if (c.stat_keys != nullptr) block_minmax_to_keys(gmin, gmax, c.stat_keys + 2u * blockIdx.y);
+  if (!stats) return;
+  uint32_t* keys = c.stat_keys + 2u * img_i;
+
+  if (FILTER) {
+    // which estimates could be this wave's exact minimum / maximum, and could still move the image's extreme?
+    const uint32_t k0 = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k1 = __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wave_minmax(amin, amax);
+    float wmin = emin, wmax = emax;          // what this wave already knows exactly (tiles that took the exact path)
+    wave_minmax(wmin, wmax);
+    const float pub_min = fminf(k1 != 0u ? key_to_float(~k0) : __builtin_inff(), wmin);   // exact values only
+    const float pub_max = fmaxf(k1 != 0u ? key_to_float(k1) : -__builtin_inff(), wmax);
+    const float e = kGainRelErr;
+    const float min_hi = fminf(amin + e * __builtin_fabsf(amin), pub_min);   // an exact minimum cannot lie above this
+    const float max_lo = fmaxf(amax - e * __builtin_fabsf(amax), pub_max);
+    uint32_t cand = 0u;                      // one bit per tile of this lane
+#pragma unroll
+    for (uint32_t t = 0; t < (uint32_t)UHDR_GEN_TILES; ++t)
+#pragma unroll
+      for (uint32_t k = 0; k < 2u; ++k) {
+        const uint32_t bit = 1u << (2u * t + k);
+        if ((kept_valid & bit) && !(kept_exact & bit)) {
+          const float a = s_kept[(2u * t + k) * UHDR_GEN_BLOCK + threadIdx.x], slack = e * __builtin_fabsf(a);
+          if ((a - slack <= min_hi) || (a + slack >= max_lo)) cand |= 1u << t;
+        }
+      }
+    // every pass lets each lane re-evaluate one of its candidate pairs (lanes may sit in different tiles), so the
+    // usual "one minimum, one maximum" costs one exact pass; flat content degrades to redoing the wave's tiles
+#pragma unroll 1
+    while (__builtin_amdgcn_ballot_w64(cand != 0u) != 0ull) {
+      UHDR_COUNT(2, 1);
+      if (cand != 0u) {
+        const uint32_t t = (uint32_t)__builtin_ctz(cand);
+        cand &= cand - 1u;
+        const uint32_t idx = (blk * (uint32_t)UHDR_GEN_TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
+        const uint32_t my = idx / pairs_per_row, pr = idx - my * pairs_per_row;
+        const bool two = ALIGNED || (pr * 2u + 1u < c.map_w);
+        float gn[2];
+        exact_pair_gains<TF, ALIGNED, LUT>(c, im, im_v, my, pr, two, s_srgb, s_hdr, gn);
+        emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]);
+        if (two) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
+      }
+    }
+  }
+  wave_minmax(emin, emax);
+  publish_minmax(emin, emax, keys);
 }
 
 __global__ void k_stats_finalize(uint32_t* keys, int n) {
@@ -427,28 +642,30 @@ __global__ void k_stats_finalize(uint32_t* keys, int n) {
   keys[2 * i + 1] = __float_as_uint(mx);
 }
 
-template <int TF, bool ALIGNED, bool LUT>
+template <int TF, bool ALIGNED, bool LUT, bool FILTER>
 static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   if (total == 0 || n == 0) return hipSuccess;
   constexpr uint32_t kSpan = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
-  dim3 grid((total + kSpan - 1u) / kSpan, (unsigned)n, 1), block(UHDR_GEN_BLOCK, 1, 1);
-  hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT>), grid, block, 0, s, c, b);
+  dim3 grid((unsigned)n, (total + kSpan - 1u) / kSpan, 1), block(UHDR_GEN_BLOCK, 1, 1);
+  hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER>), grid, block, 0, s, c, b);
   return hipGetLastError();
 }
 
 template <int TF>
-static hipError_t launch_generate_tf(const GenConsts& c, const GenBatch& b, int n, bool aligned, bool lut, hipStream_t s) {
-  if (lut) return aligned ? launch_generate_t<TF, true, true>(c, b, n, s) : launch_generate_t<TF, false, true>(c, b, n, s);
-  return aligned ? launch_generate_t<TF, true, false>(c, b, n, s) : launch_generate_t<TF, false, false>(c, b, n, s);
+static hipError_t launch_generate_tf(const GenConsts& c, const GenBatch& b, int n, bool aligned, bool lut, bool filter,
+                                     hipStream_t s) {
+  if (lut) return aligned ? launch_generate_t<TF, true, true, false>(c, b, n, s) : launch_generate_t<TF, false, true, false>(c, b, n, s);
+  if (filter && TF != 2 && aligned) return launch_generate_t<TF, true, false, true>(c, b, n, s);
+  return aligned ? launch_generate_t<TF, true, false, false>(c, b, n, s) : launch_generate_t<TF, false, false, false>(c, b, n, s);
 }
 hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, bool lut,
-                           hipStream_t s) {
+                           bool filter, hipStream_t s) {
   if (lut && c.lut == nullptr) return hipErrorInvalidValue;
   switch (hdr_tf) {
-    case 0: return launch_generate_tf<0>(c, b, n, aligned, lut, s);
-    case 1: return launch_generate_tf<1>(c, b, n, aligned, lut, s);
-    case 2: return launch_generate_tf<2>(c, b, n, aligned, lut, s);
+    case 0: return launch_generate_tf<0>(c, b, n, aligned, lut, filter, s);
+    case 1: return launch_generate_tf<1>(c, b, n, aligned, lut, filter, s);
+    case 2: return launch_generate_tf<2>(c, b, n, aligned, lut, filter, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -666,7 +883,7 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
       uint4 o;
       o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
       o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
-      *reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0) = o;
+      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), o);
     } else if (FMT == 1) {
       const uint2 a = pack_f16(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16(po[0].r.y, po[0].g.y, po[0].b.y);
       const uint2 cc = pack_f16(po[1].r.x, po[1].g.x, po[1].b.x), d = pack_f16(po[1].r.y, po[1].g.y, po[1].b.y);
@@ -700,7 +917,7 @@ __global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBa
   uint32_t yrow[4];
   const uint32_t yoff = 4u * cy * im.y_stride + 4u * cx;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) yrow[r] = *reinterpret_cast<const uint32_t*>(im.y + (yoff + r * im.y_stride));
+  for (int r = 0; r < 4; ++r) yrow[r] = ld_stream(reinterpret_cast<const uint32_t*>(im.y + (yoff + r * im.y_stride)));
   uint32_t uu[2], vv[2];
   const uint32_t coff = 2u * cy * im.c_stride + 2u * cx;
 #pragma unroll
@@ -1146,6 +1363,8 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 24: y = hlg_oetf_fast(x); break;
     case 25: y = pq_oetf_fast(x); break;
     case 20: y = srgb_inv_oetf_fast(x); break;
+    case 21: y = hlg_inv_oetf_fast(x); break;
+    case 23: y = __builtin_amdgcn_logf(x); break;
     // the reference's LUT accessors over the device tables; 46: GainLUT(min, max, displayBoost = max).getGainFactor
     case 40: y = ec.lut[kLutSrgbInv + lut_index(x, kLutSrgbInvN)]; break;
     case 41: y = ec.lut[kLutHlgInv + lut_index(x, kLutHlgInvN)]; break;

@@ -91,14 +91,17 @@ class UltraHdrHip {
   status_t convertYuv(uhdr_uncompressed_ptr image, ultrahdr_color_gamut src_encoding,
                       ultrahdr_color_gamut dest_encoding);
 
-  // UHDR_HIP_APPLY_FAST (default) or UHDR_HIP_APPLY_EXACT, see include/uhdr_hip.h
+  // UHDR_HIP_APPLY_FAST (default), UHDR_HIP_APPLY_EXACT or UHDR_HIP_APPLY_LUT, see include/uhdr_hip.h
   void setApplyMode(int mode) { mApplyMode = mode; }
+  // UHDR_HIP_GENERATE_EXACT (default), UHDR_HIP_GENERATE_LUT or UHDR_HIP_GENERATE_UNFILTERED
+  void setGenerateMode(int mode) { mGenerateMode = mode; }
 
  private:
   status_t ensureInit();
   int mDevice;
   bool mReady = false;
   int mApplyMode = 0;
+  int mGenerateMode = 0;
 };
 
 // ---- editing effects: the free functions of lib/include/ultrahdr/editorhelper.h:49-63, same signatures ----------

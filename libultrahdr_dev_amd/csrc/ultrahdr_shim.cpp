@@ -85,8 +85,8 @@ status_t UltraHdrHip::generateGainMap(uhdr_uncompressed_ptr yuv420_image_ptr, uh
   d.data = map_data.get();
   uhdr_hip_metadata_t md;
   std::memset(&md, 0, sizeof(md));
-  const int rc = uhdr_hip_generate_gainmap(&y, &p, static_cast<int>(hdr_tf), &md, &d, sdr_is_601 ? 1 : 0,
-                                           UHDR_HIP_MEM_HOST, nullptr);
+  const int rc = uhdr_hip_generate_gainmap_ex(&y, &p, static_cast<int>(hdr_tf), &md, &d, sdr_is_601 ? 1 : 0,
+                                              mGenerateMode, UHDR_HIP_MEM_HOST, nullptr);
   if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
   metadata->version = md.version;
   metadata->maxContentBoost = md.maxContentBoost;

@@ -1,0 +1,97 @@
+/*
+ * jpeg_libjpeg_harness.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Drives the libjpeg that ships in the image (/opt/conda: IJG libjpeg 9d) with the call sequence of the reference's
+ * JpegEncoderHelper (lib/src/jpegencoderhelper.cpp:86-283), so that oracle/jpeg_oracle.c can be pinned against a real
+ * libjpeg.  The reference's own helper does not compile against these headers (`return true;` from a function
+ * returning libjpeg's `boolean`, an enum in IJG 9; it is written for libjpeg-turbo, where `boolean` is an int), and
+ * no libjpeg-turbo headers exist in the image, so the sequence is restated in C here:
+ *   jpeg_set_defaults, jpeg_set_quality(q, TRUE), raw_data_in, JDCT_ISLOW, sampling 2x2/1x1/1x1 or 1x1   (:119-136)
+ *   optional APP2 marker right after jpeg_start_compress                                                (:97-100)
+ *   16 luma + 8 chroma rows (or 8 rows of one plane) per jpeg_write_raw_data; rows past the height are one zero row;
+ *   rows are copied into zero-padded buffers only when the stride is smaller than the 16-aligned width   (:138-283)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <jpeglib.h>
+
+#define BATCH 16
+#define ALIGNM(x, m) ((((x) + ((m)-1)) / (m)) * (m))
+
+long lj_jpeg_encode(const unsigned char* y, const unsigned char* uv, int w, int h, int ls, int cs, int quality,
+                    const void* icc, unsigned icc_n, unsigned char* out, long cap) {
+  struct jpeg_compress_struct c;
+  struct jpeg_error_mgr e;
+  c.err = jpeg_std_error(&e);
+  jpeg_create_compress(&c);
+  unsigned char* mem = NULL;
+  unsigned long memsz = 0;
+  jpeg_mem_dest(&c, &mem, &memsz);
+  const int gray = uv == NULL;
+  c.image_width = w;
+  c.image_height = h;
+  c.input_components = gray ? 1 : 3;
+  c.in_color_space = gray ? JCS_GRAYSCALE : JCS_YCbCr;
+  jpeg_set_defaults(&c);
+  jpeg_set_quality(&c, quality, TRUE);
+  c.raw_data_in = TRUE;
+  c.dct_method = JDCT_ISLOW;
+  c.comp_info[0].h_samp_factor = gray ? 1 : 2;
+  c.comp_info[0].v_samp_factor = gray ? 1 : 2;
+  for (int i = 1; i < c.num_components; i++) {
+    c.comp_info[i].h_samp_factor = 1;
+    c.comp_info[i].v_samp_factor = 1;
+  }
+  jpeg_start_compress(&c, TRUE);
+  if (icc != NULL && icc_n > 0) jpeg_write_marker(&c, JPEG_APP0 + 2, (const JOCTET*)icc, icc_n);
+
+  const int aw = ALIGNM(w, BATCH), acw = ALIGNM(w / 2, BATCH / 2);
+  const int pad_y = ls < aw, pad_c = cs < acw;
+  unsigned char* empty = (unsigned char*)calloc(aw, 1);
+  unsigned char* ybuf = (unsigned char*)calloc((size_t)aw * BATCH, 1);
+  unsigned char* cbbuf = (unsigned char*)calloc((size_t)acw * BATCH / 2 + 1, 1);
+  unsigned char* crbuf = (unsigned char*)calloc((size_t)acw * BATCH / 2 + 1, 1);
+  JSAMPROW yr[BATCH], cbr[BATCH / 2], crr[BATCH / 2];
+  JSAMPARRAY planes[3] = {yr, cbr, crr};
+  const unsigned char* u = uv;
+  const unsigned char* v = uv ? uv + (size_t)cs * h / 2 : NULL;
+  while (c.next_scanline < c.image_height) {
+    for (int i = 0; i < BATCH; i++) {
+      size_t sl = c.next_scanline + i;
+      if (sl < (size_t)h) {
+        yr[i] = (JSAMPROW)(y + sl * ls);
+        if (pad_y) {
+          memcpy(ybuf + (size_t)i * aw, yr[i], w);
+          yr[i] = ybuf + (size_t)i * aw;
+        }
+      } else {
+        yr[i] = empty;
+      }
+    }
+    if (!gray)
+      for (int i = 0; i < BATCH / 2; i++) {
+        size_t sl = c.next_scanline / 2 + i;
+        if (sl < (size_t)h / 2) {
+          cbr[i] = (JSAMPROW)(u + sl * cs);
+          crr[i] = (JSAMPROW)(v + sl * cs);
+          if (pad_c) {
+            memcpy(cbbuf + (size_t)i * acw, cbr[i], w / 2);
+            cbr[i] = cbbuf + (size_t)i * acw;
+            memcpy(crbuf + (size_t)i * acw, crr[i], w / 2);
+            crr[i] = crbuf + (size_t)i * acw;
+          }
+        } else {
+          cbr[i] = crr[i] = empty;
+        }
+      }
+    jpeg_write_raw_data(&c, planes, BATCH);
+  }
+  jpeg_finish_compress(&c);
+  jpeg_destroy_compress(&c);
+  const long n = (long)memsz;
+  if (n <= cap) memcpy(out, mem, n);
+  free(mem); free(empty); free(ybuf); free(cbbuf); free(crbuf);
+  return n;
+}

@@ -92,6 +92,11 @@ def _declare(lib, p):
         d("checksum_u8", C.c_uint64, C.c_void_p, sz)
         d("checksum_u32", C.c_uint64, C.c_void_p, sz)
         d("eval_transfer", None, i32, C.c_void_p, C.c_void_p, sz, f32, f32)
+        d("jpeg_encode", C.c_long, C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, C.c_void_p, C.c_uint, C.c_void_p, C.c_long)
+        d("jpeg_header", C.c_long, i32, i32, i32, i32, C.c_void_p, C.c_uint, C.c_void_p, C.c_long)
+        d("jpeg_block_count", C.c_long, i32, i32, i32)
+        d("jpeg_coefficients", C.c_long, C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, C.c_void_p)
+        d("jpeg_quant_table", None, i32, i32, C.c_void_p)
         d("lut_table", C.POINTER(f32), i32, C.POINTER(sz))
         d("gainLutFactor", f32, C.POINTER(f32), f32)
         d("applyGainLUT", Color, Color, f32, C.POINTER(f32))
@@ -127,6 +132,56 @@ def load_ref():
             build(ref=True)
         _cache["ref"] = _declare(C.CDLL(path), "ref_") if os.path.exists(path) else None
     return _cache["ref"]
+
+
+def load_libjpeg():
+    """the image's libjpeg behind the reference's JpegEncoderHelper call sequence (oracle/jpeg_libjpeg_harness.c),
+    or None where it cannot be built (no libjpeg)"""
+    if "lj" not in _cache:
+        path = os.path.join(_HERE, "libjpeg_harness.so")
+        if not os.path.exists(path):
+            try:
+                subprocess.check_call(["make", "-s", "-C", _HERE, "jpeg"], stderr=subprocess.DEVNULL)
+            except (subprocess.CalledProcessError, OSError):
+                pass
+        lib = None
+        if os.path.exists(path):
+            try:
+                lib = C.CDLL(path)
+                lib.lj_jpeg_encode.restype = C.c_long
+                lib.lj_jpeg_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_uint, C.c_void_p, C.c_long]
+            except OSError:
+                lib = None
+        _cache["lj"] = lib
+    return _cache["lj"]
+
+
+def jpeg_encode(which, y, uv, w, h, quality, luma_stride=None, chroma_stride=None, icc=None):
+    """JpegEncoderHelper::compressImage through the oracle ("orc") or the image's libjpeg ("lj"); y: uint8 array holding
+    the luma plane, uv: uint8 array holding U then V (V at chroma_stride*h/2) or None for a single plane -> bytes"""
+    fn = load().orc_jpeg_encode if which == "orc" else load_libjpeg().lj_jpeg_encode
+    ls = w if luma_stride is None else luma_stride
+    cs = (w // 2 if chroma_stride is None else chroma_stride) if uv is not None else 0
+    iccb = None if icc is None else np.frombuffer(icc, np.uint8)
+    cap = 1 << 16
+    while True:
+        out = np.empty(cap, np.uint8)
+        n = fn(y.ctypes.data, None if uv is None else uv.ctypes.data, w, h, ls, cs, quality,
+               None if iccb is None else iccb.ctypes.data, 0 if iccb is None else iccb.size, out.ctypes.data, cap)
+        if n <= cap:
+            return out[:max(n, 0)].tobytes() if n >= 0 else None
+        cap = int(n) + 16
+
+
+def jpeg_coefficients(y, uv, w, h, quality, luma_stride=None, chroma_stride=None):
+    lib = load()
+    n = lib.orc_jpeg_block_count(w, h, 1 if uv is None else 0)
+    coef = np.empty((n, 64), np.int16)
+    ls = w if luma_stride is None else luma_stride
+    cs = (w // 2 if chroma_stride is None else chroma_stride) if uv is not None else 0
+    lib.orc_jpeg_coefficients(y.ctypes.data, None if uv is None else uv.ctypes.data, w, h, ls, cs, quality, coef.ctypes.data)
+    return coef
 
 
 # ------------------------------------------------------------------ numpy-level helpers

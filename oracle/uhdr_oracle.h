@@ -127,6 +127,19 @@ int orc_mirror(const orc_image* in, int dir, orc_image* out);
 int orc_rotate(const orc_image* in, int clockwise_degree, orc_image* out);
 int orc_resize(const orc_image* in, int out_width, int out_height, orc_image* out);
 
+/* ---- JPEG compression of the path's outputs (jpeg_oracle.c; SURVEY 8(f) rank 1, encode side) ----
+ * JpegEncoderHelper::compressImage (lib/src/jpegencoderhelper.cpp:39-283): uv == NULL compresses one 8-bit plane
+ * (the gain map), otherwise YUV 4:2:0 planar with V at uv + cs*h/2.  Returns the size of the JPEG; at most cap bytes
+ * are written. */
+long orc_jpeg_encode(const uint8_t* y, const uint8_t* uv, int w, int h, int ls, int cs, int quality,
+                     const void* icc, unsigned icc_n, uint8_t* out, long cap);
+long orc_jpeg_header(int w, int h, int gray, int quality, const void* icc, unsigned icc_n, uint8_t* out, long cap);
+long orc_jpeg_block_count(int w, int h, int gray);
+/* quantised coefficients (natural order) of every block in entropy-coding order, dummy edge blocks included */
+long orc_jpeg_coefficients(const uint8_t* y, const uint8_t* uv, int w, int h, int ls, int cs, int quality, int16_t* coef);
+void orc_jpeg_quant_table(int quality, int chroma, uint16_t out[64]);
+void orc_jpeg_fdct_quant(const uint8_t samples[64], const uint16_t quant[64], int16_t coef[64]);
+
 /* fn: 0 srgbInvOetf 1 hlgInvOetf 2 pqInvOetf 3 encodeGain(y_sdr=1,y_hdr=x) 4 hlgOetf 5 pqOetf;
  * 40/41/42/44/45 the LUT accessors of fn 0/1/2/4/5; 46 GainLUT(min,max,displayBoost=max).getGainFactor */
 void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost);

@@ -185,6 +185,25 @@ def other_configs(lib, stream):
                                     ("resize to 1920x1080", lib.uhdr_hip_resize, (1920, 1080), 1920 * 1080 * 3 // 2)):
         ms = timed(lambda: fn(C.byref(fin), *fargs, C.byref(fo), api.MEM_DEVICE, stream), 10)
         out["4K YUV420 " + name] = {"ms": round(ms, 4), "GB/s (bytes written + bytes they come from)": round(2 * obytes / (ms * 1e-3) / 1e9, 1)}
+    # SURVEY 8(f) rank 1, encode side: JpegEncoderHelper::compressImage on the device (FDCT + quantisation + Huffman + byte
+    # stuffing), device planes in, device bytes out; the call ends with one stream synchronisation (it returns the size)
+    sm = synth.smooth_frame(W, H, 77) if hasattr(synth, "smooth_frame") else None
+    src = sm[1] if sm is not None else y
+    jout = torch.zeros(W * H * 2, dtype=torch.uint8, device="cuda")
+    jn = C.c_size_t()
+    jimg = api.Image(src.data_ptr(), W, H, api.CG_BT709, src.data_ptr() + W * H, W, W // 2, api.PIX_FMT_YUV420)
+    gimg = api.Image(m.data_ptr(), W // 4, H // 4, api.CG_UNSPECIFIED, None, W // 4, 0, api.PIX_FMT_MONOCHROME)
+    for name, img, q, px in (("4K YUV420 q95", jimg, 95, W * H), ("960x540 gain map q85", gimg, 85, W * H // 16)):
+        def enc():
+            assert lib.uhdr_hip_jpeg_encode(C.byref(img), q, None, 0, C.c_void_p(jout.data_ptr()), jout.numel(), C.byref(jn), api.MEM_DEVICE, stream) == 0
+        for _ in range(3):
+            enc()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            enc()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        out["JPEG encode " + name + (" (smooth synthetic content)" if sm is not None else " (LCG noise)")] = {
+            "ms": round(ms, 3), "MPix/s": round(px / 1e6 / (ms * 1e-3), 1), "jpeg_bytes": int(jn.value)}
     # configs[4]: 7680x4320 decode-side apply
     w8, h8 = 7680, 4320
     _, y8 = synth.lcg_frame(w8, h8, 1234)
@@ -239,7 +258,24 @@ def cpu_baseline(batch, fmt, nframes):
             ndiff += int((d != 0).sum())
             nch += d.size
     mpix = W * H / 1e6
+    # the next step of the reference's encode path on the CPU: libjpeg (the image's build behind the reference's call
+    # sequence, one thread) on the smooth synthetic 4K frame other_configs times on the GPU; bytes cross-checked
+    jpeg = None
+    if O.load_libjpeg() is not None:
+        _, sm = synth.smooth_frame(W, H, 77)
+        hsm = sm.cpu().numpy()
+        t0 = time.perf_counter()
+        data = O.jpeg_encode("lj", hsm[:W * H], hsm[W * H:], W, H, 95)
+        t_cpu = time.perf_counter() - t0
+        jout = torch.zeros(W * H * 2, dtype=torch.uint8, device="cuda")
+        jn = C.c_size_t()
+        jimg = api.Image(sm.data_ptr(), W, H, api.CG_BT709, sm.data_ptr() + W * H, W, W // 2, api.PIX_FMT_YUV420)
+        rc = batch.lib.uhdr_hip_jpeg_encode(C.byref(jimg), 95, None, 0, C.c_void_p(jout.data_ptr()), jout.numel(), C.byref(jn), api.MEM_DEVICE, None)
+        same = rc == 0 and jn.value == len(data) and jout[:jn.value].cpu().numpy().tobytes() == data
+        jpeg = {"libjpeg_4k_yuv420_q95_ms": round(t_cpu * 1e3, 2), "MPix/s": round(mpix / t_cpu, 1), "bytes": len(data), "threads": 1,
+                "gpu_bytes_identical": bool(same)}
     return {
+        "jpeg_encode_cpu": jpeg,
         "value": round(nframes * mpix / (t_gen + t_app), 3), "unit": "MPix/s", "cores": ncpu, "kind": "port",
         "sample": "%d of the batch's 4K frames, generate+apply(%s), oracle/uhdr_oracle.c -O2 -ffp-contract=off, "
                   "%d row-band threads" % (nframes, "HLG" if fmt == api.OUTPUT_HDR_HLG else "PQ", ncpu),

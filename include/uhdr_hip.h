@@ -193,6 +193,19 @@ int uhdr_hip_rotate(const uhdr_hip_image_t* in_img, int clockwise_degree, uhdr_h
 int uhdr_hip_resize(const uhdr_hip_image_t* in_img, int out_width, int out_height, uhdr_hip_image_t* out_img,
                     int mem_space, void* stream);
 
+/* ---- JPEG compression of the path's outputs (encode side) -------------------------------
+ * JpegEncoderHelper::compressImage (lib/src/jpegencoderhelper.cpp:39-283; lib/include/ultrahdr/jpegencoderhelper.h:43-60):
+ * baseline JPEG of a YUV420 image (image->data = Y, image->chroma_data = U, V at chroma_stride * height / 2) or, when
+ * image->pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME, of the single plane image->data -- the bytes libjpeg writes in
+ * raw-data mode with default tables, jpeg_set_quality(quality, TRUE) and the ISLOW DCT, including the reference's padding
+ * rules (rows past the height are zero; columns past the width are zero when the stride is smaller than the 16-aligned
+ * width, the caller's bytes otherwise).  icc (HOST memory, may be NULL) becomes an APP2 segment after the JFIF header.
+ * FDCT, quantisation, Huffman coding and byte stuffing all run on the device.  out (capacity out_capacity) lives in the
+ * memory space given by mem_space like the image planes; *out_size (HOST) receives the JPEG size.  The call waits for
+ * the stream.  Returns ERROR_INSUFFICIENT_RESOURCE with *out_size set when out_capacity is too small. */
+int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void* icc, size_t icc_size, void* out,
+                         size_t out_capacity, size_t* out_size, int mem_space, void* stream);
+
 /* ---- batches (device memory only, asynchronous on `stream`) ------------------------------ */
 /* The reference processes one image per call; a batch is n independent calls with identical
  * (hdr_tf, sdr_is_601 | metadata, output_format, max_display_boost).  Images of equal size share

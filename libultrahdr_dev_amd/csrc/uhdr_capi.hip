@@ -14,6 +14,7 @@
 
 #include "../../include/uhdr_hip.h"
 #include "uhdr_kernels.h"
+#include "uhdr_jpeg.h"
 
 namespace {
 
@@ -444,6 +445,7 @@ int uhdr_hip_init(int device) {
     HIP_TRY(hipMalloc(&st.lut, sizeof(float) * kLutTotal));
     HIP_TRY(launch_build_luts(st.lut, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(jpeg::upload_tables());
     st.ready = true;
   }
   return UHDR_HIP_NO_ERROR;
@@ -482,6 +484,97 @@ int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float 
   ec.log2_min_d = std::log2((double)min_boost);
   ec.log2_max_d = std::log2((double)max_boost);
   HIP_TRY(launch_eval_transfer(fn, in, out, n, ec, static_cast<hipStream_t>(stream)));
+  return UHDR_HIP_NO_ERROR;
+}
+
+// JpegEncoderHelper::compressImage (jpegencoderhelper.cpp:39-52) on the device
+int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void* icc, size_t icc_size, void* out,
+                         size_t out_capacity, size_t* out_size, int mem_space, void* stream) {
+  if (image == nullptr || out_size == nullptr || image->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  const bool gray = image->pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
+  if (!gray && image->chroma_data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (out == nullptr && out_capacity != 0) return UHDR_HIP_ERROR_BAD_PTR;
+  const size_t w = image->width, h = image->height;
+  if (w == 0 || h == 0 || w > 65500 || h > 65500) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;   // libjpeg's JPEG_MAX_DIMENSION
+  if (!gray && ((w | h) & 1)) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lk(g_host_mu);   // the encoder workspace is shared
+
+  const size_t ls = image->luma_stride ? image->luma_stride : w;
+  const size_t cs = gray ? 0 : image->chroma_stride;
+  const size_t aw = (w + 15) / 16 * 16, acw = (w / 2 + 7) / 8 * 8;
+  jpeg::Job j;
+  memset(&j, 0, sizeof(j));
+  j.gray = gray ? 1 : 0;
+  j.ybw = (uint32_t)((w + 7) / 8); j.ybh = (uint32_t)((h + 7) / 8);
+  j.mcus_x = (uint32_t)((w + 15) / 16);
+  j.nblk = gray ? j.ybw * j.ybh : j.mcus_x * (uint32_t)((h + 15) / 16) * 6u;
+  uint16_t qn[64];
+  jpeg::quant_table(quality, false, qn); jpeg::zigzag_table(qn, j.q_lum);
+  jpeg::quant_table(quality, true, qn); jpeg::zigzag_table(qn, j.q_chr);
+  for (int i = 0; i < 64; ++i) {
+    j.m_lum[i] = (uint32_t)((1ull << 32) / ((uint32_t)j.q_lum[i] << 3)) + 1u;
+    j.m_chr[i] = (uint32_t)((1ull << 32) / ((uint32_t)j.q_chr[i] << 3)) + 1u;
+  }
+
+  const uint8_t* py = static_cast<const uint8_t*>(image->data);
+  const uint8_t* pu = static_cast<const uint8_t*>(image->chroma_data);
+  size_t dls = ls, dcs = cs;
+  if (mem_space != UHDR_HIP_MEM_DEVICE) {
+    // stage exactly the bytes the reference would touch: w columns when it pads, the 16-aligned width otherwise
+    const size_t ycols = ls < aw ? w : aw, ccols = cs < acw ? w / 2 : acw;
+    dls = round_up(ycols, 64); dcs = round_up(ccols ? ccols : 1, 64);
+    if ((rc = stage_reserve(st, 0, dls * h)) != 0) return rc;
+    if ((rc = h2d_plane(st->stage[0], dls, py, ls, ycols, h, 1, s)) != 0) return rc;
+    py = static_cast<const uint8_t*>(st->stage[0]);
+    if (!gray) {
+      if ((rc = stage_reserve(st, 1, dcs * h + 64)) != 0) return rc;
+      uint8_t* du = static_cast<uint8_t*>(st->stage[1]);
+      if ((rc = h2d_plane(du, dcs, pu, cs, ccols, h / 2, 1, s)) != 0) return rc;
+      if ((rc = h2d_plane(du + dcs * (h / 2), dcs, pu + cs * h / 2, cs, ccols, h / 2, 1, s)) != 0) return rc;
+      pu = du;
+    }
+  }
+  auto plane = [](const uint8_t* p, size_t pw, size_t ph, size_t stride, bool pad) {
+    jpeg::Plane q;
+    q.p = p; q.w = (int)pw; q.h = (int)ph; q.stride = (int)stride; q.pad_cols = pad ? 1 : 0;
+    q.aligned4 = (reinterpret_cast<uintptr_t>(p) % 4 == 0 && stride % 4 == 0) ? 1 : 0;
+    return q;
+  };
+  j.plane[0] = plane(py, w, h, dls, ls < aw);
+  if (!gray) {
+    const size_t v_off = mem_space != UHDR_HIP_MEM_DEVICE ? dcs * (h / 2) : cs * h / 2;   // chromaStride * height / 2 (:140)
+    j.plane[1] = plane(pu, w / 2, h / 2, dcs, cs < acw);
+    j.plane[2] = plane(pu + v_off, w / 2, h / 2, dcs, cs < acw);
+  }
+
+  std::vector<uint8_t> header;
+  jpeg::build_header((int)w, (int)h, gray, quality, icc, icc_size, header);
+  jpeg::Layout l;
+  const size_t ws_bytes = jpeg::workspace_bytes(j.nblk, &l);
+  if ((rc = stage_reserve(st, 7, ws_bytes)) != 0) return rc;
+  uint8_t* ws = static_cast<uint8_t*>(st->stage[7]);
+  uint8_t* dout = static_cast<uint8_t*>(out);
+  size_t dcap = out_capacity;
+  if (mem_space != UHDR_HIP_MEM_DEVICE) {   // worst case: every stream byte stuffed
+    dcap = header.size() + 2 * l.stream_bytes + 2;
+    if ((rc = stage_reserve(st, 5, dcap)) != 0) return rc;
+    dout = static_cast<uint8_t*>(st->stage[5]);
+  }
+  if (dcap >= header.size()) HIP_TRY(hipMemcpyAsync(dout, header.data(), header.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(jpeg::encode_async(j, l, ws, dout, dcap >= header.size() ? dcap : 0, header.size(), s));
+  uint64_t total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, ws + l.totals + 8, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *out_size = (size_t)total;
+  if (total > out_capacity) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  if (mem_space != UHDR_HIP_MEM_DEVICE) {
+    HIP_TRY(hipMemcpyAsync(out, dout, total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   return UHDR_HIP_NO_ERROR;
 }
 

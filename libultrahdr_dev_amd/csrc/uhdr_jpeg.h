@@ -1,0 +1,49 @@
+// uhdr_jpeg.h -- internal interface of the GPU baseline-JPEG encoder (uhdr_jpeg.hip)
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace uhdr {
+namespace jpeg {
+
+struct Plane {
+  const uint8_t* p;
+  int w, h, stride;
+  int pad_cols;   // columns >= w read as zero (the reference copies the row into a zero-padded buffer) instead of from p
+  int aligned4;   // p and stride are multiples of 4: whole-dword row loads
+};
+struct Job {
+  Plane plane[3];          // Y, Cb, Cr (one plane: only [0])
+  uint16_t q_lum[64], q_chr[64];   // quantisation tables in zigzag order
+  uint32_t m_lum[64], m_chr[64];   // floor(2^32 / (q << 3)) + 1: n / (q << 3) == mulhi(n, m) for n < 2^16 (exact: n * (q << 3) < 2^32)
+  uint32_t nblk;           // blocks in entropy-coding order, dummy edge blocks included
+  uint32_t ybw, ybh;       // luma size in blocks
+  uint32_t mcus_x;         // MCUs per row (4:2:0)
+  int gray;
+  // workspace (device)
+  int16_t* coef;           // nblk x 64, zigzag order
+  uint32_t* bits;          // nblk (+1 zero)
+  uint64_t* bit_off;       // nblk + 1 (exclusive scan; [nblk] = total)
+  uint32_t* stream;        // packed entropy-coded bits before byte stuffing, big-endian words
+  uint32_t* ff_count;      // per 64-byte chunk of the stream
+  uint32_t* ff_off;
+  uint32_t max_chunks;
+};
+struct Layout {
+  size_t coef, bits, bit_off, stream, stream_bytes, ff_count, ff_off, totals, scan_tmp, scan_tmp_bytes;
+  uint32_t max_chunks;
+};
+
+hipError_t upload_tables();
+void quant_table(int quality, bool chroma, uint16_t out_natural[64]);
+void zigzag_table(const uint16_t natural[64], uint16_t zz[64]);
+void build_header(int w, int h, bool gray, int quality, const void* icc, size_t icc_n, std::vector<uint8_t>& out);
+size_t workspace_bytes(uint32_t nblk, Layout* l);
+// enqueues the whole encoder; the JPEG (without the header, which the caller places at out[0, header_len)) lands at
+// out + header_len, its total size (header included) in the uint64 at ws + l.totals + 8
+hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint64_t out_cap, uint64_t header_len, hipStream_t s);
+
+}  // namespace jpeg
+}  // namespace uhdr

@@ -39,3 +39,31 @@ def lcg_frame(w, h, seed, device="cuda"):
     p010 = torch.stack([(p & 0xFF).to(torch.uint8), (p >> 8).to(torch.uint8)], dim=1).reshape(-1)
     yuv = (d_y & 255).to(torch.uint8)
     return p010.contiguous(), yuv.contiguous()
+
+
+def smooth_frame(w, h, seed, device="cuda"):
+    """SURVEY.md 8(d) 'smooth' variant: low-frequency cosine planes in the legal ranges plus a little noise, built on the
+    device.  Returns (p010 uint16[w*h*3/2], yuv uint8[w*h*3/2]) like lcg_frame.  Natural-image-like statistics matter for
+    the JPEG timings (entropy-coded size depends on content); the pixel kernels do not care."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def plane(pw, ph, lo, hi, noise):
+        yy = torch.arange(ph, device=device, dtype=torch.float32).view(-1, 1)
+        xx = torch.arange(pw, device=device, dtype=torch.float32).view(1, -1)
+        acc = torch.zeros((ph, pw), device=device)
+        for k in range(3):
+            fx, fy, ph0 = (0.7 + 0.9 * k) / pw, (1.1 + 0.6 * k) / ph, 0.5 + 1.3 * k + 0.01 * seed
+            acc = acc + torch.cos(6.283185 * (fx * xx + fy * yy) + ph0)
+        v = lo + (acc / 6.0 + 0.5) * (hi - lo) + (torch.rand((ph, pw), generator=g, device=device) - 0.5) * noise
+        return v.clamp_(lo, hi)
+
+    y8 = plane(w, h, 0, 255, 6.0).to(torch.uint8).reshape(-1)
+    u8 = plane(w // 2, h // 2, 16, 240, 3.0).to(torch.uint8).reshape(-1)
+    v8 = plane(w // 2, h // 2, 16, 240, 3.0).flip(0).to(torch.uint8).reshape(-1)
+    yuv = torch.cat([y8, u8, v8])
+    hy = (plane(w, h, 64, 940, 12.0).to(torch.int32) << 6).to(torch.uint16).reshape(-1)
+    hu = (plane(w // 2, h // 2, 64, 960, 6.0).to(torch.int32) << 6)
+    hv = (plane(w // 2, h // 2, 64, 960, 6.0).flip(1).to(torch.int32) << 6)
+    huv = torch.stack([hu, hv], dim=-1).to(torch.uint16).reshape(-1)
+    return torch.cat([hy, huv]), yuv

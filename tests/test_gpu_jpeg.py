@@ -1,0 +1,97 @@
+"""-m gpu: the device JPEG encoder (uhdr_hip_jpeg_encode = JpegEncoderHelper::compressImage,
+lib/src/jpegencoderhelper.cpp:39-283) against the CPU checker oracle/jpeg_oracle.c, whole files, BYTE FOR BYTE.
+The checker itself is pinned to the image's libjpeg builds by tests/test_jpeg_oracle.py (CPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.test_jpeg_oracle import SIZES, _content, _planes
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_encode(lib, hip, yb, ub, w, h, q, ls, cs, device, icc=None, cap=None):
+    from tests.gpu_util import dev_empty, stream_ptr, to_dev, to_host
+    gray = ub is None
+    n = C.c_size_t()
+    iccp = None if icc is None else C.c_char_p(icc)
+    iccn = 0 if icc is None else len(icc)
+    if device:
+        dy = to_dev(yb)
+        du = None if gray else to_dev(ub)
+        img = hip.Image(dy.data_ptr(), w, h, hip.CG_UNSPECIFIED, None if gray else du.data_ptr(), ls, cs,
+                        hip.PIX_FMT_MONOCHROME if gray else hip.PIX_FMT_YUV420)
+        cap = cap if cap is not None else w * h * 4 + 4096
+        dout = dev_empty(cap, 0xCD)
+        rc = lib.uhdr_hip_jpeg_encode(C.byref(img), q, iccp, iccn, C.c_void_p(dout.data_ptr()), cap, C.byref(n), hip.MEM_DEVICE, stream_ptr())
+        return rc, n.value, (to_host(dout, min(n.value, cap)).tobytes() if rc == 0 else None)
+    img = hip.Image(yb.ctypes.data, w, h, hip.CG_UNSPECIFIED, None if gray else ub.ctypes.data, ls, cs,
+                    hip.PIX_FMT_MONOCHROME if gray else hip.PIX_FMT_YUV420)
+    cap = cap if cap is not None else w * h * 4 + 4096
+    out = np.full(cap, 0xCD, np.uint8)
+    rc = lib.uhdr_hip_jpeg_encode(C.byref(img), q, iccp, iccn, C.c_void_p(out.ctypes.data), cap, C.byref(n), hip.MEM_HOST, None)
+    return rc, n.value, (out[:n.value].tobytes() if rc == 0 else None)
+
+
+@pytest.mark.parametrize("kind", ["smooth", "noise", "extreme", "flat"])
+@pytest.mark.parametrize("device", [True, False])
+def test_encoder_is_byte_exact_for_every_size_class(hip, orc, kind, device):
+    lib = hip.load()
+    rng = np.random.RandomState(len(kind) + int(device))
+    for w, h in SIZES:
+        y, u, v = _content(kind, w, h, rng)
+        aw, acw = (w + 15) // 16 * 16, (w // 2 + 7) // 8 * 8
+        for ls, cs in ((w, w // 2), (aw, acw), (aw + 16, acw + 8), (w + 2, w // 2 + 1)):
+            yb, ub = _planes(y, u, v, ls, cs, rng)
+            for q in (90, 85, 50, 20, 1, 100) if (w, h) in ((64, 48), (40, 24)) else (85,):
+                rc, n, got = _gpu_encode(lib, hip, yb, ub, w, h, q, ls, cs, device)
+                want = orc.jpeg_encode("orc", yb, ub, w, h, q, ls, cs)
+                assert rc == 0 and n == len(want) and got == want, ("yuv420", kind, w, h, ls, cs, q, n, len(want))
+                rc, n, got = _gpu_encode(lib, hip, yb, None, w, h, q, ls, 0, device)
+                want = orc.jpeg_encode("orc", yb, None, w, h, q, ls)
+                assert rc == 0 and got == want, ("plane", kind, w, h, ls, q, n, len(want))
+
+
+def test_icc_segment_capacity_and_argument_errors(hip, orc):
+    lib = hip.load()
+    rng = np.random.RandomState(9)
+    w, h = 64, 48
+    y, u, v = _content("smooth", w, h, rng)
+    yb, ub = _planes(y, u, v, w, w // 2, rng)
+    icc = bytes(range(256)) * 2
+    for device in (True, False):
+        rc, n, got = _gpu_encode(lib, hip, yb, ub, w, h, 90, w, w // 2, device, icc=icc)
+        assert rc == 0 and got == orc.jpeg_encode("orc", yb, ub, w, h, 90, icc=icc)
+        rc, n, _ = _gpu_encode(lib, hip, yb, ub, w, h, 90, w, w // 2, device, cap=700)      # header fits, data does not
+        assert rc == hip.ERROR_INSUFFICIENT_RESOURCE and n == len(orc.jpeg_encode("orc", yb, ub, w, h, 90))
+        rc, n, _ = _gpu_encode(lib, hip, yb, ub, w, h, 90, w, w // 2, device, cap=16)       # not even the header
+        assert rc == hip.ERROR_INSUFFICIENT_RESOURCE and n == len(orc.jpeg_encode("orc", yb, ub, w, h, 90))
+    n = C.c_size_t()
+    img = hip.Image(yb.ctypes.data, 63, 48, -1, ub.ctypes.data, 64, 32, hip.PIX_FMT_YUV420)
+    out = np.zeros(1 << 16, np.uint8)
+    assert lib.uhdr_hip_jpeg_encode(C.byref(img), 90, None, 0, C.c_void_p(out.ctypes.data), out.size, C.byref(n), hip.MEM_HOST, None) == hip.ERROR_RESOLUTION_MISMATCH
+    assert lib.uhdr_hip_jpeg_encode(None, 90, None, 0, C.c_void_p(out.ctypes.data), out.size, C.byref(n), hip.MEM_HOST, None) == hip.ERROR_BAD_PTR
+    img = hip.Image(yb.ctypes.data, 64, 48, -1, None, 64, 32, hip.PIX_FMT_YUV420)
+    assert lib.uhdr_hip_jpeg_encode(C.byref(img), 90, None, 0, C.c_void_p(out.ctypes.data), out.size, C.byref(n), hip.MEM_HOST, None) == hip.ERROR_BAD_PTR
+
+
+@pytest.mark.parametrize("q", [95, 85])
+def test_4k_frame_and_its_gain_map(hip, orc, q):
+    """configs[2]-sized content: a 3840x2160 YUV420 frame (base image, quality 95 in the reference's API-0/1) and its
+    960x540 gain map (quality 85, jpegr.cpp:294-297), both produced on the device and compressed there"""
+    from tests.gpu_util import gpu_generate
+    from tests.test_gpu_parity import smooth_frame
+    lib = hip.load()
+    w, h = 3840, 2160
+    p010, yuv = smooth_frame(w, h, 5)
+    rc, n, got = _gpu_encode(lib, hip, yuv[:w * h], yuv[w * h:], w, h, q, w, w // 2, True)
+    want = orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, q)
+    assert rc == 0 and got == want, (n, len(want))
+    from tests.gpu_util import to_dev
+    dp, dy = to_dev(p010), to_dev(yuv)
+    st, gmap, _, _ = gpu_generate(lib, hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709), hip.p010_image(dp.data_ptr(), w, h, hip.CG_BT2100), hip.TF_HLG)
+    assert st == 0
+    gm = np.ascontiguousarray(gmap.reshape(-1))
+    rc, n, got = _gpu_encode(lib, hip, gm, None, w // 4, h // 4, q, w // 4, 0, True)
+    assert rc == 0 and got == orc.jpeg_encode("orc", gm, None, w // 4, h // 4, q)

@@ -95,3 +95,69 @@ long lj_jpeg_encode(const unsigned char* y, const unsigned char* uv, int w, int 
   free(mem); free(empty); free(ybuf); free(cbbuf); free(crbuf);
   return n;
 }
+
+/* JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR) (lib/src/jpegdecoderhelper.cpp:188-327 + decompressYUV :352-448,
+ * decompressSingleChannel :450-516): raw_data_out, JDCT_ISLOW, 16 rows per jpeg_read_raw_data, planes cropped to w x h.
+ * Returns the bytes written, or a negative value (-2: not 4:2:0 / grayscale, -3: cap too small, -1: libjpeg error). */
+#include <setjmp.h>
+struct lj_err { struct jpeg_error_mgr pub; jmp_buf jb; };
+static void lj_error_exit(j_common_ptr c) { longjmp(((struct lj_err*)c->err)->jb, 1); }
+static void lj_silent(j_common_ptr c) { (void)c; }
+long lj_jpeg_decode(const unsigned char* jpg, long n, unsigned char* out, long cap, int* pw, int* ph, int* pgray) {
+  struct jpeg_decompress_struct c;
+  struct lj_err e;
+  c.err = jpeg_std_error(&e.pub);
+  e.pub.error_exit = lj_error_exit;
+  e.pub.output_message = lj_silent;
+  unsigned char* scratch = NULL;
+  if (setjmp(e.jb)) { jpeg_destroy_decompress(&c); free(scratch); return -1; }
+  jpeg_create_decompress(&c);
+  jpeg_mem_src(&c, (unsigned char*)jpg, (unsigned long)n);
+  if (jpeg_read_header(&c, TRUE) != JPEG_HEADER_OK) { jpeg_destroy_decompress(&c); return -1; }
+  const int w = (int)c.image_width, h = (int)c.image_height;
+  int gray;
+  if (c.jpeg_color_space == JCS_YCbCr) {
+    if (c.comp_info[0].h_samp_factor != 2 || c.comp_info[0].v_samp_factor != 2 || c.comp_info[1].h_samp_factor != 1 ||
+        c.comp_info[1].v_samp_factor != 1 || c.comp_info[2].h_samp_factor != 1 || c.comp_info[2].v_samp_factor != 1) {
+      jpeg_destroy_decompress(&c);
+      return -2;
+    }
+    gray = 0;
+  } else if (c.jpeg_color_space == JCS_GRAYSCALE) {
+    gray = 1;
+  } else {
+    jpeg_destroy_decompress(&c);
+    return -2;
+  }
+  *pw = w; *ph = h; *pgray = gray;
+  const long need = gray ? (long)w * h : (long)w * h * 3 / 2;
+  if (need > cap) { jpeg_destroy_decompress(&c); return -3; }
+  c.out_color_space = c.jpeg_color_space;
+  c.raw_data_out = TRUE;
+  c.dct_method = JDCT_ISLOW;
+  jpeg_start_decompress(&c);
+  const int aw = ALIGNM(w, BATCH);
+  /* always decode into the 16-aligned intermediate rows and copy the image part out (the reference does so whenever the
+     width is not a multiple of 16 and writes in place otherwise: same bytes) */
+  scratch = (unsigned char*)calloc((size_t)aw * BATCH * 3 / 2 + (size_t)aw, 1);
+  unsigned char *yi = scratch, *ui = yi + (size_t)aw * BATCH, *vi = ui + (size_t)aw * BATCH / 4;
+  JSAMPROW yr[BATCH], cbr[BATCH / 2], crr[BATCH / 2];
+  JSAMPARRAY planes[3] = {yr, cbr, crr};
+  for (int i = 0; i < BATCH; i++) yr[i] = yi + (size_t)i * aw;
+  for (int i = 0; i < BATCH / 2; i++) { cbr[i] = ui + (size_t)i * (aw / 2); crr[i] = vi + (size_t)i * (aw / 2); }
+  unsigned char *yp = out, *up = out + (size_t)w * h, *vp = up + (size_t)w * h / 4;
+  while (c.output_scanline < c.image_height) {
+    const size_t s0 = c.output_scanline;
+    const int got = (int)jpeg_read_raw_data(&c, planes, BATCH);
+    if (got <= 0) break;
+    for (int i = 0; i < got; i++)
+      if (s0 + i < (size_t)h) memcpy(yp + (s0 + i) * w, yr[i], w);
+    if (!gray)
+      for (int i = 0; i < BATCH / 2; i++)
+        if (s0 / 2 + i < (size_t)h / 2) { memcpy(up + (s0 / 2 + i) * (w / 2), cbr[i], w / 2); memcpy(vp + (s0 / 2 + i) * (w / 2), crr[i], w / 2); }
+  }
+  jpeg_finish_decompress(&c);
+  jpeg_destroy_decompress(&c);
+  free(scratch);
+  return need;
+}

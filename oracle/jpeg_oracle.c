@@ -369,3 +369,204 @@ long orc_jpeg_encode(const uint8_t* y, const uint8_t* uv, int w, int h, int ls, 
   free(coef);
   return b.n;
 }
+
+/* =====================================================================================================================
+ * Decoding: what JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR) returns (lib/src/jpegdecoderhelper.cpp:188-327,
+ * :352-516): libjpeg with raw_data_out and JDCT_ISLOW on a 4:2:0 YCbCr or a grayscale JPEG; the result buffer holds the
+ * w x h luma plane followed (4:2:0) by the (w/2) x (h/2) Cb and Cr planes at w*h and w*h + w*h/4, i.e. the component
+ * planes cropped to the image size.  Restated for the baseline sequential Huffman process (SOF0; SOF1 with 8-bit
+ * samples is the same process): T.81 Annex B markers, F.2.2 decoding, A.3.3 dequantisation + libjpeg's "islow" IDCT.
+ * Progressive and arithmetic-coded files (which libjpeg would also read) are outside this restatement: -2.
+ * ===================================================================================================================== */
+typedef struct { uint8_t look_len[65536]; uint8_t look_sym[65536]; int present; } dhuff;
+static void dhuff_build(dhuff* t, const uint8_t bits[16], const uint8_t* vals) {
+  memset(t->look_len, 0, sizeof(t->look_len));
+  unsigned code = 0;
+  int p = 0;
+  for (int l = 1; l <= 16; ++l) {
+    for (int i = 0; i < bits[l - 1]; ++i, ++p) {
+      const unsigned lo = code << (16 - l), n = 1u << (16 - l);
+      for (unsigned k = 0; k < n && lo + k < 65536u; ++k) { t->look_len[lo + k] = (uint8_t)l; t->look_sym[lo + k] = vals[p]; }
+      code++;
+    }
+    code <<= 1;
+  }
+  t->present = 1;
+}
+typedef struct { const uint8_t* p; long n, pos; uint64_t acc; int nacc; int hit_marker; } bitr;
+static void br_fill(bitr* b) { /* entropy-coded segment: FF00 -> FF, any other FFxx ends the segment (zeros are fed after it) */
+  while (b->nacc <= 48) {
+    unsigned byte = 0;
+    if (!b->hit_marker && b->pos < b->n) {
+      byte = b->p[b->pos];
+      if (byte == 0xFF) {
+        if (b->pos + 1 < b->n && b->p[b->pos + 1] == 0) b->pos += 2;
+        else { b->hit_marker = 1; byte = 0; }
+      } else b->pos++;
+    }
+    b->acc = (b->acc << 8) | byte;
+    b->nacc += 8;
+  }
+}
+static unsigned br_peek16(bitr* b) { br_fill(b); return (unsigned)((b->acc >> (b->nacc - 16)) & 0xFFFFu); }
+static void br_skip(bitr* b, int n) { b->nacc -= n; }
+static int br_get(bitr* b, int n) {
+  if (n == 0) return 0;
+  br_fill(b);
+  int v = (int)((b->acc >> (b->nacc - n)) & ((1u << n) - 1u));
+  b->nacc -= n;
+  return v;
+}
+static int extend(int v, int n) { return n == 0 ? 0 : (v < (1 << (n - 1)) ? v - (1 << n) + 1 : v); } /* F.2.2.1 */
+
+/* libjpeg jidctint.c ("islow"), coefficients in natural order already multiplied by the quantiser */
+static void idct_1d(const int32_t in[8], int32_t out[8], int pass) {
+  int32_t z2 = in[2], z3 = in[6];
+  int32_t z1 = (z2 + z3) * FIX_0_541196100;
+  int32_t tmp2 = z1 + z3 * (-FIX_1_847759065), tmp3 = z1 + z2 * FIX_0_765366865;
+  z2 = in[0]; z3 = in[4];
+  int32_t tmp0 = (z2 + z3) << CONST_BITS, tmp1 = (z2 - z3) << CONST_BITS;
+  int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int32_t z4 = tmp1 + tmp3, z5 = (z3 + z4) * FIX_1_175875602;
+  tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
+  z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  const int sh = pass == 0 ? CONST_BITS - PASS1_BITS : CONST_BITS + PASS1_BITS + 3;
+  out[0] = DESCALE(tmp10 + tmp3, sh); out[7] = DESCALE(tmp10 - tmp3, sh);
+  out[1] = DESCALE(tmp11 + tmp2, sh); out[6] = DESCALE(tmp11 - tmp2, sh);
+  out[2] = DESCALE(tmp12 + tmp1, sh); out[5] = DESCALE(tmp12 - tmp1, sh);
+  out[3] = DESCALE(tmp13 + tmp0, sh); out[4] = DESCALE(tmp13 - tmp0, sh);
+}
+void orc_jpeg_idct(const int16_t coef_natural[64], const uint16_t quant_natural[64], uint8_t samples[64]) {
+  int32_t ws[64], v[8], r[8];
+  for (int c = 0; c < 8; ++c) { /* pass 1: columns */
+    for (int k = 0; k < 8; ++k) v[k] = (int32_t)coef_natural[k * 8 + c] * (int32_t)quant_natural[k * 8 + c];
+    idct_1d(v, r, 0);
+    for (int k = 0; k < 8; ++k) ws[k * 8 + c] = r[k];
+  }
+  for (int row = 0; row < 8; ++row) { /* pass 2: rows, + 128, clamp (libjpeg's range_limit table) */
+    idct_1d(&ws[row * 8], r, 1);
+    for (int k = 0; k < 8; ++k) {
+      int32_t x = r[k] + 128;
+      samples[row * 8 + k] = (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x));
+    }
+  }
+}
+
+static unsigned rd16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
+/* returns bytes written (w*h*3/2 or w*h), -1 malformed, -2 unsupported process / sampling, -3 cap too small (sizes set) */
+long orc_jpeg_decode(const uint8_t* jpg, long n, uint8_t* out, long cap, int* pw, int* ph, int* pgray) {
+  if (jpg == NULL || n < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return -1;
+  static dhuff tbl[2][4]; /* [class][id]; not re-entrant: the oracle is called from one thread for decoding */
+  uint16_t quant[4][64];
+  int have_q[4] = {0, 0, 0, 0};
+  for (int c = 0; c < 2; ++c) for (int i = 0; i < 4; ++i) tbl[c][i].present = 0;
+  int w = 0, h = 0, nc = 0, hs[3] = {0}, vs[3] = {0}, tq[3] = {0}, cid[3] = {0}, restart = 0;
+  long pos = 2;
+  for (;;) {
+    if (pos + 4 > n || jpg[pos] != 0xFF) return -1;
+    while (pos < n && jpg[pos] == 0xFF && jpg[pos + 1] == 0xFF) pos++; /* fill bytes */
+    const unsigned m = jpg[pos + 1];
+    const long len = rd16(jpg + pos + 2);
+    const uint8_t* seg = jpg + pos + 4;
+    if (pos + 2 + len > n || len < 2) return -1;
+    if (m == 0xDB) {
+      for (long o = 0; o + 1 <= len - 2;) {
+        const int pq = seg[o] >> 4, id = seg[o] & 15;
+        if (id > 3 || (o + 1 + (pq ? 128 : 64)) > len - 2) return -1;
+        for (int i = 0; i < 64; ++i) quant[id][kZigzag[i]] = pq ? (uint16_t)rd16(seg + o + 1 + 2 * i) : seg[o + 1 + i];
+        have_q[id] = 1;
+        o += 1 + (pq ? 128 : 64);
+      }
+    } else if (m == 0xC4) {
+      for (long o = 0; o + 17 <= len - 2;) {
+        const int cls = seg[o] >> 4, id = seg[o] & 15;
+        int cnt = 0;
+        for (int i = 0; i < 16; ++i) cnt += seg[o + 1 + i];
+        if (cls > 1 || id > 3 || cnt > 256 || o + 17 + cnt > len - 2) return -1;
+        dhuff_build(&tbl[cls][id], seg + o + 1, seg + o + 17);
+        o += 17 + cnt;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (seg[0] != 8) return -2;
+      h = (int)rd16(seg + 1); w = (int)rd16(seg + 3); nc = seg[5];
+      if (nc != 1 && nc != 3) return -2;
+      for (int c = 0; c < nc; ++c) { cid[c] = seg[6 + 3 * c]; hs[c] = seg[7 + 3 * c] >> 4; vs[c] = seg[7 + 3 * c] & 15; tq[c] = seg[8 + 3 * c]; }
+    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      return -2;
+    } else if (m == 0xDD) {
+      restart = (int)rd16(seg);
+    } else if (m == 0xDA) {
+      if (nc == 0 || seg[0] != nc) return -2; /* one interleaved scan with all components */
+      int td[3], ta[3];
+      for (int c = 0; c < nc; ++c) {
+        if (seg[1 + 2 * c] != cid[c]) return -2;
+        td[c] = seg[2 + 2 * c] >> 4; ta[c] = seg[2 + 2 * c] & 15;
+        if (td[c] > 3 || ta[c] > 3 || !tbl[0][td[c]].present || !tbl[1][ta[c]].present || tq[c] > 3 || !have_q[tq[c]]) return -1;
+      }
+      const int gray = nc == 1;
+      if (gray ? 0 : !(hs[0] == 2 && vs[0] == 2 && hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1)) return -2; /* :256-262 */
+      if (w <= 0 || h <= 0) return -1;
+      *pw = w; *ph = h; *pgray = gray;
+      const long need = gray ? (long)w * h : (long)w * h + 2 * ((long)w * h / 4);
+      if (need > cap) return -3;
+      const int mcux = gray ? (w + 7) / 8 : (w + 15) / 16, mcuy = gray ? (h + 7) / 8 : (h + 15) / 16;
+      const int bpm = gray ? 1 : 6;
+      uint8_t* planes[3] = {out, out + (size_t)w * h, out + (size_t)w * h + (size_t)w * h / 4};
+      const int pwid[3] = {w, w / 2, w / 2}, phgt[3] = {h, h / 2, h / 2};
+      bitr b = {jpg, n, pos + 2 + len, 0, 0, 0};
+      int pred[3] = {0, 0, 0}, rst_left = restart;
+      for (int my = 0; my < mcuy; ++my)
+        for (int mx = 0; mx < mcux; ++mx) {
+          if (restart && rst_left == 0) { /* B.2.5 / F.2.2.4: byte-align, expect RSTn, reset predictors */
+            b.nacc = 0; b.acc = 0;
+            if (b.hit_marker) { b.pos += 2; b.hit_marker = 0; }
+            else if (b.pos + 1 < b.n && b.p[b.pos] == 0xFF && (b.p[b.pos + 1] & 0xF8) == 0xD0) b.pos += 2;
+            pred[0] = pred[1] = pred[2] = 0;
+            rst_left = restart;
+          }
+          for (int k = 0; k < bpm; ++k) {
+            const int c = gray ? 0 : (k < 4 ? 0 : k - 3);
+            int16_t blk[64];
+            memset(blk, 0, sizeof(blk));
+            unsigned look = br_peek16(&b);
+            int l = tbl[0][td[c]].look_len[look];
+            if (l == 0) return -1;
+            int s = tbl[0][td[c]].look_sym[look];
+            br_skip(&b, l);
+            pred[c] += extend(br_get(&b, s), s);
+            blk[0] = (int16_t)pred[c];
+            for (int z = 1; z < 64;) {
+              look = br_peek16(&b);
+              l = tbl[1][ta[c]].look_len[look];
+              if (l == 0) return -1;
+              const int rs = tbl[1][ta[c]].look_sym[look];
+              br_skip(&b, l);
+              const int r = rs >> 4, sz = rs & 15;
+              if (sz == 0) { if (r == 15) { z += 16; continue; } break; }
+              z += r;
+              if (z > 63) return -1;
+              blk[kZigzag[z]] = (int16_t)extend(br_get(&b, sz), sz);
+              z++;
+            }
+            uint8_t smp[64];
+            orc_jpeg_idct(blk, quant[tq[c]], smp);
+            const int bx = gray ? mx : (c == 0 ? mx * 2 + (k & 1) : mx), by = gray ? my : (c == 0 ? my * 2 + (k >> 1) : my);
+            for (int r2 = 0; r2 < 8; ++r2)
+              for (int c2 = 0; c2 < 8; ++c2) {
+                const int yy = by * 8 + r2, xx = bx * 8 + c2;
+                if (yy < phgt[c] && xx < pwid[c]) planes[c][(size_t)yy * pwid[c] + xx] = smp[r2 * 8 + c2];
+              }
+          }
+          if (restart) rst_left--;
+        }
+      return need;
+    } else if (m == 0xD9) {
+      return -1;
+    }
+    pos += 2 + len;
+  }
+}

@@ -97,6 +97,7 @@ def _declare(lib, p):
         d("jpeg_block_count", C.c_long, i32, i32, i32)
         d("jpeg_coefficients", C.c_long, C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, C.c_void_p)
         d("jpeg_quant_table", None, i32, i32, C.c_void_p)
+        d("jpeg_decode", C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
         d("lut_table", C.POINTER(f32), i32, C.POINTER(sz))
         d("gainLutFactor", f32, C.POINTER(f32), f32)
         d("applyGainLUT", Color, Color, f32, C.POINTER(f32))
@@ -151,6 +152,9 @@ def load_libjpeg():
                 lib.lj_jpeg_encode.restype = C.c_long
                 lib.lj_jpeg_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                C.c_uint, C.c_void_p, C.c_long]
+                lib.lj_jpeg_decode.restype = C.c_long
+                lib.lj_jpeg_decode.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_int)]
             except OSError:
                 lib = None
         _cache["lj"] = lib
@@ -172,6 +176,23 @@ def jpeg_encode(which, y, uv, w, h, quality, luma_stride=None, chroma_stride=Non
         if n <= cap:
             return out[:max(n, 0)].tobytes() if n >= 0 else None
         cap = int(n) + 16
+
+
+def jpeg_decode(which, data):
+    """JpegDecoderHelper::decompressImage(DECODE_TO_YCBCR) through the oracle ("orc") or the image's libjpeg ("lj"):
+    -> (status, planes uint8 array, w, h, gray); status < 0 on failure"""
+    fn = load().orc_jpeg_decode if which == "orc" else load_libjpeg().lj_jpeg_decode
+    buf = np.frombuffer(data, np.uint8)
+    w, h, g = C.c_int(), C.c_int(), C.c_int()
+    cap = 1 << 16
+    for _ in range(2):
+        out = np.zeros(cap, np.uint8)
+        n = fn(buf.ctypes.data, buf.size, out.ctypes.data, cap, C.byref(w), C.byref(h), C.byref(g))
+        if n == -3:
+            cap = w.value * h.value * 2 + 64
+            continue
+        break
+    return int(n), (out[:n].copy() if n > 0 else None), w.value, h.value, g.value
 
 
 def jpeg_coefficients(y, uv, w, h, quality, luma_stride=None, chroma_stride=None):

@@ -139,6 +139,11 @@ long orc_jpeg_block_count(int w, int h, int gray);
 long orc_jpeg_coefficients(const uint8_t* y, const uint8_t* uv, int w, int h, int ls, int cs, int quality, int16_t* coef);
 void orc_jpeg_quant_table(int quality, int chroma, uint16_t out[64]);
 void orc_jpeg_fdct_quant(const uint8_t samples[64], const uint16_t quant[64], int16_t coef[64]);
+/* JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR) (lib/src/jpegdecoderhelper.cpp:188-516) for baseline files:
+ * out = w*h luma, then (4:2:0) Cb and Cr of (w/2)*(h/2) at w*h and w*h + w*h/4.  Returns bytes written; -1 malformed,
+ * -2 process / sampling outside the restatement, -3 cap too small (*w, *h, *gray are set). */
+long orc_jpeg_decode(const uint8_t* jpg, long n, uint8_t* out, long cap, int* w, int* h, int* gray);
+void orc_jpeg_idct(const int16_t coef_natural[64], const uint16_t quant_natural[64], uint8_t samples[64]);
 
 /* fn: 0 srgbInvOetf 1 hlgInvOetf 2 pqInvOetf 3 encodeGain(y_sdr=1,y_hdr=x) 4 hlgOetf 5 pqOetf;
  * 40/41/42/44/45 the LUT accessors of fn 0/1/2/4/5; 46 GainLUT(min,max,displayBoost=max).getGainFactor */

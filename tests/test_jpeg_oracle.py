@@ -154,3 +154,77 @@ def test_encoder_properties_the_reference_tests_check(orc):
             pytest.skip("Pillow not usable")
         back = np.load(os.path.join(d, "y.npy"))
     assert back.shape == (h, w) and np.abs(back - y.astype(int)).mean() < 3.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decoding: JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR) (lib/src/jpegdecoderhelper.cpp:188-516)
+# ---------------------------------------------------------------------------------------------------------------------
+_PIL_ENCODE = r"""
+import io, sys, numpy as np
+from PIL import Image
+d = np.load(sys.argv[1]); out = {}
+y, u, v = d["y"], d["u"], d["v"]
+ycc = np.stack([y, np.repeat(np.repeat(u, 2, 0), 2, 1), np.repeat(np.repeat(v, 2, 0), 2, 1)], -1)
+im = Image.fromarray(ycc, mode="YCbCr")
+def enc(img, **kw):
+    b = io.BytesIO(); img.save(b, "JPEG", **kw); return np.frombuffer(b.getvalue(), np.uint8)
+out["opt"] = enc(im, quality=80, subsampling=2, optimize=True)                       # non-default Huffman tables
+out["rst"] = enc(im, quality=90, subsampling=2, restart_marker_blocks=5)             # restart intervals
+out["rst_rows"] = enc(im, quality=60, subsampling=2, restart_marker_rows=1)
+out["gray_opt"] = enc(Image.fromarray(y, mode="L"), quality=85, optimize=True)
+out["prog"] = enc(im, quality=80, subsampling=2, progressive=True)                   # outside the restatement
+out["s444"] = enc(im, quality=80, subsampling=0)                                     # the reference rejects it
+np.savez(sys.argv[2], **out)
+"""
+
+
+def jpeg_corpus(orc, tmp_path=None):
+    """(name, jpeg bytes) pairs: the oracle encoder's own output over sizes / qualities / content, and (when Pillow is
+    usable) libjpeg-turbo files with optimised tables and restart markers"""
+    rng = np.random.RandomState(21)
+    corpus = []
+    for kind in ("smooth", "noise", "extreme", "flat"):
+        for (w, h), q in zip(SIZES, (90, 85, 50, 20, 100, 75, 95, 60, 1, 85, 92)):
+            y, u, v = _content(kind, w, h, rng)
+            uv = np.ascontiguousarray(np.concatenate([u.reshape(-1), v.reshape(-1)]))
+            corpus.append(("%s_%dx%d_q%d" % (kind, w, h, q), orc.jpeg_encode("orc", np.ascontiguousarray(y), uv, w, h, q)))
+            corpus.append(("%s_plane_%dx%d_q%d" % (kind, w, h, q), orc.jpeg_encode("orc", np.ascontiguousarray(y), None, w, h, q)))
+    extra = {}
+    if tmp_path is not None:
+        y, u, v = _content("smooth", 208, 112, rng)
+        np.savez(tmp_path / "pin.npz", y=y, u=u, v=v)
+        try:
+            subprocess.check_call([sys.executable, "-c", _PIL_ENCODE, str(tmp_path / "pin.npz"), str(tmp_path / "pout.npz")],
+                                  stderr=subprocess.DEVNULL)
+            res = np.load(tmp_path / "pout.npz")
+            extra = {k: res[k].tobytes() for k in res.files}
+        except (subprocess.CalledProcessError, OSError):
+            extra = {}
+    return corpus, extra
+
+
+def test_decoder_restatement_equals_libjpeg(orc, tmp_path):
+    if orc.load_libjpeg() is None:
+        pytest.skip("no libjpeg in this image")
+    corpus, extra = jpeg_corpus(orc, tmp_path)
+    for name, data in corpus + [(k, extra[k]) for k in ("opt", "rst", "rst_rows", "gray_opt") if k in extra]:
+        a = orc.jpeg_decode("orc", data)
+        b = orc.jpeg_decode("lj", data)
+        assert a[0] == b[0] > 0 and a[2:] == b[2:], (name, a[0], b[0])
+        assert np.array_equal(a[1], b[1]), (name, int((a[1] != b[1]).sum()))
+    if "prog" in extra:   # libjpeg reads progressive files; the restatement (and the device decoder) say "unsupported"
+        assert orc.jpeg_decode("lj", extra["prog"])[0] > 0 and orc.jpeg_decode("orc", extra["prog"])[0] == -2
+    if "s444" in extra:   # jpegdecoderhelper.cpp:256-262: only 4:2:0
+        assert orc.jpeg_decode("lj", extra["s444"])[0] == -2 and orc.jpeg_decode("orc", extra["s444"])[0] == -2
+    assert orc.jpeg_decode("orc", b"\xff\xd8\xff\xd9")[0] == -1 and orc.jpeg_decode("orc", b"notajpeg")[0] == -1
+
+
+def test_decode_of_encode_is_close_to_the_input(orc):
+    rng = np.random.RandomState(2)
+    w, h = 128, 96
+    y, u, v = _content("smooth", w, h, rng)
+    uv = np.ascontiguousarray(np.concatenate([u.reshape(-1), v.reshape(-1)]))
+    st, planes, dw, dh, gray = orc.jpeg_decode("orc", orc.jpeg_encode("orc", np.ascontiguousarray(y), uv, w, h, 95))
+    assert st == w * h * 3 // 2 and (dw, dh, gray) == (w, h, 0)
+    assert np.abs(planes[:w * h].astype(int) - y.reshape(-1)).mean() < 2.0
+    assert np.abs(planes[w * h:w * h * 5 // 4].astype(int) - u.reshape(-1)).mean() < 2.0

@@ -204,6 +204,23 @@ def other_configs(lib, stream):
         ms = (time.perf_counter() - t0) / 10 * 1e3
         out["JPEG encode " + name + (" (smooth synthetic content)" if sm is not None else " (LCG noise)")] = {
             "ms": round(ms, 3), "MPix/s": round(px / 1e6 / (ms * 1e-3), 1), "jpeg_bytes": int(jn.value)}
+    # ... and the decode side: JpegDecoderHelper::decompressImage(DECODE_TO_YCBCR) on the device (host JPEG bytes in, device planes out)
+    assert lib.uhdr_hip_jpeg_encode(C.byref(jimg), 95, None, 0, C.c_void_p(jout.data_ptr()), jout.numel(), C.byref(jn), api.MEM_DEVICE, stream) == 0
+    jbytes = jout[:int(jn.value)].cpu().numpy().copy()
+    dplanes = torch.zeros(W * H * 3 // 2, dtype=torch.uint8, device="cuda")
+    ddesc = api.Image()
+
+    def dec():
+        assert lib.uhdr_hip_jpeg_decode(C.c_void_p(jbytes.ctypes.data), jbytes.size, C.c_void_p(dplanes.data_ptr()), dplanes.numel(), C.byref(ddesc),
+                                        api.MEM_DEVICE, stream) == 0
+    for _ in range(3):
+        dec()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        dec()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    out["JPEG decode 4K YUV420 q95 (the file encoded above; host bytes in, device planes out)"] = {
+        "ms": round(ms, 3), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1), "jpeg_bytes": int(jbytes.size)}
     # configs[4]: 7680x4320 decode-side apply
     w8, h8 = 7680, 4320
     _, y8 = synth.lcg_frame(w8, h8, 1234)
@@ -272,8 +289,16 @@ def cpu_baseline(batch, fmt, nframes):
         jimg = api.Image(sm.data_ptr(), W, H, api.CG_BT709, sm.data_ptr() + W * H, W, W // 2, api.PIX_FMT_YUV420)
         rc = batch.lib.uhdr_hip_jpeg_encode(C.byref(jimg), 95, None, 0, C.c_void_p(jout.data_ptr()), jout.numel(), C.byref(jn), api.MEM_DEVICE, None)
         same = rc == 0 and jn.value == len(data) and jout[:jn.value].cpu().numpy().tobytes() == data
+        t0 = time.perf_counter()
+        dst, dplanes, _, _, _ = O.jpeg_decode("lj", data)
+        t_dec = time.perf_counter() - t0
+        gp = torch.zeros(W * H * 3 // 2, dtype=torch.uint8, device="cuda")
+        gd = api.Image()
+        dbuf = np.frombuffer(data, np.uint8)
+        rc = batch.lib.uhdr_hip_jpeg_decode(C.c_void_p(dbuf.ctypes.data), dbuf.size, C.c_void_p(gp.data_ptr()), gp.numel(), C.byref(gd), api.MEM_DEVICE, None)
+        same_dec = rc == 0 and dst > 0 and np.array_equal(gp.cpu().numpy(), dplanes)
         jpeg = {"libjpeg_4k_yuv420_q95_ms": round(t_cpu * 1e3, 2), "MPix/s": round(mpix / t_cpu, 1), "bytes": len(data), "threads": 1,
-                "gpu_bytes_identical": bool(same)}
+                "gpu_bytes_identical": bool(same), "libjpeg_decode_ms": round(t_dec * 1e3, 2), "gpu_decoded_planes_identical": bool(same_dec)}
     return {
         "jpeg_encode_cpu": jpeg,
         "value": round(nframes * mpix / (t_gen + t_app), 3), "unit": "MPix/s", "cores": ncpu, "kind": "port",

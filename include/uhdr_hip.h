@@ -206,6 +206,18 @@ int uhdr_hip_resize(const uhdr_hip_image_t* in_img, int out_width, int out_heigh
 int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void* icc, size_t icc_size, void* out,
                          size_t out_capacity, size_t* out_size, int mem_space, void* stream);
 
+/* JpegDecoderHelper::decompressImage(image, length, DECODE_TO_YCBCR) (lib/src/jpegdecoderhelper.cpp:188-516;
+ * lib/include/ultrahdr/jpegdecoderhelper.h:54-56): a baseline 4:2:0 YCbCr or grayscale JPEG (HOST memory) -> the bytes
+ * libjpeg returns with raw_data_out and JDCT_ISLOW, laid out as the reference's result buffer: width x height luma, then
+ * (4:2:0) the (width/2) x (height/2) Cb and Cr planes at width*height and width*height + width*height/4.  out lives in
+ * the memory space given by mem_space.  *desc is filled (data = out, chroma_data, strides, pixelFormat YUV420 or
+ * MONOCHROME) when the header is readable, also on ERROR_INSUFFICIENT_RESOURCE (out_capacity too small: width*height*3/2
+ * resp. width*height bytes are needed).  Huffman decoding (self-synchronising parallel decoder), dequantisation and IDCT
+ * run on the device.  ERROR_UNSUPPORTED_FEATURE: progressive / arithmetic / restart-interval files and samplings other
+ * than 4:2:0 (the last the reference rejects too, :256-262); UNKNOWN_ERROR: malformed file.  The call waits for the stream. */
+int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
+                         int mem_space, void* stream);
+
 /* ---- batches (device memory only, asynchronous on `stream`) ------------------------------ */
 /* The reference processes one image per call; a batch is n independent calls with identical
  * (hdr_tf, sdr_is_601 | metadata, output_format, max_display_boost).  Images of equal size share

@@ -578,6 +578,62 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
   return UHDR_HIP_NO_ERROR;
 }
 
+// JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR) (jpegdecoderhelper.cpp:188-327) on the device
+int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
+                         int mem_space, void* stream) {
+  if (jpeg == nullptr || desc == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  jpeg::DecInfo info;
+  const int prc = jpeg::parse_header(static_cast<const uint8_t*>(jpeg), jpeg_size, &info);
+  if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  if (prc != 0) return UHDR_HIP_UNKNOWN_ERROR;
+  const size_t w = (size_t)info.w, h = (size_t)info.h;
+  if (w > 8192 || h > 8192) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;   // kMaxWidth / kMaxHeight, jpegdecoderhelper.h:42-43
+  const size_t luma = w * h, chroma = luma / 4, need = info.gray ? luma : luma + 2 * chroma;
+  desc->data = out;
+  desc->width = w; desc->height = h;
+  desc->colorGamut = UHDR_HIP_CG_UNSPECIFIED;
+  desc->luma_stride = w;
+  desc->chroma_data = info.gray ? nullptr : static_cast<uint8_t*>(out) + luma;
+  desc->chroma_stride = info.gray ? 0 : w / 2;
+  desc->pixelFormat = info.gray ? UHDR_HIP_PIX_FMT_MONOCHROME : UHDR_HIP_PIX_FMT_YUV420;
+  if (out == nullptr || out_capacity < need) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lk(g_host_mu);
+
+  jpeg::DecLayout l;
+  const size_t ws_bytes = jpeg::dec_workspace_bytes(info, &l);
+  if ((rc = stage_reserve(st, 7, ws_bytes)) != 0) return rc;
+  uint8_t* ws = static_cast<uint8_t*>(st->stage[7]);
+  HIP_TRY(hipMemcpyAsync(ws + l.src, static_cast<const uint8_t*>(jpeg) + info.scan_offset, info.scan_bytes, hipMemcpyHostToDevice, s));
+  uint8_t* dout = static_cast<uint8_t*>(out);
+  if (mem_space != UHDR_HIP_MEM_DEVICE) {
+    if ((rc = stage_reserve(st, 5, need)) != 0) return rc;
+    dout = static_cast<uint8_t*>(st->stage[5]);
+  }
+  jpeg::DecPlane planes[3];
+  memset(planes, 0, sizeof(planes));
+  auto mk = [](uint8_t* p, size_t pw, size_t ph) {
+    jpeg::DecPlane q;
+    q.p = p; q.w = (int)pw; q.h = (int)ph; q.stride = (int)pw;
+    q.aligned8 = (reinterpret_cast<uintptr_t>(p) % 8 == 0 && pw % 8 == 0) ? 1 : 0;
+    return q;
+  };
+  planes[0] = mk(dout, w, h);
+  if (!info.gray) { planes[1] = mk(dout + luma, w / 2, h / 2); planes[2] = mk(dout + luma + chroma, w / 2, h / 2); }
+  hipError_t herr = hipSuccess;
+  const int drc = jpeg::decode_device(info, l, ws, planes, s, &herr);
+  if (drc > 0) { set_err("uhdr_hip_jpeg_decode", herr); return UHDR_HIP_UNKNOWN_ERROR; }
+  if (drc < 0) { snprintf(t_err, sizeof(t_err), "uhdr_hip_jpeg_decode: corrupt entropy-coded data"); return UHDR_HIP_UNKNOWN_ERROR; }
+  if (mem_space != UHDR_HIP_MEM_DEVICE) {
+    HIP_TRY(hipMemcpyAsync(out, dout, need, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
 int uhdr_hip_lut_table(int which, float* out, size_t capacity, size_t* count) {
   if (out == nullptr || count == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   DeviceState* st = nullptr;

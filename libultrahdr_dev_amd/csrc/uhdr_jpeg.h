@@ -45,5 +45,47 @@ size_t workspace_bytes(uint32_t nblk, Layout* l);
 // out + header_len, its total size (header included) in the uint64 at ws + l.totals + 8
 hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint64_t out_cap, uint64_t header_len, hipStream_t s);
 
+// ---- decoder (uhdr_jpeg_dec.hip) -------------------------------------------------------------------------------------
+struct HuffSpec {            // one DHT table in canonical form (T.81 Annex C)
+  uint16_t first_code[17];   // first code of each length (index = length)
+  uint16_t first_val[17];    // index into vals of that code
+  uint16_t count[17];
+  uint8_t vals[256];
+  int present;
+};
+struct DecTables { HuffSpec huff[4]; };   // [0] DC luma, [1] AC luma, [2] DC chroma, [3] AC chroma
+struct DecPlane {
+  uint8_t* p;
+  int w, h, stride;
+  int aligned8;
+};
+struct DecInfo {
+  int w, h, gray;
+  uint16_t quant[3][64];     // per component, zigzag order (as stored in the file)
+  DecTables tables;
+  int td[2], ta[2];
+  size_t scan_offset, scan_bytes;   // the entropy-coded segment inside the file
+};
+struct DecLayout {
+  size_t src, raw, kept, kept_off, lut, adv, st_a, st_b, dirty_a, dirty_b, nblocks, first_block, coef, dc[3], flags, scan_tmp, scan_tmp_bytes;
+  uint32_t nchunks, nsub_max, nblk, mcus_x;
+};
+struct DecJob {
+  const uint32_t* raw;       // unstuffed entropy-coded bits, big-endian words, zero padded
+  const uint16_t* lut;       // 4 x 65536 (length << 8 | symbol)
+  const uint16_t* adv;       // 4 x 65536 position-only entries (see k_jd_build_lut)
+  uint32_t total_bits, nsub, nblk, mcus_x;
+  int gray;
+  uint32_t dc_tbl[2], ac_tbl[2];
+  int16_t* coef;             // nblk x 64, zigzag order
+  DecPlane plane[3];
+  uint16_t quant[3][64];
+};
+// 0 ok, -1 malformed, -2 outside what this decoder (or the reference: sampling) supports
+int parse_header(const uint8_t* jpg, size_t n, DecInfo* info);
+size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l);
+// the entropy-coded segment must already sit at ws + l.src; 0 ok, -1 corrupt stream, 1 HIP error (*herr)
+int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr);
+
 }  // namespace jpeg
 }  // namespace uhdr

@@ -1,0 +1,627 @@
+// uhdr_jpeg_dec.hip -- baseline JPEG decompression on the GPU (decode side).
+//
+// Drop-in for the reference's JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR)
+// (lib/src/jpegdecoderhelper.cpp:188-327 + decompressYUV :352-448, decompressSingleChannel :450-516): a 4:2:0 YCbCr or a
+// grayscale baseline JPEG -> the w x h luma plane followed by the (w/2) x (h/2) Cb and Cr planes, the bytes libjpeg
+// returns with raw_data_out and JDCT_ISLOW.  This is the step in front of applyGainMap on the decode path (jpegr.cpp:796-801).
+//
+// A baseline scan without restart markers is ONE bit string: where a code starts is only known once everything before
+// it has been decoded.  The decoder uses the self-synchronisation of Huffman codes (Klein & Wiseman 2003; Weissenberger &
+// Schmidt 2018): a decoder started at a wrong bit position falls in step with the true decoder after a few symbols.
+//   k_jd_unstuff_*   drop the 0x00 after every 0xFF (count per 256-byte chunk, scan, compact) -> raw bit string
+//   k_jd_build_lut   16-bit lookup tables (length, symbol) of the file's own Huffman tables
+//   k_jd_sync<0>     every thread decodes one 512-bit subsequence from a guessed state (block 0, coefficient 0) and
+//                    records the state (bit, block-in-MCU, coefficient) it crosses the subsequence's end with
+//   k_jd_sync<1>     rounds: thread i re-decodes subsequence i from the end state of i-1 (only if that state changed);
+//                    when no end state changes any more, every subsequence's start state is the true one (thread 0
+//                    starts from the true state).  Bit and coefficient position fall in step within tens of bits, the
+//                    block-in-MCU index (which decides luma vs. chroma tables) only after ~7 MCUs of a 4:2:0 file, so
+//                    a 4K frame takes 5-8 rounds at quality 75 and 21-24 at quality 95; a round is one lane decoding
+//                    512 bits (~25 us), whatever the number of subsequences: that product is the decoder's latency.
+//   (scan of the blocks completed per subsequence -> index of the block each subsequence starts in)
+//   k_jd_write       final decode from the true start states: DC differences and AC values into zeroed coefficient blocks
+//   (three masked scans turn DC differences into DC values per component)
+//   k_jd_idct        one thread per block: dequantise, "islow" IDCT, +128, clamp, store cropped to the plane
+// Files with restart intervals, progressive or arithmetic-coded files and samplings other than 4:2:0 / grayscale return
+// UHDR_HIP_ERROR_UNSUPPORTED_FEATURE (the reference's encoder never writes the first three; it rejects the last itself).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstring>
+
+#include "uhdr_jpeg.h"
+
+namespace uhdr {
+namespace jpeg {
+
+#ifndef UHDR_JD_SUBBITS
+#define UHDR_JD_SUBBITS 512
+#endif
+constexpr uint32_t kSubBits = UHDR_JD_SUBBITS;   // bits per subsequence
+constexpr uint32_t kUnstuffChunk = 64;  // bytes per thread in the unstuffing passes
+
+// ---- unstuffing ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, uint32_t n, uint32_t* kept) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t b0 = t * kUnstuffChunk;
+  if (b0 >= n) return;
+  const uint32_t len = n - b0 < kUnstuffChunk ? n - b0 : kUnstuffChunk;
+  uint32_t k = 0;
+  uint8_t prev = b0 ? src[b0 - 1] : 0;
+  for (uint32_t i = 0; i < len; ++i) {
+    const uint8_t v = src[b0 + i];
+    k += !(v == 0 && prev == 0xFF);
+    prev = v;
+  }
+  kept[t] = k;
+}
+// a workgroup compacts its 16 KiB into LDS and writes the run out as aligned dwords (its start in `dst` is arbitrary)
+__global__ void __launch_bounds__(256) k_jd_unstuff_copy(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst) {
+  __shared__ uint8_t s_buf[256 * kUnstuffChunk + 8];
+  __shared__ uint32_t s_len;
+  const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
+  const uint32_t blk_b0 = first * kUnstuffChunk;
+  if (blk_b0 >= n) return;
+  const uint32_t base = off[first];
+  const uint32_t b0 = t * kUnstuffChunk;
+  if (threadIdx.x == 0) s_len = 0u;
+  __syncthreads();
+  if (b0 < n) {
+    const uint32_t len = n - b0 < kUnstuffChunk ? n - b0 : kUnstuffChunk;
+    uint32_t lo = off[t] - base;
+    uint8_t prev = b0 ? src[b0 - 1] : 0;
+    const uint4* q = reinterpret_cast<const uint4*>(src + b0);     // src is 256-byte aligned, chunks are 64 bytes
+#pragma unroll
+    for (uint32_t k4 = 0; k4 < kUnstuffChunk / 16u; ++k4) {
+      const uint4 v = q[k4];                                       // (may read up to 15 bytes past n inside the workspace)
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (uint32_t k = 0; k < 16u; ++k) {
+        const uint8_t by = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
+        if (k4 * 16u + k < len) {
+          if (!(by == 0 && prev == 0xFF)) s_buf[lo++] = by;
+          prev = by;
+        }
+      }
+    }
+    if (b0 + len == n || threadIdx.x == 255u) s_len = lo;
+  }
+  __syncthreads();
+  const uint32_t len = s_len;
+  uint8_t* d0 = dst + base;
+  const uint32_t head = (uint32_t)((4u - (reinterpret_cast<uintptr_t>(d0) & 3u)) & 3u);
+  const uint32_t head_n = head < len ? head : len;
+  if (threadIdx.x < head_n) d0[threadIdx.x] = s_buf[threadIdx.x];
+  const uint32_t nwords = (len - head_n) >> 2;
+  for (uint32_t k = threadIdx.x; k < nwords; k += 256u) {
+    const uint32_t o = head_n + 4u * k;
+    *reinterpret_cast<uint32_t*>(d0 + o) = (uint32_t)s_buf[o] | ((uint32_t)s_buf[o + 1] << 8) | ((uint32_t)s_buf[o + 2] << 16) | ((uint32_t)s_buf[o + 3] << 24);
+  }
+  const uint32_t tail0 = head_n + 4u * nwords;
+  if (threadIdx.x < len - tail0) d0[tail0 + threadIdx.x] = s_buf[tail0 + threadIdx.x];
+}
+
+constexpr uint32_t kFastBitsEarly = 9;   // == kFastBits (first-level table width), needed before its definition
+// ---- Huffman lookup tables -----------------------------------------------------------------------------------------
+// entry x (the next 16 bits of the stream): (code length << 8) | symbol, 0 when no code matches
+// adv[x]: what the position-only passes need from a symbol, in one 16-bit entry: bit 15 = the code is longer than
+// kFastBits, bits 8..12 = bits consumed (code + value bits, <= 27), bits 0..6 = advance of the coefficient index
+// (DC: 1; AC: run + 1, ZRL 16, EOB 64).  No code: one bit consumed, index unchanged.
+__global__ void __launch_bounds__(256) k_jd_build_lut(const DecTables t, uint16_t* lut, uint16_t* adv) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;   // 4 tables x 65536
+  const uint32_t tb = g >> 16, x = g & 0xFFFFu;
+  const HuffSpec& h = t.huff[tb];
+  uint16_t e = 0;
+  if (h.present) {
+#pragma unroll 1
+    for (uint32_t l = 1; l <= 16u; ++l) {
+      const uint32_t code = x >> (16u - l);
+      if (code >= h.first_code[l] && code - h.first_code[l] < h.count[l]) {
+        e = (uint16_t)((l << 8) | h.vals[h.first_val[l] + code - h.first_code[l]]);
+        break;
+      }
+    }
+  }
+  lut[g] = e;
+  const uint32_t len = e >> 8, sym = e & 0xFFu, vb = sym & 15u, r = sym >> 4;
+  uint32_t a = (1u << 8);   // no code
+  if (len != 0u) {
+    const uint32_t dz = (tb & 1u) == 0u ? 1u : (vb != 0u ? r + 1u : (r == 15u ? 16u : 64u));
+    a = ((len > kFastBitsEarly ? 1u : 0u) << 15) | ((len + vb) << 8) | dz;
+  }
+  adv[g] = (uint16_t)a;
+}
+
+// ---- the sequential decoder one thread runs over a stretch of bits ------------------------------------------------------
+struct DState { uint32_t p; uint32_t cz; };   // bit position; (block-in-MCU << 8) | coefficient index
+__device__ __forceinline__ int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }   // T.81 F.2.2.1
+
+// A symbol costs two dependent memory reads (stream bits, then the code table); from L2 that is ~1000 cycles per symbol.
+// So: the bit window lives in registers (64 bits, refilled one word at a time, the word after next already in flight) and
+// the first kFastBits bits of every code are looked up in LDS; only longer codes go to the 16-bit table in global memory.
+constexpr uint32_t kFastBits = kFastBitsEarly;
+struct Reader {
+  const uint32_t* words;
+  uint64_t win;     // bits [base, base + 64) of the stream, MSB first
+  uint32_t nextw;   // bits [base + 64, base + 96), still in memory byte order (swapped on use: the load stays in flight)
+  uint32_t base;    // multiple of 32
+  __device__ __forceinline__ void init(const uint32_t* w, uint32_t p) {
+    words = w;
+    const uint32_t i = p >> 5;
+    base = i << 5;
+    win = ((uint64_t)__builtin_bswap32(w[i]) << 32) | (uint64_t)__builtin_bswap32(w[i + 1]);
+    nextw = w[i + 2];
+  }
+  __device__ __forceinline__ void advance_to(uint32_t p) {   // p - base < 64
+    if (p - base >= 32u) {
+      win = (win << 32) | (uint64_t)__builtin_bswap32(nextw);
+      base += 32u;
+      nextw = words[(base >> 5) + 2u];
+    }
+  }
+};
+
+// One symbol.  MODE 0: advance only; MODE 1: also report the coefficient (position zpos, value val; has = true).
+// A bit pattern that is no code (only possible off-sync, or in a corrupt file) consumes one bit: any deterministic rule
+// will do for the synchronisation, and the final pass flags it.
+template <int MODE>
+__device__ __forceinline__ bool step(const DecJob& j, const uint16_t (*s_lut)[1u << kFastBits], Reader& rd, DState& s,
+                                     bool& block_done, int& zpos, int& val, bool& has) {
+  const uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
+  const uint32_t comp_chroma = j.gray ? 0u : (c >= 4u ? 1u : 0u);
+  const uint32_t tb = 2u * comp_chroma + (z != 0u ? 1u : 0u);   // slots: 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma (no table in memory: a
+                                                                 // lane-indexed kernel-argument array is a ~500-cycle load per symbol)
+  const uint32_t sh = s.p - rd.base;
+  const uint64_t w = rd.win;
+  const uint32_t peek = (uint32_t)(w >> (48u - sh)) & 0xFFFFu;
+  uint32_t e = s_lut[tb][peek >> (16u - kFastBits)];
+  if (e == 0u) e = j.lut[(tb << 16) | peek];
+  const uint32_t len = e >> 8, sym = e & 0xFFu;
+  block_done = false;
+  has = false;
+  bool ok = true;
+  if (len == 0u) { s.p += 1u; rd.advance_to(s.p); return false; }
+  uint32_t nz = z, vbits = 0;
+  if (z == 0u) {
+    vbits = sym & 15u;
+    nz = 1u;
+    if (MODE == 1) { zpos = 0; has = true; }
+  } else {
+    const uint32_t r = sym >> 4;
+    vbits = sym & 15u;
+    if (vbits == 0u) {
+      if (r == 15u) nz = z + 16u;
+      else nz = 64u;                       // EOB
+    } else {
+      nz = z + r;
+      if (MODE == 1) { zpos = (int)nz; has = nz < 64u; }
+      ok = nz < 64u;
+      nz += 1u;
+    }
+  }
+  if (MODE == 1 && has) {
+    const int raw = vbits ? (int)((w >> (64u - sh - len - vbits)) & ((1u << vbits) - 1u)) : 0;
+    val = vbits ? extend(raw, (int)vbits) : 0;
+  }
+  s.p += len + vbits;
+  rd.advance_to(s.p);
+  if (nz >= 64u) { block_done = true; nz = 0u; }
+  const uint32_t bpm = j.gray ? 1u : 6u;
+  const uint32_t nc = block_done ? (c + 1u == bpm ? 0u : c + 1u) : c;
+  s.cz = (nc << 8) | nz;
+  return ok;
+}
+
+// The position-only form of step() for the synchronisation passes: no branches but the rare long-code lookup.
+__device__ __forceinline__ void step_pos(const DecJob& j, const uint16_t (*s_adv)[1u << kFastBits], Reader& rd, DState& s, uint32_t& blocks) {
+  const uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
+  const uint32_t tb = (j.gray ? 0u : (c >= 4u ? 2u : 0u)) + (z != 0u ? 1u : 0u);
+  const uint32_t sh = s.p - rd.base;
+  const uint32_t peek = (uint32_t)(rd.win >> (48u - sh)) & 0xFFFFu;
+  uint32_t a = s_adv[tb][peek >> (16u - kFastBits)];
+  if (a & 0x8000u) a = j.adv[(tb << 16) | peek];
+  s.p += (a >> 8) & 31u;
+  rd.advance_to(s.p);
+  uint32_t nz = z + (a & 127u);
+  const bool done = nz >= 64u;
+  nz = done ? 0u : nz;
+  const uint32_t bpm = j.gray ? 1u : 6u;
+  const uint32_t nc = done ? (c + 1u == bpm ? 0u : c + 1u) : c;
+  blocks += done ? 1u : 0u;
+  s.cz = (nc << 8) | nz;
+}
+__device__ __forceinline__ void load_fast_adv(const DecJob& j, uint16_t (*s_adv)[1u << kFastBits]) {
+  for (uint32_t g = threadIdx.x; g < 4u << kFastBits; g += blockDim.x) {
+    const uint32_t tb = g >> kFastBits, x = g & ((1u << kFastBits) - 1u);
+    // final only for a code of at most kFastBits bits; "no code" for this particular completion says nothing about the others
+    const uint16_t a = j.adv[(tb << 16) | (x << (16u - kFastBits))];
+    s_adv[tb][x] = (a == (uint16_t)0x0100u) ? (uint16_t)0x8000u : a;
+  }
+  __syncthreads();
+}
+
+// workgroup prologue: the first-level tables (codes of at most kFastBits bits; 0 = look in the full table)
+__device__ __forceinline__ void load_fast_lut(const DecJob& j, uint16_t (*s_lut)[1u << kFastBits]) {
+  for (uint32_t g = threadIdx.x; g < 4u << kFastBits; g += blockDim.x) {
+    const uint32_t tb = g >> kFastBits, x = g & ((1u << kFastBits) - 1u);
+    const uint16_t e = j.lut[(tb << 16) | (x << (16u - kFastBits))];
+    s_lut[tb][x] = (e >> 8) <= kFastBits ? e : (uint16_t)0;
+  }
+  __syncthreads();
+}
+
+// ROUND 0: start from the guess (subsequence start, block 0, coefficient 0); ROUND 1: start from the end state of the
+// previous subsequence as of the last round.  Both: decode until the subsequence's end is crossed, record the state.
+// Only subsequences whose start state changed in the previous round are decoded again (dirty_in).
+template <int ROUND>
+__global__ void __launch_bounds__(256) k_jd_sync(const DecJob j, const DState* prev, DState* next, const uint8_t* dirty_in,
+                                                 uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {
+  __shared__ uint16_t s_adv[4][1u << kFastBits];
+  load_fast_adv(j, s_adv);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= j.nsub) return;
+  if (ROUND == 1 && (i == 0u || !dirty_in[i])) {
+    next[i] = prev[i];
+    dirty_out[i + 1u] = 0;
+    return;
+  }
+  DState s;
+  if (i == 0u) { s.p = 0u; s.cz = 0u; }
+  else if (ROUND == 0) { s.p = i * kSubBits; s.cz = 0u; }
+  else s = prev[i - 1u];
+  const uint32_t end = (i + 1u) * kSubBits < j.total_bits ? (i + 1u) * kSubBits : j.total_bits;
+  Reader rd;
+  rd.init(j.raw, s.p);
+  uint32_t nb = 0;
+  while (s.p < end) step_pos(j, s_adv, rd, s, nb);
+  uint8_t ch = 1;
+  if (ROUND == 1) {
+    const DState old = prev[i];
+    ch = (old.p != s.p || old.cz != s.cz) ? 1 : 0;
+    if (ch) *changed = 1u;
+  }
+  next[i] = s;
+  nblocks[i] = nb;            // blocks completed inside this subsequence, valid once its start state is the true one
+  dirty_out[i + 1u] = ch;     // the next subsequence starts from a new state
+}
+
+__global__ void __launch_bounds__(256) k_jd_write(const DecJob j, const DState* st, const uint32_t* first_block, uint32_t* error) {
+  __shared__ uint16_t s_lut[4][1u << kFastBits];
+  load_fast_lut(j, s_lut);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= j.nsub) return;
+  DState s;
+  if (i == 0u) { s.p = 0u; s.cz = 0u; } else s = st[i - 1u];
+  const uint32_t end = (i + 1u) * kSubBits < j.total_bits ? (i + 1u) * kSubBits : j.total_bits;
+  Reader rd;
+  rd.init(j.raw, s.p);
+  uint32_t blk = first_block[i];
+  bool bd, has;
+  int zp = 0, v = 0;
+  while (s.p < end && blk < j.nblk) {
+    const bool ok = step<1>(j, s_lut, rd, s, bd, zp, v, has);
+    if (!ok) *error = 1u;
+    if (has) j.coef[(size_t)blk * 64u + (uint32_t)zp] = (int16_t)v;
+    blk += bd;
+  }
+  if (i == j.nsub - 1u && (blk != j.nblk || s.p > j.total_bits)) *error = 1u;   // the scan must end exactly after the last block
+}
+
+// ---- DC prediction: value = running sum of the differences of the same component ---------------------------------------
+struct DcPick {
+  const int16_t* coef;
+  int comp, gray;
+  __host__ __device__ int operator()(uint32_t b) const {
+    const int c = gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
+    return c == comp ? (int)coef[(size_t)b * 64u] : 0;
+  }
+};
+__global__ void __launch_bounds__(256) k_jd_dc_apply(const DecJob j, const int* sum0, const int* sum1, const int* sum2) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b >= j.nblk) return;
+  const int c = j.gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
+  const int* s = c == 0 ? sum0 : (c == 1 ? sum1 : sum2);
+  j.coef[(size_t)b * 64u] = (int16_t)s[b];
+}
+
+// ---- dequantisation + IDCT -----------------------------------------------------------------------------------------
+__device__ __forceinline__ int dscale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+template <int PASS>
+__device__ __forceinline__ void idct8(int (&d)[64], int base, int stride) {   // libjpeg jidctint.c
+  int z2 = d[base + 2 * stride], z3 = d[base + 6 * stride];
+  int z1 = (z2 + z3) * 4433;
+  int tmp2 = z1 + z3 * (-15137), tmp3 = z1 + z2 * 6270;
+  z2 = d[base]; z3 = d[base + 4 * stride];
+  int tmp0 = (z2 + z3) << 13, tmp1 = (z2 - z3) << 13;
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = d[base + 7 * stride]; tmp1 = d[base + 5 * stride]; tmp2 = d[base + 3 * stride]; tmp3 = d[base + stride];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int z4 = tmp1 + tmp3;
+  const int z5 = (z3 + z4) * 9633;
+  tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
+  z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  constexpr int sh = PASS == 0 ? 11 : 18;
+  d[base] = dscale(tmp10 + tmp3, sh); d[base + 7 * stride] = dscale(tmp10 - tmp3, sh);
+  d[base + stride] = dscale(tmp11 + tmp2, sh); d[base + 6 * stride] = dscale(tmp11 - tmp2, sh);
+  d[base + 2 * stride] = dscale(tmp12 + tmp1, sh); d[base + 5 * stride] = dscale(tmp12 - tmp1, sh);
+  d[base + 3 * stride] = dscale(tmp13 + tmp0, sh); d[base + 4 * stride] = dscale(tmp13 - tmp0, sh);
+}
+
+__global__ void __launch_bounds__(128) k_jd_idct(const DecJob j) {
+  const uint32_t b = blockIdx.x * 128u + threadIdx.x;
+  if (b >= j.nblk) return;
+  int comp, br, bc;
+  if (j.gray) { comp = 0; br = (int)(b / j.mcus_x); bc = (int)(b - (uint32_t)br * j.mcus_x); }
+  else {
+    const uint32_t mcu = b / 6u, k = b - mcu * 6u;
+    const int mr = (int)(mcu / j.mcus_x), mc = (int)(mcu - (uint32_t)mr * j.mcus_x);
+    if (k < 4u) { comp = 0; br = 2 * mr + (int)(k >> 1); bc = 2 * mc + (int)(k & 1u); }
+    else { comp = (int)k - 3; br = mr; bc = mc; }
+  }
+  const DecPlane& pl = j.plane[comp];
+  if (br * 8 >= pl.h || bc * 8 >= pl.w) return;      // a dummy block of the encoder: nothing of it is inside the image
+  const uint16_t* q = j.quant[comp];                 // zigzag order
+  constexpr uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                               41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  int d[64];
+  const uint4* src = reinterpret_cast<const uint4*>(j.coef + (size_t)b * 64u);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint4 v = src[k];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      d[nat[8 * k + 2 * m]] = (int)(int16_t)(w[m] & 0xffffu) * (int)q[8 * k + 2 * m];
+      d[nat[8 * k + 2 * m + 1]] = (int)(int16_t)(w[m] >> 16) * (int)q[8 * k + 2 * m + 1];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) idct8<0>(d, c, 8);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) idct8<1>(d, r * 8, 1);
+  uint8_t* dst = pl.p + (size_t)(br * 8) * pl.stride + bc * 8;
+  const bool whole = br * 8 + 8 <= pl.h && bc * 8 + 8 <= pl.w && pl.aligned8;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    uint32_t o[2] = {0u, 0u};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      int x = d[r * 8 + c] + 128;
+      x = x < 0 ? 0 : (x > 255 ? 255 : x);
+      o[c >> 2] |= (uint32_t)x << (8 * (c & 3));
+    }
+    if (whole) *reinterpret_cast<uint2*>(dst + (size_t)r * pl.stride) = make_uint2(o[0], o[1]);
+    else if (br * 8 + r < pl.h)
+      for (int c = 0; c < 8; ++c)
+        if (bc * 8 + c < pl.w) dst[(size_t)r * pl.stride + c] = (uint8_t)(o[c >> 2] >> (8 * (c & 3)));
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+static unsigned rd16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
+  if (jpg == nullptr || n < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return -1;
+  memset(info, 0, sizeof(*info));
+  static const uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                  41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                  30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  (void)nat;
+  uint16_t quant[4][64];   // zigzag order, as stored in the file
+  bool have_q[4] = {false, false, false, false};
+  HuffSpec huff[2][4];
+  memset(huff, 0, sizeof(huff));
+  int nc = 0, hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, cid[3] = {0, 0, 0};
+  size_t pos = 2;
+  for (;;) {
+    while (pos + 1 < n && jpg[pos] == 0xFF && jpg[pos + 1] == 0xFF) pos++;
+    if (pos + 4 > n || jpg[pos] != 0xFF) return -1;
+    const unsigned m = jpg[pos + 1];
+    const size_t len = rd16(jpg + pos + 2);
+    const uint8_t* seg = jpg + pos + 4;
+    if (len < 2 || pos + 2 + len > n) return -1;
+    if (m == 0xDB) {
+      for (size_t o = 0; o + 1 <= len - 2;) {
+        const int pq = seg[o] >> 4, id = seg[o] & 15;
+        const size_t sz = pq ? 128 : 64;
+        if (id > 3 || o + 1 + sz > len - 2) return -1;
+        for (int i = 0; i < 64; ++i) quant[id][i] = pq ? (uint16_t)rd16(seg + o + 1 + 2 * i) : seg[o + 1 + i];
+        have_q[id] = true;
+        o += 1 + sz;
+      }
+    } else if (m == 0xC4) {
+      for (size_t o = 0; o + 17 <= len - 2;) {
+        const int cls = seg[o] >> 4, id = seg[o] & 15;
+        int cnt = 0;
+        for (int i = 0; i < 16; ++i) cnt += seg[o + 1 + i];
+        if (cls > 1 || id > 3 || cnt > 256 || o + 17 + (size_t)cnt > len - 2) return -1;
+        HuffSpec& h = huff[cls][id];
+        memset(&h, 0, sizeof(h));
+        uint32_t code = 0, p = 0;
+        for (int l = 1; l <= 16; ++l) {   // T.81 Annex C
+          h.first_code[l] = (uint16_t)code;
+          h.first_val[l] = (uint16_t)p;
+          h.count[l] = seg[o + l];
+          code += h.count[l];
+          p += h.count[l];
+          code <<= 1;
+        }
+        memcpy(h.vals, seg + o + 17, (size_t)cnt);
+        h.present = 1;
+        o += 17 + (size_t)cnt;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (len < 8 || seg[0] != 8) return -2;
+      info->h = (int)rd16(seg + 1); info->w = (int)rd16(seg + 3); nc = seg[5];
+      if (nc != 1 && nc != 3) return -2;
+      if (len < (size_t)(8 + 3 * nc)) return -1;
+      for (int c = 0; c < nc; ++c) { cid[c] = seg[6 + 3 * c]; hs[c] = seg[7 + 3 * c] >> 4; vs[c] = seg[7 + 3 * c] & 15; tq[c] = seg[8 + 3 * c]; }
+    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      return -2;   // progressive, lossless, arithmetic: libjpeg reads some of these, this decoder does not
+    } else if (m == 0xDD) {
+      if (rd16(seg) != 0) return -2;   // restart intervals
+    } else if (m == 0xDA) {
+      if (nc == 0 || seg[0] != nc || len < (size_t)(6 + 2 * nc)) return -2;
+      info->gray = nc == 1;
+      if (!info->gray && !(hs[0] == 2 && vs[0] == 2 && hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1)) return -2;   // :256-262
+      if (info->w <= 0 || info->h <= 0) return -1;
+      for (int c = 0; c < nc; ++c) {
+        if (seg[1 + 2 * c] != cid[c]) return -2;
+        const int td = seg[2 + 2 * c] >> 4, ta = seg[2 + 2 * c] & 15;
+        if (td > 3 || ta > 3 || !huff[0][td].present || !huff[1][ta].present || tq[c] > 3 || !have_q[tq[c]]) return -1;
+        memcpy(info->quant[c], quant[tq[c]], sizeof(quant[0]));
+        if (c <= 1) {   // luma tables in slots 0 (DC) / 1 (AC), chroma in 2 / 3; Cr must share Cb's tables
+          info->tables.huff[2 * c] = huff[0][td];
+          info->tables.huff[2 * c + 1] = huff[1][ta];
+          info->td[c] = td; info->ta[c] = ta;
+        } else if (td != info->td[1] || ta != info->ta[1]) {
+          return -2;
+        }
+      }
+      info->scan_offset = pos + 2 + len;
+      // the entropy-coded segment ends at the first marker that is neither a stuffed zero nor a fill byte
+      size_t e = info->scan_offset;
+      for (;;) {   // memchr: the segment is megabytes long and 0xFF is rare in it
+        const void* f = e + 1 < n ? memchr(jpg + e, 0xFF, n - 1 - e) : nullptr;
+        if (f == nullptr) return -1;
+        e = (size_t)(static_cast<const uint8_t*>(f) - jpg);
+        if (jpg[e + 1] != 0x00 && jpg[e + 1] != 0xFF) break;
+        e += jpg[e + 1] == 0x00 ? 2 : 1;
+      }
+      if ((jpg[e + 1] & 0xF8) == 0xD0) return -2;   // RSTn without DRI cannot happen in a valid file
+      info->scan_bytes = e - info->scan_offset;
+      return 0;
+    } else if (m == 0xD9) {
+      return -1;
+    }
+    pos += 2 + len;
+  }
+}
+
+size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const uint32_t w = (uint32_t)info.w, h = (uint32_t)info.h;
+  l->mcus_x = info.gray ? (w + 7) / 8 : (w + 15) / 16;
+  const uint32_t mcus_y = info.gray ? (h + 7) / 8 : (h + 15) / 16;
+  l->nblk = l->mcus_x * mcus_y * (info.gray ? 1u : 6u);
+  const size_t nbytes = info.scan_bytes;
+  l->nchunks = (uint32_t)((nbytes + kUnstuffChunk - 1) / kUnstuffChunk);
+  l->nsub_max = (uint32_t)((nbytes * 8 + kSubBits - 1) / kSubBits) + 1u;
+  size_t o = 0;
+  l->src = o; o += up(nbytes + 16);
+  l->raw = o; o += up(nbytes + 64);
+  l->kept = o; o += up((size_t)(l->nchunks + 1) * 4);
+  l->kept_off = o; o += up((size_t)(l->nchunks + 1) * 4);
+  l->lut = o; o += up((size_t)4 * 65536 * 2);
+  l->adv = o; o += up((size_t)4 * 65536 * 2);
+  l->st_a = o; o += up((size_t)l->nsub_max * sizeof(DState));
+  l->st_b = o; o += up((size_t)l->nsub_max * sizeof(DState));
+  l->dirty_a = o; o += up((size_t)l->nsub_max + 2);
+  l->dirty_b = o; o += up((size_t)l->nsub_max + 2);
+  l->nblocks = o; o += up((size_t)(l->nsub_max + 1) * 4);
+  l->first_block = o; o += up((size_t)(l->nsub_max + 1) * 4);
+  l->coef = o; o += up((size_t)l->nblk * 128);
+  l->dc[0] = o; o += up((size_t)l->nblk * 4);
+  l->dc[1] = o; o += up((size_t)l->nblk * 4);
+  l->dc[2] = o; o += up((size_t)l->nblk * 4);
+  l->flags = o; o += 256;   // [0] changed, [1] error, [2] raw byte count
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nchunks + 1));
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nsub_max + 1));
+  {
+    hipcub::CountingInputIterator<uint32_t> cnt(0u);
+    hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{nullptr, 0, 0});
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, t3, it, (int*)nullptr, (int)l->nblk);
+  }
+  l->scan_tmp_bytes = up((t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3)) + 256);
+  l->scan_tmp = o; o += l->scan_tmp_bytes;
+  return o;
+}
+
+// Runs the whole decoder on `s` (synchronises: the number of synchronisation rounds is data dependent).
+// src_dev: the entropy-coded segment already in device memory at ws + l.src.  Returns 0, -1 (corrupt) or a hipError_t > 0.
+int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr) {
+#define JD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *herr = _e; return 1; } } while (0)
+  const uint32_t nbytes = (uint32_t)info.scan_bytes;
+  uint8_t* src = ws + l.src;
+  uint8_t* raw = ws + l.raw;
+  uint32_t* kept = reinterpret_cast<uint32_t*>(ws + l.kept);
+  uint32_t* kept_off = reinterpret_cast<uint32_t*>(ws + l.kept_off);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(ws + l.flags);
+  JD_TRY(hipMemsetAsync(flags, 0, 256, s));
+  JD_TRY(hipMemsetAsync(raw, 0, ((size_t)nbytes + 64 + 255) / 256 * 256, s));
+  JD_TRY(hipMemsetAsync(kept + l.nchunks, 0, 4, s));
+  const dim3 gu((l.nchunks + 255u) / 256u), b256(256);
+  hipLaunchKernelGGL(k_jd_unstuff_count, gu, b256, 0, s, src, nbytes, kept);
+  size_t tmp = l.scan_tmp_bytes;
+  JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, kept, kept_off, (int)(l.nchunks + 1u), s));
+  hipLaunchKernelGGL(k_jd_unstuff_copy, gu, b256, 0, s, src, nbytes, kept_off, raw);
+  uint32_t raw_bytes = 0;
+  JD_TRY(hipMemcpyAsync(&raw_bytes, kept_off + l.nchunks, 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_jd_build_lut, dim3(4u * 65536u / 256u), b256, 0, s, info.tables, reinterpret_cast<uint16_t*>(ws + l.lut),
+                     reinterpret_cast<uint16_t*>(ws + l.adv));
+  JD_TRY(hipStreamSynchronize(s));
+
+  DecJob j;
+  memset(&j, 0, sizeof(j));
+  j.raw = reinterpret_cast<const uint32_t*>(raw);
+  j.lut = reinterpret_cast<const uint16_t*>(ws + l.lut);
+  j.adv = reinterpret_cast<const uint16_t*>(ws + l.adv);
+  j.total_bits = raw_bytes * 8u;
+  j.nsub = (j.total_bits + kSubBits - 1u) / kSubBits;
+  if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
+  j.gray = info.gray;
+  j.nblk = l.nblk;
+  j.mcus_x = l.mcus_x;
+  j.dc_tbl[0] = 0; j.ac_tbl[0] = 1; j.dc_tbl[1] = 2; j.ac_tbl[1] = 3;
+  j.coef = reinterpret_cast<int16_t*>(ws + l.coef);
+  for (int c = 0; c < 3; ++c) { j.plane[c] = planes[c]; memcpy(j.quant[c], info.quant[c], sizeof(j.quant[c])); }
+  DState* sa = reinterpret_cast<DState*>(ws + l.st_a);
+  DState* sb = reinterpret_cast<DState*>(ws + l.st_b);
+  const dim3 gs((j.nsub + 255u) / 256u);
+  uint8_t* da = ws + l.dirty_a;
+  uint8_t* db = ws + l.dirty_b;
+  uint32_t* nblocks = reinterpret_cast<uint32_t*>(ws + l.nblocks);
+  hipLaunchKernelGGL(k_jd_sync<0>, gs, b256, 0, s, j, (const DState*)nullptr, sa, (const uint8_t*)nullptr, da, nblocks, flags);
+  // rounds until a round changes nothing; kRoundsPerCheck rounds are enqueued per host check (a converged round costs a launch)
+  constexpr uint32_t kRoundsPerCheck = 4;
+  for (uint32_t round = 0;; round += kRoundsPerCheck) {
+    if (round > j.nsub + kRoundsPerCheck) return -1;   // cannot happen: every round fixes at least one more subsequence
+    for (uint32_t r = 0; r < kRoundsPerCheck; r += 2) {
+      if (r == kRoundsPerCheck - 2) JD_TRY(hipMemsetAsync(flags, 0, 4, s));   // only the last pair of the batch decides
+      hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sa, sb, (const uint8_t*)da, db, nblocks, flags);
+      hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sb, sa, (const uint8_t*)db, da, nblocks, flags);
+    }
+    uint32_t changed = 0;
+    JD_TRY(hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, s));
+    JD_TRY(hipStreamSynchronize(s));
+    if (!changed) break;
+  }
+  uint32_t* first_block = reinterpret_cast<uint32_t*>(ws + l.first_block);
+  tmp = l.scan_tmp_bytes;
+  JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, nblocks, first_block, (int)j.nsub, s));
+  JD_TRY(hipMemsetAsync(j.coef, 0, (size_t)j.nblk * 128, s));
+  hipLaunchKernelGGL(k_jd_write, gs, b256, 0, s, j, (const DState*)sa, (const uint32_t*)first_block, flags + 1);
+  int* dc[3] = {reinterpret_cast<int*>(ws + l.dc[0]), reinterpret_cast<int*>(ws + l.dc[1]), reinterpret_cast<int*>(ws + l.dc[2])};
+  for (int c = 0; c < (info.gray ? 1 : 3); ++c) {
+    hipcub::CountingInputIterator<uint32_t> cnt(0u);
+    hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{j.coef, c, info.gray});
+    tmp = l.scan_tmp_bytes;
+    JD_TRY(hipcub::DeviceScan::InclusiveSum(ws + l.scan_tmp, tmp, it, dc[c], (int)j.nblk, s));
+  }
+  const dim3 gb256((j.nblk + 255u) / 256u);
+  hipLaunchKernelGGL(k_jd_dc_apply, gb256, b256, 0, s, j, (const int*)dc[0], (const int*)dc[1], (const int*)dc[2]);
+  hipLaunchKernelGGL(k_jd_idct, dim3((j.nblk + 127u) / 128u), dim3(128), 0, s, j);
+  uint32_t err = 0;
+  JD_TRY(hipMemcpyAsync(&err, flags + 1, 4, hipMemcpyDeviceToHost, s));
+  JD_TRY(hipStreamSynchronize(s));
+  JD_TRY(hipGetLastError());
+  return err ? -1 : 0;
+#undef JD_TRY
+}
+
+}  // namespace jpeg
+}  // namespace uhdr

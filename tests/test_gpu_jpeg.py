@@ -95,3 +95,76 @@ def test_4k_frame_and_its_gain_map(hip, orc, q):
     gm = np.ascontiguousarray(gmap.reshape(-1))
     rc, n, got = _gpu_encode(lib, hip, gm, None, w // 4, h // 4, q, w // 4, 0, True)
     assert rc == 0 and got == orc.jpeg_encode("orc", gm, None, w // 4, h // 4, q)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decoder: uhdr_hip_jpeg_decode = JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR)
+# ---------------------------------------------------------------------------------------------------------------------
+def _gpu_decode(lib, hip, data, device, cap=None):
+    from tests.gpu_util import dev_empty, stream_ptr, to_host
+    buf = np.frombuffer(data, np.uint8)
+    desc = hip.Image()
+    probe = lib.uhdr_hip_jpeg_decode(C.c_void_p(buf.ctypes.data), buf.size, None, 0, C.byref(desc), hip.MEM_HOST, None)
+    if probe != hip.ERROR_INSUFFICIENT_RESOURCE:
+        return probe, None, desc
+    need = desc.width * desc.height * (1 if desc.pixelFormat == hip.PIX_FMT_MONOCHROME else 3) // (1 if desc.pixelFormat == hip.PIX_FMT_MONOCHROME else 2)
+    if desc.pixelFormat != hip.PIX_FMT_MONOCHROME:
+        need = desc.width * desc.height + 2 * (desc.width * desc.height // 4)
+    cap = need if cap is None else cap
+    if device:
+        dout = dev_empty(cap + 64, 0xCD)
+        rc = lib.uhdr_hip_jpeg_decode(C.c_void_p(buf.ctypes.data), buf.size, C.c_void_p(dout.data_ptr()), cap, C.byref(desc), hip.MEM_DEVICE, stream_ptr())
+        return rc, (to_host(dout, need).copy() if rc == 0 else None), desc
+    out = np.full(cap + 64, 0xCD, np.uint8)
+    rc = lib.uhdr_hip_jpeg_decode(C.c_void_p(buf.ctypes.data), buf.size, C.c_void_p(out.ctypes.data), cap, C.byref(desc), hip.MEM_HOST, None)
+    return rc, (out[:need].copy() if rc == 0 else None), desc
+
+
+@pytest.mark.parametrize("device", [True, False])
+def test_decoder_is_byte_exact_on_the_corpus(hip, orc, tmp_path, device):
+    from tests.test_jpeg_oracle import jpeg_corpus
+    lib = hip.load()
+    corpus, extra = jpeg_corpus(orc, tmp_path)
+    for name, data in corpus + [(k, extra[k]) for k in ("opt", "gray_opt") if k in extra]:
+        rc, got, desc = _gpu_decode(lib, hip, data, device)
+        st, want, w, h, gray = orc.jpeg_decode("orc", data)
+        assert rc == 0 and st > 0, (name, rc, st)
+        assert (desc.width, desc.height) == (w, h) and (desc.pixelFormat == hip.PIX_FMT_MONOCHROME) == bool(gray), name
+        assert np.array_equal(got, want), (name, int((got != want).sum()))
+    for k in ("prog", "rst", "rst_rows", "s444"):      # outside the device decoder (and, for 4:4:4, outside the reference)
+        if k in extra:
+            assert _gpu_decode(lib, hip, extra[k], device)[0] == hip.ERROR_UNSUPPORTED_FEATURE, k
+
+
+def test_decoder_rejects_malformed_input(hip, orc):
+    lib = hip.load()
+    rng = np.random.RandomState(4)
+    y, u, v = _content("smooth", 64, 48, rng)
+    uv = np.ascontiguousarray(np.concatenate([u.reshape(-1), v.reshape(-1)]))
+    good = orc.jpeg_encode("orc", np.ascontiguousarray(y), uv, 64, 48, 90)
+    desc = hip.Image()
+    for bad in (b"", b"\xff\xd8", b"notajpegnotajpeg", good[:300], good[:len(good) // 2]):
+        buf = np.frombuffer(bad + b"\0" * 8, np.uint8)
+        rc = lib.uhdr_hip_jpeg_decode(C.c_void_p(buf.ctypes.data), len(bad), None, 0, C.byref(desc), hip.MEM_HOST, None)
+        assert rc in (hip.UNKNOWN_ERROR, hip.ERROR_BAD_PTR), (len(bad), rc)
+    # entropy-coded data cut short but with a valid EOI glued on: the scan ends before the last block
+    cut = good[:len(good) - 200] + b"\xff\xd9"
+    rc, _, _ = _gpu_decode(lib, hip, cut, True)
+    assert rc == hip.UNKNOWN_ERROR
+    assert lib.uhdr_hip_jpeg_decode(None, 10, None, 0, C.byref(desc), hip.MEM_HOST, None) == hip.ERROR_BAD_PTR
+
+
+def test_4k_round_trip_through_the_device_codec(hip, orc):
+    """encode a 4K frame on the device, decode it on the device, compare with the oracle's decode of the same bytes; then
+    the decoded planes feed applyGainMap (the decode path of jpegr.cpp:796-801)"""
+    from tests.gpu_util import dev_empty, gpu_apply, stream_ptr, to_dev, to_host
+    from tests.test_gpu_parity import smooth_frame
+    lib = hip.load()
+    w, h = 3840, 2160
+    _, yuv = smooth_frame(w, h, 8)
+    rc, n, data = _gpu_encode(lib, hip, yuv[:w * h], yuv[w * h:], w, h, 95, w, w // 2, True)
+    assert rc == 0
+    rc, got, desc = _gpu_decode(lib, hip, data, True)
+    st, want, dw, dh, gray = orc.jpeg_decode("orc", data)
+    assert rc == 0 and st == w * h * 3 // 2 and np.array_equal(got, want)
+    assert np.abs(got[:w * h].astype(int) - yuv[:w * h].astype(int)).mean() < 2.0

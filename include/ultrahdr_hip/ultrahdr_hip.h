@@ -21,6 +21,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace ultrahdr {
 
@@ -112,6 +113,37 @@ status_t crop(uhdr_uncompressed_ptr const in_img, int left, int right, int top, 
 status_t mirror(uhdr_uncompressed_ptr const in_img, ultrahdr_mirroring_direction mirror_dir, uhdr_uncompressed_ptr out_img);
 status_t rotate(uhdr_uncompressed_ptr const in_img, int clockwise_degree, uhdr_uncompressed_ptr out_img);
 status_t resize(uhdr_uncompressed_ptr const in_img, int out_width, int out_height, uhdr_uncompressed_ptr out_img);
+
+// ---- JPEG helpers: the members callers use of JpegEncoderHelper (lib/include/ultrahdr/jpegencoderhelper.h:43-60) and of
+// JpegDecoderHelper (lib/include/ultrahdr/jpegdecoderhelper.h:54-100), same names and meaning; host buffers in and out, the
+// codec itself runs on HIP device 0 (uhdr_hip_jpeg_encode / uhdr_hip_jpeg_decode).
+class JpegEncoderHelperHip {
+ public:
+  // uvBuffer == nullptr compresses the single plane yBuffer (the gain map, jpegr.cpp:294-297)
+  bool compressImage(const uint8_t* yBuffer, const uint8_t* uvBuffer, int width, int height, int lumaStride, int chromaStride,
+                     int quality, const void* iccBuffer, unsigned int iccSize);
+  void* getCompressedImagePtr() { return mResultBuffer.data(); }
+  size_t getCompressedImageSize() { return mResultBuffer.size(); }
+
+ private:
+  std::vector<uint8_t> mResultBuffer;
+};
+
+class JpegDecoderHelperHip {
+ public:
+  // DECODE_TO_YCBCR only (what applyGainMap's caller asks for, jpegr.cpp:780-801): 4:2:0 -> Y, Cb, Cr planes; grayscale -> Y
+  bool decompressImage(const void* image, int length);
+  void* getDecompressedImagePtr() { return mResultBuffer.data(); }
+  size_t getDecompressedImageSize() { return mResultBuffer.size(); }
+  size_t getDecompressedImageWidth() { return mWidth; }
+  size_t getDecompressedImageHeight() { return mHeight; }
+  bool isSingleChannel() { return mSingleChannel; }
+
+ private:
+  std::vector<uint8_t> mResultBuffer;
+  size_t mWidth = 0, mHeight = 0;
+  bool mSingleChannel = false;
+};
 
 }  // namespace ultrahdr
 

@@ -187,4 +187,39 @@ status_t resize(uhdr_uncompressed_ptr const in_img, int out_width, int out_heigh
   });
 }
 
+// ---- JPEG helpers ----------------------------------------------------------------------------------------------------
+bool JpegEncoderHelperHip::compressImage(const uint8_t* yBuffer, const uint8_t* uvBuffer, int width, int height, int lumaStride,
+                                         int chromaStride, int quality, const void* iccBuffer, unsigned int iccSize) {
+  mResultBuffer.clear();   // jpegencoderhelper.cpp:42
+  if (width <= 0 || height <= 0 || uhdr_hip_init(0) != UHDR_HIP_NO_ERROR) return false;
+  uhdr_hip_image_t img = {const_cast<uint8_t*>(yBuffer), (size_t)width, (size_t)height, UHDR_HIP_CG_UNSPECIFIED,
+                          const_cast<uint8_t*>(uvBuffer), (size_t)lumaStride, (size_t)chromaStride,
+                          uvBuffer ? UHDR_HIP_PIX_FMT_YUV420 : UHDR_HIP_PIX_FMT_MONOCHROME};
+  mResultBuffer.resize((size_t)width * height + 65536);
+  size_t n = 0;
+  int rc = uhdr_hip_jpeg_encode(&img, quality, iccBuffer, iccSize, mResultBuffer.data(), mResultBuffer.size(), &n, UHDR_HIP_MEM_HOST, nullptr);
+  if (rc == UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) {   // n holds the size needed
+    mResultBuffer.resize(n);
+    rc = uhdr_hip_jpeg_encode(&img, quality, iccBuffer, iccSize, mResultBuffer.data(), n, &n, UHDR_HIP_MEM_HOST, nullptr);
+  }
+  mResultBuffer.resize(rc == UHDR_HIP_NO_ERROR ? n : 0);
+  return rc == UHDR_HIP_NO_ERROR;
+}
+
+bool JpegDecoderHelperHip::decompressImage(const void* image, int length) {
+  mResultBuffer.clear();
+  mWidth = mHeight = 0;
+  if (image == nullptr || length <= 0 || uhdr_hip_init(0) != UHDR_HIP_NO_ERROR) return false;
+  uhdr_hip_image_t desc;
+  int rc = uhdr_hip_jpeg_decode(image, (size_t)length, nullptr, 0, &desc, UHDR_HIP_MEM_HOST, nullptr);
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return false;   // unreadable header, unsupported process, too large
+  mSingleChannel = desc.pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
+  const size_t luma = desc.width * desc.height;
+  mResultBuffer.resize(mSingleChannel ? luma : luma + 2 * (luma / 4));   // jpegdecoderhelper.cpp:264,266
+  rc = uhdr_hip_jpeg_decode(image, (size_t)length, mResultBuffer.data(), mResultBuffer.size(), &desc, UHDR_HIP_MEM_HOST, nullptr);
+  if (rc != UHDR_HIP_NO_ERROR) { mResultBuffer.clear(); return false; }
+  mWidth = desc.width; mHeight = desc.height;
+  return true;
+}
+
 }  // namespace ultrahdr

@@ -105,6 +105,22 @@ int main(int argc, char** argv) {
   CHECK(resize(&fin, 640, 360, &fout) == ULTRAHDR_NO_ERROR && fout.width == 640 && fout.height == 360);
   dump(out + "/resize.bin", fx.data(), 640 * 360 * 3 / 2);
   CHECK(rotate(&fin, 45, &fout) == ERROR_ULTRAHDR_INVALID_CROPPING_PARAMETERS);
+  // JPEG helpers: the gain map as a single-plane JPEG (jpegr.cpp:294-297, quality 85), the SDR frame at quality 95, and back
+  JpegEncoderHelperHip enc_map, enc_sdr;
+  CHECK(enc_map.compressImage(reinterpret_cast<uint8_t*>(map.data), nullptr, (int)map.width, (int)map.height, (int)map.luma_stride, 0, 85, nullptr, 0));
+  CHECK(enc_map.getCompressedImageSize() > 0);
+  dump(out + "/map_q85.jpg", enc_map.getCompressedImagePtr(), enc_map.getCompressedImageSize());
+  const uint8_t icc[5] = {'i', 'c', 'c', '!', 0};
+  CHECK(enc_sdr.compressImage(yuv.data(), yuv.data() + w * h, (int)w, (int)h, (int)w, (int)(w / 2), 95, icc, sizeof(icc)));
+  dump(out + "/sdr_q95.jpg", enc_sdr.getCompressedImagePtr(), enc_sdr.getCompressedImageSize());
+  JpegDecoderHelperHip dec;
+  CHECK(dec.decompressImage(enc_sdr.getCompressedImagePtr(), (int)enc_sdr.getCompressedImageSize()));
+  CHECK(dec.getDecompressedImageWidth() == w && dec.getDecompressedImageHeight() == h && !dec.isSingleChannel());
+  CHECK(dec.getDecompressedImageSize() == w * h * 3 / 2);
+  dump(out + "/sdr_q95_decoded.bin", dec.getDecompressedImagePtr(), dec.getDecompressedImageSize());
+  CHECK(dec.decompressImage(enc_map.getCompressedImagePtr(), (int)enc_map.getCompressedImageSize()) && dec.isSingleChannel());
+  dump(out + "/map_q85_decoded.bin", dec.getDecompressedImagePtr(), dec.getDecompressedImageSize());
+  CHECK(!dec.decompressImage("not a jpeg", 10));
   printf("shim_test ok\n");
   return 0;
 }

@@ -58,6 +58,15 @@ def test_cpp_shim_on_reference_fixture(hip, orc, tmp_path):
         oi = orc.Image(o.ctypes.data, 0, 0, -1, None, 0, 0, -1)
         assert fn(C.byref(src), *args, C.byref(oi)) == 0
         assert np.array_equal(np.fromfile(tmp_path / fname, np.uint8), o[:nbytes]), fname
+    # JPEG helper mirrors against the CPU checker (pinned to libjpeg by tests/test_jpeg_oracle.py)
+    want = orc.jpeg_encode("orc", np.ascontiguousarray(gmap.reshape(-1)), None, w // 4, h // 4, 85)
+    assert open(tmp_path / "map_q85.jpg", "rb").read() == want
+    want = orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, 95, icc=b"icc!\0")
+    assert open(tmp_path / "sdr_q95.jpg", "rb").read() == want
+    st, planes, dw, dh, gray = orc.jpeg_decode("orc", want)
+    assert st > 0 and np.array_equal(np.fromfile(tmp_path / "sdr_q95_decoded.bin", np.uint8), planes)
+    st, planes, dw, dh, gray = orc.jpeg_decode("orc", open(tmp_path / "map_q85.jpg", "rb").read())
+    assert st > 0 and gray and np.array_equal(np.fromfile(tmp_path / "map_q85_decoded.bin", np.uint8), planes)
 
 
 def test_hbm_synthetic_frames_match_the_survey_lcg(hip, orc):

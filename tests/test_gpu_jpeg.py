@@ -168,3 +168,39 @@ def test_4k_round_trip_through_the_device_codec(hip, orc):
     st, want, dw, dh, gray = orc.jpeg_decode("orc", data)
     assert rc == 0 and st == w * h * 3 // 2 and np.array_equal(got, want)
     assert np.abs(got[:w * h].astype(int) - yuv[:w * h].astype(int)).mean() < 2.0
+
+
+def test_decoder_survives_corrupted_files(hip, orc):
+    """450 single- and multi-byte corruptions of valid files (header and entropy-coded data alike): every call must come
+    back with a status of the documented set -- no fault, no hang -- and an untouched file still decodes afterwards.
+    (What a corrupt file decodes TO is not compared: libjpeg and this decoder resynchronise differently after an error.)"""
+    lib = hip.load()
+    rng = np.random.RandomState(77)
+    allowed = {0, hip.UNKNOWN_ERROR, hip.ERROR_UNSUPPORTED_FEATURE, hip.ERROR_RESOLUTION_MISMATCH, hip.ERROR_BAD_PTR}
+    seeds = []
+    for kind, (w, h), gray in (("smooth", (64, 48), False), ("noise", (40, 24), True), ("extreme", (130, 66), False)):
+        y, u, v = _content(kind, w, h, rng)
+        uv = None if gray else np.ascontiguousarray(np.concatenate([u.reshape(-1), v.reshape(-1)]))
+        seeds.append(orc.jpeg_encode("orc", np.ascontiguousarray(y), uv, w, h, 80))
+    outcomes = {}
+    for good in seeds:
+        for _ in range(150):
+            b = bytearray(good)
+            for _k in range(rng.randint(1, 4)):
+                pos = rng.randint(2, len(b))
+                b[pos] = rng.randint(0, 256) if rng.rand() < 0.7 else b[pos] ^ (1 << rng.randint(0, 8))
+            buf = np.frombuffer(bytes(b) + b"\0" * 8, np.uint8)
+            desc = hip.Image()
+            rc = lib.uhdr_hip_jpeg_decode(C.c_void_p(buf.ctypes.data), len(b), None, 0, C.byref(desc), hip.MEM_HOST, None)
+            if rc == hip.ERROR_INSUFFICIENT_RESOURCE:
+                need = desc.width * desc.height * 2 + 64
+                if need > (1 << 23):
+                    continue          # a corrupted size field asking for a huge image: the probe already answered
+                out = np.zeros(need, np.uint8)
+                rc = lib.uhdr_hip_jpeg_decode(C.c_void_p(buf.ctypes.data), len(b), C.c_void_p(out.ctypes.data), need, C.byref(desc), hip.MEM_HOST, None)
+            assert rc in allowed, rc
+            outcomes[rc] = outcomes.get(rc, 0) + 1
+        rc, got, _ = _gpu_decode(lib, hip, good, False)
+        assert rc == 0 and np.array_equal(got, orc.jpeg_decode("orc", good)[1])
+    print("corrupted-file outcomes by status:", outcomes)
+    assert outcomes.get(0, 0) > 0 and outcomes.get(hip.UNKNOWN_ERROR, 0) > 0

@@ -193,6 +193,20 @@ int uhdr_hip_rotate(const uhdr_hip_image_t* in_img, int clockwise_degree, uhdr_h
 int uhdr_hip_resize(const uhdr_hip_image_t* in_img, int out_width, int out_height, uhdr_hip_image_t* out_img,
                     int mem_space, void* stream);
 
+/* addEffects (lib/src/editorhelper.cpp:362-446; the way ultrahdr.cpp applies a configuration's effects to the SDR image and to
+ * the gain map, :886-1429): the effects in order, every intermediate image tightly packed in device memory, the last one
+ * copied to out->data (caller-allocated: the largest intermediate extent must fit) with out's fields set as the reference
+ * leaves them (chroma_data = data + luma_stride * height for YUV420).  n == 0 copies width*height(*3/2) bytes and the
+ * descriptor.  Where the reference is undefined this call reports instead: the status of a failing effect (the reference
+ * ignores it and copies uninitialised fields), and ERROR_UNSUPPORTED_FEATURE for a mirror / rotate-180 of an image whose
+ * strides exceed its width (the reference overruns its temporary buffer). */
+typedef struct uhdr_hip_effect {
+  int32_t type;          /* 0 crop, 1 mirror, 2 rotate, 3 resize */
+  int32_t a, b, c, d;    /* crop: left, right, top, bottom; mirror: direction; rotate: clockwise degrees; resize: width, height */
+} uhdr_hip_effect_t;
+int uhdr_hip_add_effects(const uhdr_hip_image_t* in_img, const uhdr_hip_effect_t* effects, int n, uhdr_hip_image_t* out_img,
+                         int mem_space, void* stream);
+
 /* ---- JPEG compression of the path's outputs (encode side) -------------------------------
  * JpegEncoderHelper::compressImage (lib/src/jpegencoderhelper.cpp:39-283; lib/include/ultrahdr/jpegencoderhelper.h:43-60):
  * baseline JPEG of a YUV420 image (image->data = Y, image->chroma_data = U, V at chroma_stride * height / 2) or, when

@@ -114,6 +114,16 @@ status_t mirror(uhdr_uncompressed_ptr const in_img, ultrahdr_mirroring_direction
 status_t rotate(uhdr_uncompressed_ptr const in_img, int clockwise_degree, uhdr_uncompressed_ptr out_img);
 status_t resize(uhdr_uncompressed_ptr const in_img, int out_width, int out_height, uhdr_uncompressed_ptr out_img);
 
+// addEffects (lib/include/ultrahdr/editorhelper.h:27-47,62-63): the effect structs and the chaining call, same names
+struct ultrahdr_effect {
+  virtual ~ultrahdr_effect() = default;
+};
+struct ultrahdr_crop_effect : ultrahdr_effect { int left, right, top, bottom; };
+struct ultrahdr_mirror_effect : ultrahdr_effect { ultrahdr_mirroring_direction mirror_dir; };
+struct ultrahdr_rotate_effect : ultrahdr_effect { int clockwise_degree; };
+struct ultrahdr_resize_effect : ultrahdr_effect { int new_width, new_height; };
+status_t addEffects(uhdr_uncompressed_ptr const in_img, std::vector<ultrahdr_effect*>& effects, uhdr_uncompressed_ptr out_image);
+
 // ---- JPEG helpers: the members callers use of JpegEncoderHelper (lib/include/ultrahdr/jpegencoderhelper.h:43-60) and of
 // JpegDecoderHelper (lib/include/ultrahdr/jpegdecoderhelper.h:54-100), same names and meaning; host buffers in and out, the
 // codec itself runs on HIP device 0 (uhdr_hip_jpeg_encode / uhdr_hip_jpeg_decode).

@@ -34,6 +34,11 @@ class Image(C.Structure):
                 ("pixelFormat", C.c_int32)]
 
 
+class Effect(C.Structure):
+    """uhdr_hip_effect_t: type 0 crop(a=left,b=right,c=top,d=bottom) 1 mirror(a=dir) 2 rotate(a=degrees) 3 resize(a=w,b=h)"""
+    _fields_ = [("type", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("d", C.c_int32)]
+
+
 class Metadata(C.Structure):
     """uhdr_hip_metadata_t == ultrahdr_metadata_struct (ultrahdr.h:129-147)."""
     _fields_ = [("version", C.c_char * 8), ("maxContentBoost", C.c_float),
@@ -62,6 +67,7 @@ SIGNATURES = {
     "uhdr_hip_resize": (C.c_int, [_IP, C.c_int, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_generate_gainmap_ex": (C.c_int, [_IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_generate_gainmap_batch_ex": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uhdr_hip_add_effects": (C.c_int, [_IP, C.c_void_p, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_jpeg_encode": (C.c_int, [_IP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
     "uhdr_hip_jpeg_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_lut_table": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -1106,4 +1106,97 @@ int uhdr_hip_resize(const uhdr_hip_image_t* in_img, int out_width, int out_heigh
   return fx_run(FXK_RESIZE, in_img, out_width, out_height, 0, 0, out_img, mem_space, stream);
 }
 
+// addEffects (editorhelper.cpp:362-446): the chain stays in device memory, two ping-pong temporaries
+int uhdr_hip_add_effects(const uhdr_hip_image_t* in, const uhdr_hip_effect_t* effects, int n, uhdr_hip_image_t* out, int mem_space,
+                         void* stream) {
+  if (in == nullptr || in->data == nullptr || out == nullptr || out->data == nullptr || n < 0 || (n > 0 && effects == nullptr))
+    return UHDR_HIP_ERROR_BAD_PTR;
+  if (in->pixelFormat != UHDR_HIP_PIX_FMT_YUV420 && in->pixelFormat != UHDR_HIP_PIX_FMT_MONOCHROME)
+    return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  const bool mono = in->pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
+  const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
+  DeviceState* st = nullptr;
+  int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lk(g_host_mu);   // temporaries are shared
+
+  auto packed = [mono](size_t w, size_t h) { return mono ? w * h : w * h * 3 / 2; };
+  size_t size = packed(in->width, in->height);
+  const size_t size0 = size;
+  // extents of every intermediate image (all tightly packed after the first effect)
+  size_t max_bytes = size0;
+  {
+    size_t w = in->width, h = in->height;
+    for (int i = 0; i < n; ++i) {
+      const uhdr_hip_effect_t& e = effects[i];
+      if (e.type == 0) { if (e.b < e.a || e.d < e.c) return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS; w = (size_t)(e.b - e.a + 1); h = (size_t)(e.d - e.c + 1); }
+      else if (e.type == 2) { if (e.a == 90 || e.a == 270) std::swap(w, h); }
+      else if (e.type == 3) { if (e.a <= 0 || e.b <= 0) return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS; w = (size_t)e.a; h = (size_t)e.b; }
+      else if (e.type != 1) return UHDR_HIP_ERROR_BAD_PTR;
+      max_bytes = std::max(max_bytes, packed(w, h));
+    }
+  }
+  // The reference's out image is written after every step (:432-437), so beyond the last result it keeps the tails of the
+  // earlier, larger ones.  dev_out plays that image: the caller's buffer itself, or its device stand-in for host calls.
+  uint8_t* dev_out = static_cast<uint8_t*>(out->data);
+  if (host) {
+    if ((rc = stage_reserve(st, 5, max_bytes + 64)) != 0) return rc;
+    dev_out = static_cast<uint8_t*>(st->stage[5]);
+  }
+  // :383-390: the descriptor and width*height(*3/2) bytes starting at the luma pointer are copied first
+  out->width = in->width; out->height = in->height; out->colorGamut = in->colorGamut; out->pixelFormat = in->pixelFormat;
+  out->luma_stride = in->luma_stride; out->chroma_stride = in->chroma_stride;
+  if (size0) HIP_TRY(hipMemcpyAsync(dev_out, in->data, size0, host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+  // the first effect reads the caller's image (any strides); host images are staged as fx_run does
+  uhdr_hip_image_t last = *in;
+  const size_t ls0 = in->luma_stride != 0 ? in->luma_stride : in->width;
+  const size_t cs0 = in->chroma_stride != 0 ? in->chroma_stride : (ls0 >> 1);
+  if (host && n > 0) {
+    const size_t luma_bytes = in->height ? ls0 * (in->height - 1) + in->width : 0;
+    const size_t chroma_bytes = (!mono && in->height) ? cs0 * (in->height - 1) + in->width / 2 : 0;
+    if ((rc = stage_reserve(st, 0, luma_bytes)) != 0) return rc;
+    if ((rc = stage_reserve(st, 1, chroma_bytes)) != 0) return rc;
+    if (luma_bytes) HIP_TRY(hipMemcpyAsync(st->stage[0], in->data, luma_bytes, hipMemcpyHostToDevice, s));
+    const uint8_t* hc = in->chroma_data ? static_cast<const uint8_t*>(in->chroma_data) : static_cast<const uint8_t*>(in->data) + ls0 * in->height;
+    if (chroma_bytes) HIP_TRY(hipMemcpyAsync(st->stage[1], hc, chroma_bytes, hipMemcpyHostToDevice, s));
+    last.data = st->stage[0];
+    last.chroma_data = mono ? nullptr : st->stage[1];
+    last.luma_stride = ls0; last.chroma_stride = cs0;
+  }
+  if ((rc = stage_reserve(st, 2, max_bytes + 64)) != 0) return rc;
+  for (int i = 0; i < n; ++i) {
+    const uhdr_hip_effect_t& e = effects[i];
+    const size_t lls = last.luma_stride != 0 ? last.luma_stride : last.width;
+    const bool keeps_stride = e.type == 1 || (e.type == 2 && e.a == 180);
+    if (keeps_stride && (lls != last.width || (!mono && last.chroma_stride != 0 && last.chroma_stride != last.width / 2)))
+      return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;   // the reference writes past its `size`-byte temporary here
+    // same argument checks as the single effects (fx_run)
+    if (e.type == 0 && (e.a < 0 || (size_t)e.b >= last.width || e.c < 0 || (size_t)e.d >= last.height)) return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS;
+    if (e.type == 2 && e.a != 90 && e.a != 180 && e.a != 270) return UHDR_HIP_ERROR_INVALID_CROPPING_PARAMETERS;
+    uhdr_hip_image_t tmp = *out;
+    tmp.data = st->stage[2];
+    FxJobs jobs;
+    const int kind = e.type == 0 ? FXK_CROP : e.type == 1 ? FXK_MIRROR : e.type == 2 ? FXK_ROTATE : FXK_RESIZE;
+    if ((rc = fx_plan(kind, last, e.a, e.b, e.c, e.d, &tmp, &jobs)) != 0) return rc;
+    HIP_TRY(launch_effect(jobs, s));
+    size = e.type == 0 ? packed((size_t)(e.b - e.a + 1), (size_t)(e.d - e.c + 1))
+         : e.type == 3 ? packed((size_t)e.a, (size_t)e.b) : packed(last.width, last.height);   // :395-430
+    if (size) HIP_TRY(hipMemcpyAsync(dev_out, tmp.data, size, hipMemcpyDeviceToDevice, s));    // the "deep copy", :437
+    last = tmp;
+    last.data = dev_out;                                                                         // last = out_img, :442
+    last.chroma_data = mono ? nullptr : dev_out + last.luma_stride * last.height;               // :438-440
+  }
+  if (n > 0) {
+    out->width = last.width; out->height = last.height; out->colorGamut = last.colorGamut; out->pixelFormat = last.pixelFormat;
+    out->luma_stride = last.luma_stride; out->chroma_stride = last.chroma_stride;
+    if (!mono) out->chroma_data = static_cast<uint8_t*>(out->data) + out->luma_stride * out->height;
+  }
+  if (host) {
+    if (max_bytes) HIP_TRY(hipMemcpyAsync(out->data, dev_out, max_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
 }  // extern "C"

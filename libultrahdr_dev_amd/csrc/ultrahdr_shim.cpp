@@ -5,6 +5,7 @@
 
 #include <cstring>
 #include <memory>
+#include <vector>
 
 #include "uhdr_hip.h"
 
@@ -185,6 +186,30 @@ status_t resize(uhdr_uncompressed_ptr const in_img, int out_width, int out_heigh
   return run_effect(in_img, out_img, [&](uhdr_hip_image_t* i, uhdr_hip_image_t* o) {
     return uhdr_hip_resize(i, out_width, out_height, o, UHDR_HIP_MEM_HOST, nullptr);
   });
+}
+
+status_t addEffects(uhdr_uncompressed_ptr const in_img, std::vector<ultrahdr_effect*>& effects, uhdr_uncompressed_ptr out_image) {
+  if (in_img == nullptr || in_img->data == nullptr || out_image == nullptr || out_image->data == nullptr) return ERROR_ULTRAHDR_BAD_PTR;
+  if (uhdr_hip_init(0) != UHDR_HIP_NO_ERROR) return ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE;
+  std::vector<uhdr_hip_effect_t> fx;
+  for (ultrahdr_effect* e : effects) {   // the reference's dynamic_cast ladder (editorhelper.cpp:394-430); unknown effects are skipped there too
+    if (auto* c = dynamic_cast<ultrahdr_crop_effect*>(e)) fx.push_back({0, c->left, c->right, c->top, c->bottom});
+    else if (auto* m = dynamic_cast<ultrahdr_mirror_effect*>(e)) fx.push_back({1, (int)m->mirror_dir, 0, 0, 0});
+    else if (auto* r = dynamic_cast<ultrahdr_rotate_effect*>(e)) fx.push_back({2, r->clockwise_degree, 0, 0, 0});
+    else if (auto* z = dynamic_cast<ultrahdr_resize_effect*>(e)) fx.push_back({3, z->new_width, z->new_height, 0, 0});
+  }
+  uhdr_hip_image_t i = {in_img->data, in_img->width, in_img->height, (int32_t)in_img->colorGamut, in_img->chroma_data,
+                        in_img->luma_stride, in_img->chroma_stride, (int32_t)in_img->pixelFormat};
+  uhdr_hip_image_t o = {out_image->data, out_image->width, out_image->height, (int32_t)out_image->colorGamut, out_image->chroma_data,
+                        out_image->luma_stride, out_image->chroma_stride, (int32_t)out_image->pixelFormat};
+  const int rc = uhdr_hip_add_effects(&i, fx.data(), (int)fx.size(), &o, UHDR_HIP_MEM_HOST, nullptr);
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  out_image->width = o.width; out_image->height = o.height;
+  out_image->colorGamut = static_cast<ultrahdr_color_gamut>(o.colorGamut);
+  out_image->pixelFormat = static_cast<ultrahdr_pixel_format>(o.pixelFormat);
+  out_image->luma_stride = o.luma_stride; out_image->chroma_stride = o.chroma_stride;
+  out_image->chroma_data = o.chroma_data;
+  return ULTRAHDR_NO_ERROR;
 }
 
 // ---- JPEG helpers ----------------------------------------------------------------------------------------------------

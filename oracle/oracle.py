@@ -35,6 +35,11 @@ class Metadata(C.Structure):
                 ("version_ok", C.c_int32)]
 
 
+class Effect(C.Structure):
+    """type 0 crop(a=left,b=right,c=top,d=bottom) 1 mirror(a=dir) 2 rotate(a=degrees) 3 resize(a=w,b=h)"""
+    _fields_ = [("type", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("d", C.c_int32)]
+
+
 class Color(C.Structure):
     _fields_ = [("r", C.c_float), ("g", C.c_float), ("b", C.c_float)]
 
@@ -85,6 +90,7 @@ def _declare(lib, p):
     d("mirror", i32, IP, i32, IP)
     d("rotate", i32, IP, i32, IP)
     d("resize", i32, IP, i32, i32, IP)
+    d("add_effects", i32, IP, C.c_void_p, i32, IP)
     if p == "orc_":
         d("generateGainMapStats", i32, IP, IP, i32, MP, C.c_void_p, i32, i32, C.POINTER(f32))
         d("toneMap", i32, IP, IP)

@@ -22,6 +22,9 @@
 
 #include "ultrahdr/editorhelper.h"
 #include "ultrahdr/gainmapmath.h"
+#include <memory>
+#include <vector>
+
 #include "uhdr_oracle.h"
 
 using namespace ultrahdr;
@@ -194,6 +197,26 @@ int ref_resize(const orc_image* in, int w, int h, orc_image* out) {
   if (!in || !out) return resize(nullptr, w, h, nullptr);
   auto i = to_ref(in); auto o = to_ref(out);
   int rc = resize(&i, w, h, &o);
+  if (rc == 0) fx_back(o, out);
+  return rc;
+}
+
+/* the reference's addEffects (editorhelper.cpp:362-446) over its own effect structs */
+int ref_add_effects(const orc_image* in, const orc_effect* fx, int n, orc_image* out) {
+  if (!in || !out) return addEffects(nullptr, *(new std::vector<ultrahdr_effect*>()), nullptr);
+  std::vector<std::unique_ptr<ultrahdr_effect>> own;
+  std::vector<ultrahdr_effect*> effects;
+  for (int i = 0; i < n; ++i) {
+    switch (fx[i].type) {
+      case 0: { auto* e = new ultrahdr_crop_effect; e->left = fx[i].a; e->right = fx[i].b; e->top = fx[i].c; e->bottom = fx[i].d; own.emplace_back(e); break; }
+      case 1: { auto* e = new ultrahdr_mirror_effect; e->mirror_dir = fx[i].a == 0 ? ULTRAHDR_MIRROR_VERTICAL : ULTRAHDR_MIRROR_HORIZONTAL; own.emplace_back(e); break; }
+      case 2: { auto* e = new ultrahdr_rotate_effect; e->clockwise_degree = fx[i].a; own.emplace_back(e); break; }
+      default: { auto* e = new ultrahdr_resize_effect; e->new_width = fx[i].a; e->new_height = fx[i].b; own.emplace_back(e); break; }
+    }
+    effects.push_back(own.back().get());
+  }
+  auto i = to_ref(in); auto o = to_ref(out);
+  int rc = addEffects(&i, effects, &o);
   if (rc == 0) fx_back(o, out);
   return rc;
 }

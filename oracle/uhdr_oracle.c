@@ -953,6 +953,55 @@ int orc_resize(const orc_image* in, int ow, int oh, orc_image* out) {
 }
 
 /* batch evaluation of the scalar functions (tests compare the device functions against these) */
+/* addEffects (editorhelper.cpp:362-446): the effects applied in order, each into a fresh tightly sized buffer whose
+ * bytes are then copied into out->data; out's fields follow the last effect and its chroma pointer is re-derived as
+ * data + luma_stride * height.  Restated for the cases in which the reference is defined: it ignores the status of the
+ * individual effects (and then copies uninitialised fields); here the first failing effect's status is returned. */
+int orc_add_effects(const orc_image* in, const orc_effect* fx, int n, orc_image* out) {
+  if (in == NULL || in->data == NULL || out == NULL || out->data == NULL) return ORC_ERR_BAD_PTR;
+  const int mono = in->pixelFormat == 2;
+  size_t size = in->width * in->height;
+  if (!mono) size = size * 3 / 2;
+  out->width = in->width; out->height = in->height; out->colorGamut = in->colorGamut; out->pixelFormat = in->pixelFormat;
+  out->luma_stride = in->luma_stride; out->chroma_stride = in->chroma_stride;
+  memcpy(out->data, in->data, size);
+  const orc_image* last = in;
+  for (int i = 0; i < n; ++i) {
+    orc_image tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    int rc;
+    switch (fx[i].type) {
+      case 0: size = (size_t)(fx[i].d - fx[i].c + 1) * (size_t)(fx[i].b - fx[i].a + 1); break;
+      case 1: case 2: size = last->width * last->height; break;
+      case 3: size = (size_t)fx[i].a * (size_t)fx[i].b; break;
+      default: return ORC_ERR_BAD_PTR;
+    }
+    if (!mono) size = size * 3 / 2;
+    /* (the reference allocates exactly `size`; mirror / rotate-180 of a padded image write more than that there) */
+    size_t cap = size;
+    if (fx[i].type == 1 || fx[i].type == 2) {
+      size_t ls = last->luma_stride ? last->luma_stride : last->width;
+      cap = ls * last->height * 2 + 64;
+    }
+    uint8_t* buf = (uint8_t*)malloc(cap ? cap : 1);
+    tmp.data = buf;
+    switch (fx[i].type) {
+      case 0: rc = orc_crop(last, fx[i].a, fx[i].b, fx[i].c, fx[i].d, &tmp); break;
+      case 1: rc = orc_mirror(last, fx[i].a, &tmp); break;
+      case 2: rc = orc_rotate(last, fx[i].a, &tmp); break;
+      default: rc = orc_resize(last, fx[i].a, fx[i].b, &tmp); break;
+    }
+    if (rc != ORC_OK) { free(buf); return rc; }
+    out->width = tmp.width; out->height = tmp.height; out->colorGamut = tmp.colorGamut; out->pixelFormat = tmp.pixelFormat;
+    out->luma_stride = tmp.luma_stride; out->chroma_stride = tmp.chroma_stride;
+    memcpy(out->data, tmp.data, size);
+    if (!mono) out->chroma_data = (uint8_t*)out->data + out->luma_stride * out->height;
+    free(buf);
+    last = out;
+  }
+  return ORC_OK;
+}
+
 void orc_eval_transfer(int fn, const float* in, float* out, size_t n, float minBoost, float maxBoost) {
   float l2min = (float)log2((double)minBoost), l2max = (float)log2((double)maxBoost);
   float gain_lut[ORC_GAIN_LUT_N];

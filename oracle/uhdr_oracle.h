@@ -126,6 +126,9 @@ int orc_crop(const orc_image* in, int left, int right, int top, int bottom, orc_
 int orc_mirror(const orc_image* in, int dir, orc_image* out);
 int orc_rotate(const orc_image* in, int clockwise_degree, orc_image* out);
 int orc_resize(const orc_image* in, int out_width, int out_height, orc_image* out);
+/* addEffects (editorhelper.cpp:362-446).  type 0 crop(a=left,b=right,c=top,d=bottom) 1 mirror(a=dir) 2 rotate(a=degrees) 3 resize(a=w,b=h) */
+typedef struct { int32_t type, a, b, c, d; } orc_effect;
+int orc_add_effects(const orc_image* in, const orc_effect* effects, int n, orc_image* out);
 
 /* ---- JPEG compression of the path's outputs (jpeg_oracle.c; SURVEY 8(f) rank 1, encode side) ----
  * JpegEncoderHelper::compressImage (lib/src/jpegencoderhelper.cpp:39-283): uv == NULL compresses one 8-bit plane

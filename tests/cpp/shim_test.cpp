@@ -105,6 +105,19 @@ int main(int argc, char** argv) {
   CHECK(resize(&fin, 640, 360, &fout) == ULTRAHDR_NO_ERROR && fout.width == 640 && fout.height == 360);
   dump(out + "/resize.bin", fx.data(), 640 * 360 * 3 / 2);
   CHECK(rotate(&fin, 45, &fout) == ERROR_ULTRAHDR_INVALID_CROPPING_PARAMETERS);
+  // addEffects with the reference's effect structs (editorhelper_test.cpp:553-600 shape, with a valid rotation)
+  {
+    ultrahdr_resize_effect rs; rs.new_width = (int)(w * 3 / 4); rs.new_height = (int)(h * 3 / 4);
+    ultrahdr_mirror_effect mi; mi.mirror_dir = ULTRAHDR_MIRROR_VERTICAL;
+    ultrahdr_rotate_effect ro; ro.clockwise_degree = 90;
+    ultrahdr_crop_effect cr; cr.top = 10; cr.bottom = 99; cr.left = 20; cr.right = 149;
+    std::vector<ultrahdr_effect*> effects = {&rs, &mi, &ro, &cr};
+    ultrahdr_uncompressed_struct fo2{};
+    fo2.data = fx.data();
+    CHECK(addEffects(&fin, effects, &fo2) == ULTRAHDR_NO_ERROR && fo2.width == 130 && fo2.height == 90 && fo2.pixelFormat == ULTRAHDR_PIX_FMT_YUV420);
+    CHECK(fo2.chroma_data == fx.data() + 130 * 90);
+    dump(out + "/effects_chain.bin", fx.data(), 130 * 90 * 3 / 2);
+  }
   // JPEG helpers: the gain map as a single-plane JPEG (jpegr.cpp:294-297, quality 85), the SDR frame at quality 95, and back
   JpegEncoderHelperHip enc_map, enc_sdr;
   CHECK(enc_map.compressImage(reinterpret_cast<uint8_t*>(map.data), nullptr, (int)map.width, (int)map.height, (int)map.luma_stride, 0, 85, nullptr, 0));

@@ -113,3 +113,54 @@ def test_effects_full_size_roundtrips(hip, orc):
     o3 = hip.out_image(r180.data_ptr())
     assert lib.uhdr_hip_rotate(C.byref(src), 180, C.byref(o3), hip.MEM_DEVICE, s) == 0
     assert np.array_equal(to_host(m2, n), to_host(r180, n))
+
+
+@pytest.mark.parametrize("mono", [False, True])
+@pytest.mark.parametrize("device", [True, False])
+def test_add_effects_chains(hip, orc, mono, device):
+    """addEffects (editorhelper.cpp:362-446): chains stay on the device; bytes and descriptor equal the oracle's restatement
+    (pinned to the reference's object code by tests/test_oracle_pins.py)"""
+    from tests.gpu_util import dev_empty, stream_ptr, to_dev, to_host
+    from tests.test_oracle_pins import FX_CHAINS, _fx_image
+    lib, L = hip.load(), orc.load()
+    rng = np.random.RandomState(5 + int(mono))
+    w, h = 128, 96
+    for ls in (None, 144):
+        keep, img = _fx_image(orc, rng, w, h, mono, ls=ls)
+        src = keep[0]
+        for chain in FX_CHAINS:
+            padded_mirror_first = ls is not None and chain and (chain[0][0] == 1 or (chain[0][0] == 2 and chain[0][1] == 180))
+            oarr = (orc.Effect * max(len(chain), 1))(*[orc.Effect(*e) for e in chain])
+            garr = (hip.Effect * max(len(chain), 1))(*[hip.Effect(*e) for e in chain])
+            obuf = np.full(160 * 160 * 2, 0xEE, np.uint8)
+            oo = orc.Image(obuf.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+            assert L.orc_add_effects(C.byref(img), oarr, len(chain), C.byref(oo)) == 0
+            if device:
+                dsrc, dout = to_dev(src), dev_empty(obuf.size, 0xEE)
+                gi = hip.Image(dsrc.data_ptr(), w, h, img.colorGamut, None, img.luma_stride, img.chroma_stride, img.pixelFormat)
+                go = hip.Image(dout.data_ptr(), 0, 0, -1, None, 0, 0, -1)
+                rc = lib.uhdr_hip_add_effects(C.byref(gi), garr, len(chain), C.byref(go), hip.MEM_DEVICE, stream_ptr())
+                got = to_host(dout, obuf.size)
+                base = dout.data_ptr()
+            else:
+                gbuf = np.full(obuf.size, 0xEE, np.uint8)
+                gi = hip.Image(src.ctypes.data, w, h, img.colorGamut, None, img.luma_stride, img.chroma_stride, img.pixelFormat)
+                go = hip.Image(gbuf.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+                rc = lib.uhdr_hip_add_effects(C.byref(gi), garr, len(chain), C.byref(go), hip.MEM_HOST, None)
+                got, base = gbuf, gbuf.ctypes.data
+            if padded_mirror_first:
+                assert rc == hip.ERROR_UNSUPPORTED_FEATURE
+                continue
+            assert rc == 0, (chain, rc)
+            assert (go.width, go.height, go.colorGamut, go.pixelFormat, go.luma_stride, go.chroma_stride) == \
+                   (oo.width, oo.height, oo.colorGamut, oo.pixelFormat, oo.luma_stride, oo.chroma_stride), chain
+            if chain and not mono:
+                assert go.chroma_data - base == oo.chroma_data - oo.data
+            assert np.array_equal(got, obuf), (chain, ls, int((got != obuf).sum()))
+    bad = (hip.Effect * 1)(hip.Effect(2, 900, 0, 0, 0))
+    keep, img = _fx_image(orc, rng, w, h, mono)
+    gbuf = np.zeros(w * h * 2, np.uint8)
+    gi = hip.Image(keep[0].ctypes.data, w, h, 0, None, 0, 0, img.pixelFormat)
+    go = hip.Image(gbuf.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+    assert lib.uhdr_hip_add_effects(C.byref(gi), bad, 1, C.byref(go), hip.MEM_HOST, None) == hip.ERROR_INVALID_CROPPING_PARAMETERS
+    assert lib.uhdr_hip_add_effects(None, bad, 1, C.byref(go), hip.MEM_HOST, None) == hip.ERROR_BAD_PTR

@@ -58,6 +58,11 @@ def test_cpp_shim_on_reference_fixture(hip, orc, tmp_path):
         oi = orc.Image(o.ctypes.data, 0, 0, -1, None, 0, 0, -1)
         assert fn(C.byref(src), *args, C.byref(oi)) == 0
         assert np.array_equal(np.fromfile(tmp_path / fname, np.uint8), o[:nbytes]), fname
+    arr = (orc.Effect * 4)(orc.Effect(3, w * 3 // 4, h * 3 // 4, 0, 0), orc.Effect(1, 0, 0, 0, 0), orc.Effect(2, 90, 0, 0, 0), orc.Effect(0, 20, 149, 10, 99))
+    o = np.zeros(w * h * 3 // 2 + 64, np.uint8)
+    oi = orc.Image(o.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+    assert L.orc_add_effects(C.byref(src), arr, 4, C.byref(oi)) == 0 and (oi.width, oi.height) == (130, 90)
+    assert np.array_equal(np.fromfile(tmp_path / "effects_chain.bin", np.uint8), o[:130 * 90 * 3 // 2])
     # JPEG helper mirrors against the CPU checker (pinned to libjpeg by tests/test_jpeg_oracle.py)
     want = orc.jpeg_encode("orc", np.ascontiguousarray(gmap.reshape(-1)), None, w // 4, h // 4, 85)
     assert open(tmp_path / "map_q85.jpg", "rb").read() == want

@@ -551,3 +551,49 @@ def test_lut_pipelines_equal_reference_object_code(orc):
                     a = orc.apply("orc_", yi, m, md, fmt, boost, threads=2, lut=True)
                     b = orc.apply("ref_", yi, m, md, fmt, boost, threads=1, lut=True)
                     assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]), (scale, fmt, boost)
+
+
+# addEffects (editorhelper.cpp:362-446): the chain as ultrahdr.cpp applies it to the SDR image and to the gain map
+FX_CHAINS = [
+    [],
+    [(3, 96, 72, 0, 0)],
+    [(3, 96, 72, 0, 0), (1, 0, 0, 0, 0), (2, 90, 0, 0, 0), (0, 10, 49, 20, 83)],      # the shape of editorhelper_test.cpp:553-600
+    [(0, 4, 99, 2, 61), (2, 180, 0, 0, 0), (1, 1, 0, 0, 0), (3, 64, 40, 0, 0), (2, 270, 0, 0, 0)],
+    [(2, 90, 0, 0, 0), (2, 90, 0, 0, 0), (2, 90, 0, 0, 0), (2, 90, 0, 0, 0)],
+]
+
+
+def _fx_array(orc, chain):
+    arr = (orc.Effect * max(len(chain), 1))()
+    for i, e in enumerate(chain):
+        arr[i] = orc.Effect(*e)
+    return arr
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_add_effects_restatement_equals_reference_object_code(orc, mono):
+    R = orc.load_ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    L = orc.load()
+    rng = np.random.RandomState(5)
+    w, h = 128, 96
+    keep, img = _fx_image(orc, rng, w, h, mono)
+    for chain in FX_CHAINS:
+        arr = _fx_array(orc, chain)
+        outs = []
+        for lib, pre in ((L, "orc_"), (R, "ref_")):
+            buf = np.full(w * h * 2 + 64, 0xEE, np.uint8)
+            o = orc.Image(buf.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+            rc = getattr(lib, pre + "add_effects")(C.byref(img), arr, len(chain), C.byref(o))
+            outs.append((rc, buf, (o.width, o.height, o.colorGamut, o.pixelFormat, o.luma_stride, o.chroma_stride),
+                         None if (mono or not chain) else o.chroma_data - o.data))
+        assert outs[0][0] == outs[1][0] == 0, chain
+        assert outs[0][2:] == outs[1][2:], (chain, outs[0][2:], outs[1][2:])
+        assert np.array_equal(outs[0][1], outs[1][1]), chain
+    # defined deviation: the reference ignores a failing effect's status (its own test passes clockwise_degree = 900,
+    # editorhelper_test.cpp:571, and then copies uninitialised fields); the restatement reports it
+    buf = np.zeros(w * h * 2, np.uint8)
+    o = orc.Image(buf.ctypes.data, 0, 0, -1, None, 0, 0, -1)
+    assert L.orc_add_effects(C.byref(img), _fx_array(orc, [(2, 900, 0, 0, 0)]), 1, C.byref(o)) == -10011
+    assert L.orc_add_effects(None, arr, 0, C.byref(o)) == -10001

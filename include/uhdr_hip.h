@@ -232,6 +232,26 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
                          int mem_space, void* stream);
 
+/* JpegR::decodeJPEGR (lib/src/jpegr.cpp:655-822) for the HDR output formats: a JPEG/R file (HOST memory: primary JPEG + gain
+ * map JPEG, the gain map's APP1 carrying the hdrgm:* XMP attributes) -> the HDR rendition applyGainMap produces.  Container
+ * scan (extractPrimaryImageAndGainMap, :823-876), XMP metadata (getMetadataFromXMP, jpegrutils.cpp:436-545) and the ICC gamut
+ * of the primary image (IccHelper::readIccColorGamut, icc.cpp:615-685) are host bookkeeping; both JPEGs are decompressed and
+ * combined on the device.  dest_data (memory space mem_space) receives width*height*{8|4|6} bytes; *dest gets width, height
+ * and colorGamut; *metadata (optional) the parsed metadata.  Status values are the reference's: BAD_PTR,
+ * INVALID_DISPLAY_BOOST (max_display_boost < 1), INVALID_OUTPUT_FORMAT, NO_IMAGES_FOUND, GAIN_MAP_IMAGE_NOT_FOUND, DECODE_ERROR,
+ * METADATA_ERROR, then applyGainMap's own; plus ERROR_INSUFFICIENT_RESOURCE when dest_capacity is too small (*dest is filled)
+ * and ERROR_UNSUPPORTED_FEATURE for ULTRAHDR_OUTPUT_SDR (libjpeg's RGB conversion is not built) and for progressive /
+ * restart-interval JPEGs. */
+#define UHDR_HIP_ERROR_INVALID_DISPLAY_BOOST (-10008)
+#define UHDR_HIP_ERROR_INVALID_OUTPUT_FORMAT (-10009)
+#define UHDR_HIP_ERROR_DECODE_ERROR (-20002)
+#define UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND (-20003)
+#define UHDR_HIP_ERROR_METADATA_ERROR (-20005)
+#define UHDR_HIP_ERROR_NO_IMAGES_FOUND (-20006)
+int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_format, float max_display_boost, void* dest_data,
+                          size_t dest_capacity, uhdr_hip_image_t* dest, uhdr_hip_metadata_t* metadata, int apply_mode,
+                          int mem_space, void* stream);
+
 /* ---- batches (device memory only, asynchronous on `stream`) ------------------------------ */
 /* The reference processes one image per call; a batch is n independent calls with identical
  * (hdr_tf, sdr_is_601 | metadata, output_format, max_display_boost).  Images of equal size share

@@ -70,6 +70,7 @@ SIGNATURES = {
     "uhdr_hip_add_effects": (C.c_int, [_IP, C.c_void_p, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_jpeg_encode": (C.c_int, [_IP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
     "uhdr_hip_jpeg_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_jpegr_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _IP, _MP, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_lut_table": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "uhdr_hip_gain_lut": (C.c_int, [_MP, C.c_int, C.c_float, C.POINTER(C.c_float)]),
     "uhdr_hip_idw_tables": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),

@@ -15,6 +15,7 @@
 #include "../../include/uhdr_hip.h"
 #include "uhdr_kernels.h"
 #include "uhdr_jpeg.h"
+#include "uhdr_jpegr.h"
 
 namespace {
 
@@ -41,11 +42,12 @@ struct DeviceState {
   std::map<int, float*> idw;  // scale -> device tables (4 * scale*scale*4 floats)
   float* lut = nullptr;       // the five static transfer-function tables (kLutTotal floats), built at init
   // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
-  void* stage[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t stage_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  void* stage[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
 std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
+std::mutex g_jpegr_mu;              // serialises uhdr_hip_jpegr_decode (slots 8-10), which calls the entry points above
 std::map<int, DeviceState> g_dev;
 
 // gainmapmath.cpp:69-110: sqrt runs in double on a float expression, weights are float divisions
@@ -460,7 +462,7 @@ int uhdr_hip_shutdown(void) {
     (void)hipDeviceSynchronize();
     for (auto& t : kv.second.idw) (void)hipFree(t.second);
     if (kv.second.lut) (void)hipFree(kv.second.lut);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 12; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
   }
   g_dev.clear();
@@ -631,6 +633,77 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
     HIP_TRY(hipMemcpyAsync(out, dout, need, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
+  return UHDR_HIP_NO_ERROR;
+}
+
+// JpegR::decodeJPEGR (jpegr.cpp:655-822), HDR outputs
+int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_format, float max_display_boost, void* dest_data,
+                          size_t dest_capacity, uhdr_hip_image_t* dest, uhdr_hip_metadata_t* metadata, int apply_mode,
+                          int mem_space, void* stream) {
+  if (jpegr == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                   // :658-661
+  if (dest == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                    // :662-665
+  if (max_display_boost < 1.0f) return UHDR_HIP_ERROR_INVALID_DISPLAY_BOOST;                             // :666-669
+  if (output_format < UHDR_HIP_OUTPUT_SDR || output_format > UHDR_HIP_OUTPUT_HDR_LINEAR_RGB_10BIT) return UHDR_HIP_ERROR_INVALID_OUTPUT_FORMAT;
+  const uint8_t* file = static_cast<const uint8_t*>(jpegr);
+  jpegr::Range img[2];
+  const int found = jpegr::find_images(file, jpegr_size, img);                                          // :823-876
+  if (found == 0) return UHDR_HIP_ERROR_NO_IMAGES_FOUND;
+  if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
+  if (output_format == UHDR_HIP_OUTPUT_SDR) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  const uint8_t* pj = file + img[0].begin;
+  const uint8_t* gj = file + img[1].begin;
+
+  // sizes first: header probes of the two JPEGs
+  uhdr_hip_image_t ydesc, gdesc;
+  int rc = uhdr_hip_jpeg_decode(pj, img[0].len, nullptr, 0, &ydesc, UHDR_HIP_MEM_DEVICE, stream);
+  if (rc == UHDR_HIP_ERROR_UNSUPPORTED_FEATURE) return rc;
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE || ydesc.pixelFormat != UHDR_HIP_PIX_FMT_YUV420) return UHDR_HIP_ERROR_DECODE_ERROR;   // :690-694
+  rc = uhdr_hip_jpeg_decode(gj, img[1].len, nullptr, 0, &gdesc, UHDR_HIP_MEM_DEVICE, stream);
+  if (rc == UHDR_HIP_ERROR_UNSUPPORTED_FEATURE) return rc;
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return UHDR_HIP_ERROR_DECODE_ERROR;                    // :731-733
+  // metadata from the gain map's XMP packet (:756-760)
+  uhdr_hip_metadata_t md;
+  const uint8_t* xmp = nullptr;
+  size_t xmp_len = 0;
+  static const char kXmpNs[] = "http://ns.adobe.com/xap/1.0/";
+  if (!jpegr::find_app_segment(gj, img[1].len, 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) || !jpegr::metadata_from_xmp(xmp, xmp_len, &md))
+    return UHDR_HIP_ERROR_METADATA_ERROR;
+  if (metadata != nullptr) *metadata = md;
+  const uint8_t* icc = nullptr;
+  size_t icc_len = 0;
+  static const char kIccSig[] = "ICC_PROFILE";
+  const int gamut = jpegr::find_app_segment(pj, img[0].len, 0xE2, kIccSig, sizeof(kIccSig), &icc, &icc_len) ? jpegr::gamut_from_icc(icc, icc_len)
+                                                                                                           : UHDR_HIP_CG_UNSPECIFIED;
+  const size_t w = ydesc.width, h = ydesc.height;
+  dest->width = w; dest->height = h; dest->colorGamut = gamut;
+  const size_t out_bytes = w * h * apply_bpp(output_format);
+  if (dest_data == nullptr || dest_capacity < out_bytes) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+
+  DeviceState* st = nullptr;
+  if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
+  const size_t ybytes = w * h + 2 * (w * h / 4), gbytes = gdesc.width * gdesc.height * (gdesc.pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME ? 1 : 2);
+  if ((rc = stage_reserve(st, 8, ybytes + 64)) != 0) return rc;
+  if ((rc = stage_reserve(st, 9, gbytes + 64)) != 0) return rc;
+  if (host && (rc = stage_reserve(st, 10, out_bytes)) != 0) return rc;
+  if (uhdr_hip_jpeg_decode(pj, img[0].len, st->stage[8], ybytes, &ydesc, UHDR_HIP_MEM_DEVICE, stream) != UHDR_HIP_NO_ERROR)
+    return UHDR_HIP_ERROR_DECODE_ERROR;
+  if (uhdr_hip_jpeg_decode(gj, img[1].len, st->stage[9], gbytes, &gdesc, UHDR_HIP_MEM_DEVICE, stream) != UHDR_HIP_NO_ERROR)
+    return UHDR_HIP_ERROR_DECODE_ERROR;
+  // :796-801: the decoded planes as a YUV420 image with the ICC gamut; the gain map is the first plane of its JPEG
+  ydesc.colorGamut = gamut;
+  uhdr_hip_image_t gimg = gdesc;
+  gimg.chroma_data = nullptr; gimg.chroma_stride = 0; gimg.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
+  uhdr_hip_image_t ddev = *dest;
+  ddev.data = host ? st->stage[10] : dest_data;
+  rc = uhdr_hip_apply_gainmap(&ydesc, &gimg, &md, output_format, max_display_boost, &ddev, apply_mode, UHDR_HIP_MEM_DEVICE, stream);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  dest->data = dest_data;
+  dest->width = ddev.width; dest->height = ddev.height;
+  if (host) HIP_TRY(hipMemcpyAsync(dest_data, ddev.data, out_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return UHDR_HIP_NO_ERROR;
 }
 

@@ -252,6 +252,68 @@ int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_forma
                           size_t dest_capacity, uhdr_hip_image_t* dest, uhdr_hip_metadata_t* metadata, int apply_mode,
                           int mem_space, void* stream);
 
+/* JpegR::appendGainMap (lib/src/jpegr.cpp:951-1130): primary JPEG + gain-map JPEG + metadata -> JPEG/R container (XMP packets of
+ * jpegrutils.cpp:547-611, MPF segment of multipictureformat.cpp:30-92).  exif / icc: payloads of an APP1 / APP2 segment to add, or
+ * NULL; an EXIF segment found inside primary_jpeg moves in front of the XMP segment (and ERROR_MULTIPLE_EXIFS_RECEIVED if exif is
+ * given as well), with JpegDecoderHelper::extractEXIF's position arithmetic (jpegdecoderhelper.cpp:146-188).  Pure host code, no
+ * device needed.  *out_size receives the size (also when out_capacity is too small: ERROR_INSUFFICIENT_RESOURCE). */
+#define UHDR_HIP_ERROR_MULTIPLE_EXIFS_RECEIVED (-20007)
+int uhdr_hip_jpegr_append_gainmap(const void* primary_jpeg, size_t primary_size, const void* gainmap_jpeg, size_t gainmap_size,
+                                  const void* exif, size_t exif_size, const void* icc, size_t icc_size,
+                                  const uhdr_hip_metadata_t* metadata, void* out, size_t out_capacity, size_t* out_size);
+/* IccHelper::writeIccProfile (lib/src/icc.cpp:410-600) for transfer_function == UHDR_HIP_TF_SRGB (the profile of the SDR base
+ * image): "ICC_PROFILE\0" + chunk bytes + profile, as it goes into the primary JPEG's APP2.  Host code. */
+int uhdr_hip_icc_profile(int transfer_function, int color_gamut, void* out, size_t out_capacity, size_t* out_size);
+
+/* JpegR::encodeJPEGR, every overload (lib/include/ultrahdr/jpegr.h:81-185,263-265; lib/src/jpegr.cpp:186-631).  toneMap,
+ * generateGainMap, the BT.601 re-encode of the SDR image (16-aligned zero-padded copy + convertYuv unless it is P3 already), the
+ * JPEG compressions (gain map at quality 85, SDR image at `quality` with the ICC profile) and API-3's JPEG decode run on the
+ * device; the container is assembled on the host.  Raw images live in mem_space; compressed inputs, exif and `out` are HOST
+ * memory.  exif: payload of the APP1 segment ("Exif\0\0"...), or NULL.  sdr_jpeg_gamut: the colorGamut field of the reference's
+ * compressed struct (used when the JPEG carries no ICC profile).  Status values and their order are the reference's
+ * (areInputArgumentsValid :75-183, then each overload's own checks); ERROR_INSUFFICIENT_RESOURCE (with *out_size set) when
+ * out_capacity is too small, where the reference's Write() fails the same way (:46-61).
+ *   api0: P010                       -> toneMap, then as api1                          (:186-247)
+ *   api1: P010 + YUV420                                                                (:249-381)
+ *   api2: P010 + YUV420 + SDR JPEG   -> gain map from the planes, container around the given JPEG   (:384-437)
+ *   api3: P010 + SDR JPEG            -> JPEG decoded (BT.601), gain map, container     (:439-500)
+ *   api4: SDR JPEG + gain-map JPEG + metadata -> container; host only                  (:502-560)
+ *   apix: YUV420 + gain-map plane + metadata  -> both compressed, container            (:562-631) */
+#define UHDR_HIP_ERROR_UNSUPPORTED_WIDTH_HEIGHT (-10002)
+#define UHDR_HIP_ERROR_INVALID_STRIDE (-10004)
+#define UHDR_HIP_ERROR_INVALID_QUALITY_FACTOR (-10007)
+#define UHDR_HIP_ERROR_ENCODE_ERROR (-20001)
+int uhdr_hip_jpegr_encode_api0(const uhdr_hip_image_t* p010_image, int hdr_tf, int quality, const void* exif, size_t exif_size,
+                               void* out, size_t out_capacity, size_t* out_size, int mem_space, void* stream);
+int uhdr_hip_jpegr_encode_api1(const uhdr_hip_image_t* p010_image, const uhdr_hip_image_t* yuv420_image, int hdr_tf, int quality,
+                               const void* exif, size_t exif_size, void* out, size_t out_capacity, size_t* out_size, int mem_space,
+                               void* stream);
+int uhdr_hip_jpegr_encode_api2(const uhdr_hip_image_t* p010_image, const uhdr_hip_image_t* yuv420_image, const void* sdr_jpeg,
+                               size_t sdr_jpeg_size, int sdr_jpeg_gamut, int hdr_tf, void* out, size_t out_capacity,
+                               size_t* out_size, int mem_space, void* stream);
+int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_image, const void* sdr_jpeg, size_t sdr_jpeg_size, int sdr_jpeg_gamut,
+                               int hdr_tf, void* out, size_t out_capacity, size_t* out_size, int mem_space, void* stream);
+int uhdr_hip_jpegr_encode_api4(const void* sdr_jpeg, size_t sdr_jpeg_size, int sdr_jpeg_gamut, const void* gainmap_jpeg,
+                               size_t gainmap_jpeg_size, const uhdr_hip_metadata_t* metadata, void* out, size_t out_capacity,
+                               size_t* out_size);
+int uhdr_hip_jpegr_encode_apix(const uhdr_hip_image_t* yuv420_image, const uhdr_hip_image_t* gainmap_image,
+                               const uhdr_hip_metadata_t* metadata, int quality, const void* exif, size_t exif_size, void* out,
+                               size_t out_capacity, size_t* out_size, int mem_space, void* stream);
+
+/* JpegR::getJPEGRInfo (lib/src/jpegr.cpp:633-653; parseJpegInfo :878-915): the two images of a JPEG/R file and what
+ * JpegDecoderHelper::getCompressedImageParameters reports for each -- size and the first ICC / EXIF / XMP packets
+ * (jpegdecoderhelper.cpp:221-249; the reference copies them into vectors, here they are [offset, size) ranges into the file, size 0
+ * = absent; the XMP range is the reference's buffer minus its extra terminating zero).  gainmap may be NULL.  Host code.
+ * NO_IMAGES_FOUND / GAIN_MAP_IMAGE_NOT_FOUND from the split, DECODE_ERROR for an unreadable header or one over 8192x8192. */
+typedef struct uhdr_hip_jpeg_info {
+  size_t offset, size;            /* the JPEG itself (imgData) */
+  size_t width, height;
+  size_t icc_offset, icc_size;    /* iccData: "ICC_PROFILE\0" + chunk bytes + profile */
+  size_t exif_offset, exif_size;  /* exifData: "Exif\0\0" + TIFF */
+  size_t xmp_offset, xmp_size;    /* xmpData: namespace + '\0' + packet */
+} uhdr_hip_jpeg_info_t;
+int uhdr_hip_jpegr_info(const void* jpegr, size_t jpegr_size, uhdr_hip_jpeg_info_t* primary, uhdr_hip_jpeg_info_t* gainmap);
+
 /* ---- batches (device memory only, asynchronous on `stream`) ------------------------------ */
 /* The reference processes one image per call; a batch is n independent calls with identical
  * (hdr_tf, sdr_is_601 | metadata, output_format, max_display_boost).  Images of equal size share

@@ -49,7 +49,14 @@ enum status_t : int {
   ERROR_ULTRAHDR_INVALID_COLORGAMUT = -10003, ERROR_ULTRAHDR_INVALID_TRANS_FUNC = -10005,
   ERROR_ULTRAHDR_RESOLUTION_MISMATCH = -10006, ERROR_ULTRAHDR_BAD_METADATA = -10010,
   ERROR_ULTRAHDR_INVALID_CROPPING_PARAMETERS = -10011, ERROR_ULTRAHDR_UNSUPPORTED_FEATURE = -30000,
-  ERROR_ULTRAHDR_UNSUPPORTED_MAP_SCALE_FACTOR = -20008, ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE = -20009
+  ERROR_ULTRAHDR_UNSUPPORTED_MAP_SCALE_FACTOR = -20008, ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE = -20009,
+  // the container path (JpegRHip below)
+  ERROR_ULTRAHDR_UNSUPPORTED_WIDTH_HEIGHT = -10002, ERROR_ULTRAHDR_INVALID_STRIDE = -10004,
+  ERROR_ULTRAHDR_INVALID_QUALITY_FACTOR = -10007, ERROR_ULTRAHDR_INVALID_DISPLAY_BOOST = -10008,
+  ERROR_ULTRAHDR_INVALID_OUTPUT_FORMAT = -10009, ERROR_ULTRAHDR_ENCODE_ERROR = -20001, ERROR_ULTRAHDR_DECODE_ERROR = -20002,
+  ERROR_ULTRAHDR_GAIN_MAP_IMAGE_NOT_FOUND = -20003, ERROR_ULTRAHDR_BUFFER_TOO_SMALL = -20004,
+  ERROR_ULTRAHDR_METADATA_ERROR = -20005, ERROR_ULTRAHDR_NO_IMAGES_FOUND = -20006,
+  ERROR_ULTRAHDR_MULTIPLE_EXIFS_RECEIVED = -20007
 };
 
 // ultrahdr_metadata_struct / ultrahdr_uncompressed_struct: same members, order and defaults as the reference
@@ -153,6 +160,64 @@ class JpegDecoderHelperHip {
   std::vector<uint8_t> mResultBuffer;
   size_t mWidth = 0, mHeight = 0;
   bool mSingleChannel = false;
+};
+
+// ---- the JPEG/R codec: the public members of ultrahdr::JpegR (lib/include/ultrahdr/jpegr.h:59-265), same names, argument meaning,
+// defaults and status values; structs as in ultrahdr.h:186-207 and jpegr.h:37-57.  Host buffers in and out; toneMap, gain-map
+// generation / application and both JPEG codecs run on HIP device 0 (uhdr_hip_jpegr_*), the container is parsed / assembled on
+// the host.  Not covered: decodeJPEGR(ULTRAHDR_OUTPUT_SDR) (libjpeg's own RGBA conversion) -> ERROR_ULTRAHDR_UNSUPPORTED_FEATURE.
+struct ultrahdr_compressed_struct {
+  void* data;
+  int length;
+  int maxLength;
+  ultrahdr_color_gamut colorGamut;
+};
+using uhdr_compressed_ptr = ultrahdr_compressed_struct*;
+struct ultrahdr_exif_struct {
+  void* data;
+  size_t length;
+};
+using uhdr_exif_ptr = ultrahdr_exif_struct*;
+struct jpeg_info_struct {
+  std::vector<uint8_t> imgData, iccData, exifData, xmpData;
+  size_t width, height;
+};
+struct jpegr_info_struct {
+  size_t width, height;
+  jpeg_info_struct* primaryImgInfo = nullptr;
+  jpeg_info_struct* gainmapImgInfo = nullptr;
+};
+using j_info_ptr = jpeg_info_struct*;
+using uhdr_info_ptr = jpegr_info_struct*;
+
+class JpegRHip {
+ public:
+  // API-0 (jpegr.h:81) and API-1 (:103)
+  status_t encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, ultrahdr_transfer_function hdr_tf, uhdr_compressed_ptr dest, int quality,
+                       uhdr_exif_ptr exif);
+  status_t encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, uhdr_uncompressed_ptr yuv420_image_ptr, ultrahdr_transfer_function hdr_tf,
+                       uhdr_compressed_ptr dest, int quality, uhdr_exif_ptr exif);
+  // API-2 (:127), API-3 (:150), API-4 (:168)
+  status_t encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_compressed_ptr yuv420jpg_image_ptr,
+                       ultrahdr_transfer_function hdr_tf, uhdr_compressed_ptr dest);
+  status_t encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, uhdr_compressed_ptr yuv420jpg_image_ptr, ultrahdr_transfer_function hdr_tf,
+                       uhdr_compressed_ptr dest);
+  status_t encodeJPEGR(uhdr_compressed_ptr yuv420jpg_image_ptr, uhdr_compressed_ptr gainmapjpg_image_ptr, ultrahdr_metadata_ptr metadata,
+                       uhdr_compressed_ptr dest);
+  // "API-x" (:263): SDR planes + ready gain map + metadata
+  status_t encodeJPEGR(uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_uncompressed_ptr gainmap_image_ptr, ultrahdr_metadata_ptr metadata,
+                       uhdr_compressed_ptr dest, int quality, uhdr_exif_ptr exif);
+  // (:213) dest->data, exif->data and gainmap_image_ptr->data are caller-allocated, as in the reference
+  status_t decodeJPEGR(uhdr_compressed_ptr jpegr_image_ptr, uhdr_uncompressed_ptr dest, float max_display_boost = 3.4028234663852886e38f,
+                       uhdr_exif_ptr exif = nullptr, ultrahdr_output_format output_format = ULTRAHDR_OUTPUT_HDR_LINEAR,
+                       uhdr_uncompressed_ptr gainmap_image_ptr = nullptr, ultrahdr_metadata_ptr metadata = nullptr);
+  // (:231)
+  status_t getJPEGRInfo(uhdr_compressed_ptr jpegr_image_ptr, uhdr_info_ptr jpeg_image_info_ptr);
+
+  void setApplyMode(int mode) { mApplyMode = mode; }   // UHDR_HIP_APPLY_EXACT (default here: decoded files equal the reference's), FAST, LUT
+
+ private:
+  int mApplyMode = 1;
 };
 
 }  // namespace ultrahdr

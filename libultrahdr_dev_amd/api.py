@@ -19,6 +19,10 @@ ERROR_BAD_PTR, ERROR_INVALID_COLORGAMUT, ERROR_INVALID_TRANS_FUNC = -10001, -100
 ERROR_RESOLUTION_MISMATCH, ERROR_BAD_METADATA = -10006, -10010
 ERROR_INVALID_CROPPING_PARAMETERS, ERROR_UNSUPPORTED_FEATURE = -10011, -30000
 ERROR_UNSUPPORTED_MAP_SCALE_FACTOR, ERROR_INSUFFICIENT_RESOURCE = -20008, -20009
+ERROR_UNSUPPORTED_WIDTH_HEIGHT, ERROR_INVALID_STRIDE, ERROR_INVALID_QUALITY_FACTOR = -10002, -10004, -10007
+ERROR_INVALID_DISPLAY_BOOST, ERROR_INVALID_OUTPUT_FORMAT = -10008, -10009
+ERROR_ENCODE_ERROR, ERROR_DECODE_ERROR, ERROR_GAIN_MAP_IMAGE_NOT_FOUND, ERROR_METADATA_ERROR = -20001, -20002, -20003, -20005
+ERROR_NO_IMAGES_FOUND, ERROR_MULTIPLE_EXIFS_RECEIVED = -20006, -20007
 MEM_HOST, MEM_DEVICE = 0, 1
 APPLY_FAST, APPLY_EXACT, APPLY_LUT = 0, 1, 2
 GENERATE_EXACT, GENERATE_LUT, GENERATE_UNFILTERED = 0, 1, 2
@@ -37,6 +41,11 @@ class Image(C.Structure):
 class Effect(C.Structure):
     """uhdr_hip_effect_t: type 0 crop(a=left,b=right,c=top,d=bottom) 1 mirror(a=dir) 2 rotate(a=degrees) 3 resize(a=w,b=h)"""
     _fields_ = [("type", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("d", C.c_int32)]
+
+
+class JpegInfo(C.Structure):
+    """uhdr_hip_jpeg_info_t: one image of a JPEG/R file, ranges into the file"""
+    _fields_ = [(n, C.c_size_t) for n in ("offset", "size", "width", "height", "icc_offset", "icc_size", "exif_offset", "exif_size", "xmp_offset", "xmp_size")]
 
 
 class Metadata(C.Structure):
@@ -71,6 +80,18 @@ SIGNATURES = {
     "uhdr_hip_jpeg_encode": (C.c_int, [_IP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
     "uhdr_hip_jpeg_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_jpegr_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _IP, _MP, C.c_int, C.c_int, C.c_void_p]),
+    "uhdr_hip_jpegr_append_gainmap": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _MP,
+                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "uhdr_hip_icc_profile": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "uhdr_hip_jpegr_encode_api0": (C.c_int, [_IP, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
+    "uhdr_hip_jpegr_encode_api1": (C.c_int, [_IP, _IP, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int,
+                                             C.c_void_p]),
+    "uhdr_hip_jpegr_encode_api2": (C.c_int, [_IP, _IP, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int,
+                                             C.c_void_p]),
+    "uhdr_hip_jpegr_encode_api3": (C.c_int, [_IP, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
+    "uhdr_hip_jpegr_encode_api4": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, _MP, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "uhdr_hip_jpegr_encode_apix": (C.c_int, [_IP, _IP, _MP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
+    "uhdr_hip_jpegr_info": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(JpegInfo), C.POINTER(JpegInfo)]),
     "uhdr_hip_lut_table": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t)]),
     "uhdr_hip_gain_lut": (C.c_int, [_MP, C.c_int, C.c_float, C.POINTER(C.c_float)]),
     "uhdr_hip_idw_tables": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),

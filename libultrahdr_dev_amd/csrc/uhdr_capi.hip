@@ -707,6 +707,382 @@ int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_forma
   return UHDR_HIP_NO_ERROR;
 }
 
+int uhdr_hip_jpegr_append_gainmap(const void* primary_jpeg, size_t primary_size, const void* gainmap_jpeg, size_t gainmap_size,
+                                  const void* exif, size_t exif_size, const void* icc, size_t icc_size,
+                                  const uhdr_hip_metadata_t* metadata, void* out, size_t out_capacity, size_t* out_size) {
+  if (primary_jpeg == nullptr || gainmap_jpeg == nullptr || metadata == nullptr || out_size == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  std::vector<uint8_t> file;
+  const int rc = jpegr::append_gainmap(static_cast<const uint8_t*>(primary_jpeg), primary_size, static_cast<const uint8_t*>(gainmap_jpeg),
+                                       gainmap_size, static_cast<const uint8_t*>(exif), exif_size, static_cast<const uint8_t*>(icc), icc_size,
+                                       *metadata, file);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  *out_size = file.size();
+  if (out == nullptr || out_capacity < file.size()) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  memcpy(out, file.data(), file.size());
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_icc_profile(int transfer_function, int color_gamut, void* out, size_t out_capacity, size_t* out_size) {
+  if (out_size == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (transfer_function != UHDR_HIP_TF_SRGB) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;   // HLG / PQ profiles (tone-map LUTs) are not built
+  std::vector<uint8_t> icc;
+  if (!jpegr::icc_profile_srgb_transfer(color_gamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  *out_size = icc.size();
+  if (out == nullptr || out_capacity < icc.size()) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  memcpy(out, icc.data(), icc.size());
+  return UHDR_HIP_NO_ERROR;
+}
+
+}  // extern "C"
+
+namespace {
+
+// JpegR::areInputArgumentsValid, the four-argument form (jpegr.cpp:75-173), checks in the reference's order
+int check_encode_inputs(const uhdr_hip_image_t* p010, const uhdr_hip_image_t* yuv, int hdr_tf, const void* out, const size_t* out_size) {
+  if (p010 == nullptr || p010->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if ((p010->width | p010->height) & 1) return UHDR_HIP_ERROR_UNSUPPORTED_WIDTH_HEIGHT;
+  if (p010->width < 8 || p010->height < 8 || p010->width > 8192 || p010->height > 8192) return UHDR_HIP_ERROR_UNSUPPORTED_WIDTH_HEIGHT;
+  if (p010->colorGamut <= UHDR_HIP_CG_UNSPECIFIED || p010->colorGamut > UHDR_HIP_CG_BT2100) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  if (p010->luma_stride != 0 && p010->luma_stride < p010->width) return UHDR_HIP_ERROR_INVALID_STRIDE;
+  if (p010->chroma_data != nullptr && p010->chroma_stride < p010->width) return UHDR_HIP_ERROR_INVALID_STRIDE;
+  if (out == nullptr || out_size == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (hdr_tf != UHDR_HIP_TF_LINEAR && hdr_tf != UHDR_HIP_TF_HLG && hdr_tf != UHDR_HIP_TF_PQ) return UHDR_HIP_ERROR_INVALID_TRANS_FUNC;
+  if (yuv == nullptr) return UHDR_HIP_NO_ERROR;
+  if (yuv->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (yuv->luma_stride != 0 && yuv->luma_stride < yuv->width) return UHDR_HIP_ERROR_INVALID_STRIDE;
+  if (yuv->chroma_data != nullptr && yuv->chroma_stride < yuv->width / 2) return UHDR_HIP_ERROR_INVALID_STRIDE;
+  if (p010->width != yuv->width || p010->height != yuv->height) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;
+  if (yuv->colorGamut <= UHDR_HIP_CG_UNSPECIFIED || yuv->colorGamut > UHDR_HIP_CG_BT2100) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  return UHDR_HIP_NO_ERROR;
+}
+
+// "clean up input structure for later usage" (jpegr.cpp:261-275 and the same lines of every API)
+void default_p010(uhdr_hip_image_t* im) {
+  if (im->luma_stride == 0) im->luma_stride = im->width;
+  if (im->chroma_data == nullptr) { im->chroma_data = static_cast<uint16_t*>(im->data) + im->luma_stride * im->height; im->chroma_stride = im->luma_stride; }
+  im->pixelFormat = UHDR_HIP_PIX_FMT_P010;
+}
+void default_yuv(uhdr_hip_image_t* im) {
+  if (im->luma_stride == 0) im->luma_stride = im->width;
+  if (im->chroma_data == nullptr) { im->chroma_data = static_cast<uint8_t*>(im->data) + im->luma_stride * im->height; im->chroma_stride = im->luma_stride >> 1; }
+  im->pixelFormat = UHDR_HIP_PIX_FMT_YUV420;
+}
+
+struct EncodeCtx {
+  DeviceState* st;
+  void* stream;
+  int mem_space;
+  bool host() const { return mem_space != UHDR_HIP_MEM_DEVICE; }
+  hipStream_t s() const { return static_cast<hipStream_t>(stream); }
+};
+
+// JpegEncoderHelper::compressImage with the bytes landing in host memory whichever side the planes live on
+int jpeg_to_host(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, const std::vector<uint8_t>* icc, std::vector<uint8_t>& dst, size_t* n) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    int r;
+    if (c.host()) {
+      r = uhdr_hip_jpeg_encode(&img, q, icc ? icc->data() : nullptr, icc ? icc->size() : 0, dst.data(), dst.size(), n, UHDR_HIP_MEM_HOST, c.stream);
+    } else {   // device planes in, bytes to a device buffer, then down
+      int r2;
+      if ((r2 = stage_reserve(c.st, 10, dst.size())) != 0) return r2;
+      r = uhdr_hip_jpeg_encode(&img, q, icc ? icc->data() : nullptr, icc ? icc->size() : 0, c.st->stage[10], dst.size(), n, UHDR_HIP_MEM_DEVICE, c.stream);
+      if (r == UHDR_HIP_NO_ERROR) {
+        HIP_TRY(hipMemcpyAsync(dst.data(), c.st->stage[10], *n, hipMemcpyDeviceToHost, c.s()));
+        HIP_TRY(hipStreamSynchronize(c.s()));
+      }
+    }
+    if (r != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return r;
+    dst.resize(*n + 16);
+  }
+  return UHDR_HIP_ERROR_ENCODE_ERROR;
+}
+
+// compressGainMap (jpegr.cpp:806-821): one plane at kMapCompressQuality = 85
+int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, std::vector<uint8_t>& jpeg, size_t* n) {
+  uhdr_hip_image_t g = map;
+  g.chroma_data = nullptr; g.chroma_stride = 0; g.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
+  jpeg.resize(map.width * map.height + 65536);
+  return jpeg_to_host(c, g, 85, nullptr, jpeg, n) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
+}
+
+// generateGainMap followed by compressGainMap: the block every one of API-0..3 contains (e.g. jpegr.cpp:277-292)
+int make_gainmap_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& p010, int hdr_tf, int sdr_is_601,
+                      uhdr_hip_metadata_t* md, std::vector<uint8_t>& jpeg, size_t* n) {
+  const size_t mw = yuv.width / 4, mh = yuv.height / 4;
+  std::vector<uint8_t> host_map;
+  uhdr_hip_image_t map = yuv;
+  int rc;
+  if ((rc = stage_reserve(c.st, 9, mw * mh + 64)) != 0) return rc;
+  if (c.host()) { host_map.resize(mw * mh ? mw * mh : 1); map.data = host_map.data(); } else map.data = c.st->stage[9];
+  rc = uhdr_hip_generate_gainmap(&yuv, &p010, hdr_tf, md, &map, sdr_is_601, c.mem_space, c.stream);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  map.width = mw; map.height = mh; map.luma_stride = mw;
+  return gainmap_to_jpeg(c, map, jpeg, n);
+}
+
+int deliver(const std::vector<uint8_t>& file, void* out, size_t out_capacity, size_t* out_size) {
+  *out_size = file.size();
+  if (out_capacity < file.size()) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;   // Write() running past maxLength, jpegr.cpp:46-61
+  memcpy(out, file.data(), file.size());
+  return UHDR_HIP_NO_ERROR;
+}
+
+// the tail API-0 and API-1 share (jpegr.cpp:210-247 / :294-380): ICC for the SDR gamut, BT.601 re-encode unless P3, JPEG at `quality`,
+// appendGainMap.  `enc` must be private to the call when it is not P3 (it is converted in place).
+int finish_from_planes(const EncodeCtx& c, uhdr_hip_image_t enc, int quality, const void* exif, size_t exif_size,
+                       const std::vector<uint8_t>& gm_jpeg, size_t gm_n, const uhdr_hip_metadata_t& md, void* out, size_t out_capacity,
+                       size_t* out_size) {
+  std::vector<uint8_t> icc;
+  if (!jpegr::icc_profile_srgb_transfer(enc.colorGamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  int rc;
+  if (enc.colorGamut != UHDR_HIP_CG_P3 && (rc = uhdr_hip_convert_yuv(&enc, enc.colorGamut, UHDR_HIP_CG_P3, c.mem_space, c.stream)) != UHDR_HIP_NO_ERROR)
+    return rc;
+  std::vector<uint8_t> sdr_jpeg(enc.width * enc.height + 65536);
+  size_t sdr_n = 0;
+  if (jpeg_to_host(c, enc, quality, &icc, sdr_jpeg, &sdr_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
+  std::vector<uint8_t> file;
+  rc = jpegr::append_gainmap(sdr_jpeg.data(), sdr_n, gm_jpeg.data(), gm_n, static_cast<const uint8_t*>(exif), exif_size, nullptr, 0, md, file);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  return deliver(file, out, out_capacity, out_size);
+}
+
+}  // namespace
+
+extern "C" {
+
+// JpegR::encodeJPEGR API-0 (jpegr.cpp:186-247)
+int uhdr_hip_jpegr_encode_api0(const uhdr_hip_image_t* p010_in, int hdr_tf, int quality, const void* exif, size_t exif_size, void* out,
+                               size_t out_capacity, size_t* out_size, int mem_space, void* stream) {
+  if (quality < 0 || quality > 100) return UHDR_HIP_ERROR_INVALID_QUALITY_FACTOR;                                 // :175-183
+  int rc = check_encode_inputs(p010_in, nullptr, hdr_tf, out, out_size);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (exif == nullptr && exif_size != 0) return UHDR_HIP_ERROR_BAD_PTR;                                          // :190-193
+  uhdr_hip_image_t p010 = *p010_in;
+  default_p010(&p010);
+  EncodeCtx c{nullptr, stream, mem_space};
+  if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
+  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+
+  // :208-223: the tone-mapped SDR image, luma stride rounded up to the encoder's 16-column batch, zero-initialised
+  const size_t w = p010.width, h = p010.height, ls = (w + 15) / 16 * 16, total = ls * h * 3 / 2;
+  std::vector<uint8_t> host_yuv;
+  uhdr_hip_image_t yuv;
+  memset(&yuv, 0, sizeof(yuv));
+  yuv.width = w; yuv.height = h; yuv.colorGamut = p010.colorGamut;
+  yuv.luma_stride = ls; yuv.chroma_stride = ls >> 1; yuv.pixelFormat = UHDR_HIP_PIX_FMT_YUV420;
+  if (c.host()) {
+    host_yuv.assign(total, 0);
+    yuv.data = host_yuv.data();
+  } else {
+    if ((rc = stage_reserve(c.st, 8, total + 64)) != 0) return rc;
+    HIP_TRY(hipMemsetAsync(c.st->stage[8], 0, total, c.s()));
+    yuv.data = c.st->stage[8];
+  }
+  yuv.chroma_data = static_cast<uint8_t*>(yuv.data) + ls * h;
+  if ((rc = uhdr_hip_tonemap(&p010, &yuv, mem_space, stream)) != UHDR_HIP_NO_ERROR) return rc;                    // :226
+
+  uhdr_hip_metadata_t md;
+  std::vector<uint8_t> gm_jpeg;
+  size_t gm_n = 0;
+  if ((rc = make_gainmap_jpeg(c, yuv, p010, hdr_tf, 0, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;     // :228-244
+  return finish_from_planes(c, yuv, quality, exif, exif_size, gm_jpeg, gm_n, md, out, out_capacity, out_size);
+}
+
+// JpegR::encodeJPEGR API-1 (jpegr.cpp:249-381)
+int uhdr_hip_jpegr_encode_api1(const uhdr_hip_image_t* p010_in, const uhdr_hip_image_t* yuv_in, int hdr_tf, int quality, const void* exif,
+                               size_t exif_size, void* out, size_t out_capacity, size_t* out_size, int mem_space, void* stream) {
+  if (yuv_in == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                           // :253-256
+  if (quality < 0 || quality > 100) return UHDR_HIP_ERROR_INVALID_QUALITY_FACTOR;                                 // :175-183
+  int rc = check_encode_inputs(p010_in, yuv_in, hdr_tf, out, out_size);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (exif == nullptr && exif_size != 0) return UHDR_HIP_ERROR_BAD_PTR;                                          // :258-261
+  uhdr_hip_image_t p010 = *p010_in, yuv = *yuv_in;
+  default_p010(&p010);
+  default_yuv(&yuv);
+  EncodeCtx c{nullptr, stream, mem_space};
+  if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
+  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  const size_t w = yuv.width, h = yuv.height;
+
+  uhdr_hip_metadata_t md;
+  std::vector<uint8_t> gm_jpeg;
+  size_t gm_n = 0;
+  if ((rc = make_gainmap_jpeg(c, yuv, p010, hdr_tf, 0, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;     // :277-292
+
+  // :297-358: unless the SDR image is P3 (= BT.601 encoding) already, a copy with 16-aligned strides, zero padded, is what gets converted
+  uhdr_hip_image_t enc = yuv;
+  std::vector<uint8_t> host_601;
+  if (yuv.colorGamut != UHDR_HIP_CG_P3) {
+    const size_t ls = (w + 15) / 16 * 16, cs = ls >> 1, total = ls * h * 3 / 2;
+    enc.luma_stride = ls; enc.chroma_stride = cs;
+    const uint8_t* src_u = static_cast<const uint8_t*>(yuv.chroma_data);
+    const uint8_t* src_v = src_u + yuv.chroma_stride * h / 2;
+    if (c.host()) {
+      host_601.assign(total ? total : 1, 0);
+      enc.data = host_601.data();
+      uint8_t* du = host_601.data() + ls * h;
+      uint8_t* dv = du + cs * h / 2;
+      for (size_t r = 0; r < h; ++r) memcpy(host_601.data() + r * ls, static_cast<const uint8_t*>(yuv.data) + r * yuv.luma_stride, w);
+      for (size_t r = 0; r < h / 2; ++r) { memcpy(du + r * cs, src_u + r * yuv.chroma_stride, w / 2); memcpy(dv + r * cs, src_v + r * yuv.chroma_stride, w / 2); }
+    } else {
+      if ((rc = stage_reserve(c.st, 8, total + 64)) != 0) return rc;
+      uint8_t* d = static_cast<uint8_t*>(c.st->stage[8]);
+      HIP_TRY(hipMemsetAsync(d, 0, total, c.s()));
+      HIP_TRY(hipMemcpy2DAsync(d, ls, yuv.data, yuv.luma_stride, w, h, hipMemcpyDeviceToDevice, c.s()));
+      HIP_TRY(hipMemcpy2DAsync(d + ls * h, cs, src_u, yuv.chroma_stride, w / 2, h / 2, hipMemcpyDeviceToDevice, c.s()));
+      HIP_TRY(hipMemcpy2DAsync(d + ls * h + cs * h / 2, cs, src_v, yuv.chroma_stride, w / 2, h / 2, hipMemcpyDeviceToDevice, c.s()));
+      enc.data = d;
+    }
+    enc.chroma_data = static_cast<uint8_t*>(enc.data) + ls * h;
+  }
+  return finish_from_planes(c, enc, quality, exif, exif_size, gm_jpeg, gm_n, md, out, out_capacity, out_size);
+}
+
+// JpegR::encodeJPEGR API-4 (jpegr.cpp:502-560): host bytes only, nothing runs on the device
+int uhdr_hip_jpegr_encode_api4(const void* sdr_jpeg, size_t sdr_jpeg_size, int sdr_jpeg_gamut, const void* gainmap_jpeg, size_t gainmap_jpeg_size,
+                               const uhdr_hip_metadata_t* metadata, void* out, size_t out_capacity, size_t* out_size) {
+  if (sdr_jpeg == nullptr || gainmap_jpeg == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                              // :505-512
+  if (out == nullptr || out_size == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                       // :513-516
+  const uint8_t* pj = static_cast<const uint8_t*>(sdr_jpeg);
+  if (!jpegr::has_valid_header(pj, sdr_jpeg_size)) return UHDR_HIP_ERROR_DECODE_ERROR;                            // :520-524
+  const uint8_t* have = nullptr;
+  size_t have_len = 0;
+  static const char kIccSig[] = "ICC_PROFILE";
+  std::vector<uint8_t> icc;
+  if (!jpegr::find_app_segment(pj, sdr_jpeg_size, 0xE2, kIccSig, sizeof(kIccSig), &have, &have_len)) {          // :527-541
+    if (sdr_jpeg_gamut <= UHDR_HIP_CG_UNSPECIFIED || sdr_jpeg_gamut > UHDR_HIP_CG_BT2100) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+    jpegr::icc_profile_srgb_transfer(sdr_jpeg_gamut, icc);
+  }
+  if (metadata == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                         // :955-958
+  std::vector<uint8_t> file;
+  const int rc = jpegr::append_gainmap(pj, sdr_jpeg_size, static_cast<const uint8_t*>(gainmap_jpeg), gainmap_jpeg_size, nullptr, 0,
+                                       icc.empty() ? nullptr : icc.data(), icc.size(), *metadata, file);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  return deliver(file, out, out_capacity, out_size);
+}
+
+// JpegR::encodeJPEGR API-2 (jpegr.cpp:384-437)
+int uhdr_hip_jpegr_encode_api2(const uhdr_hip_image_t* p010_in, const uhdr_hip_image_t* yuv_in, const void* sdr_jpeg, size_t sdr_jpeg_size,
+                               int sdr_jpeg_gamut, int hdr_tf, void* out, size_t out_capacity, size_t* out_size, int mem_space, void* stream) {
+  if (yuv_in == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                           // :390-393
+  if (sdr_jpeg == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                         // :394-397
+  int rc = check_encode_inputs(p010_in, yuv_in, hdr_tf, out, out_size);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  uhdr_hip_image_t p010 = *p010_in, yuv = *yuv_in;
+  default_p010(&p010);
+  default_yuv(&yuv);
+  EncodeCtx c{nullptr, stream, mem_space};
+  if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
+  uhdr_hip_metadata_t md;
+  std::vector<uint8_t> gm_jpeg;
+  size_t gm_n = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_jpegr_mu);
+    if ((rc = make_gainmap_jpeg(c, yuv, p010, hdr_tf, 0, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;   // :416-434
+  }
+  return uhdr_hip_jpegr_encode_api4(sdr_jpeg, sdr_jpeg_size, sdr_jpeg_gamut, gm_jpeg.data(), gm_n, &md, out, out_capacity, out_size);
+}
+
+// JpegR::encodeJPEGR API-3 (jpegr.cpp:439-500): the SDR rendition arrives as a JPEG only and is decoded on the device
+int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_in, const void* sdr_jpeg, size_t sdr_jpeg_size, int sdr_jpeg_gamut, int hdr_tf,
+                               void* out, size_t out_capacity, size_t* out_size, int mem_space, void* stream) {
+  if (sdr_jpeg == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                         // :443-446
+  int rc = check_encode_inputs(p010_in, nullptr, hdr_tf, out, out_size);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  uhdr_hip_image_t p010 = *p010_in;
+  default_p010(&p010);
+  EncodeCtx c{nullptr, stream, mem_space};
+  if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
+  const uint8_t* pj = static_cast<const uint8_t*>(sdr_jpeg);
+
+  // :457-462 decode; a header probe first for the size
+  uhdr_hip_image_t ydesc;
+  rc = uhdr_hip_jpeg_decode(pj, sdr_jpeg_size, nullptr, 0, &ydesc, UHDR_HIP_MEM_DEVICE, stream);
+  if (rc == UHDR_HIP_ERROR_UNSUPPORTED_FEATURE) return rc;
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE || ydesc.pixelFormat != UHDR_HIP_PIX_FMT_YUV420) return UHDR_HIP_ERROR_DECODE_ERROR;
+  const size_t w = ydesc.width, h = ydesc.height, ybytes = w * h + 2 * (w * h / 4);
+  uhdr_hip_metadata_t md;
+  std::vector<uint8_t> gm_jpeg;
+  size_t gm_n = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_jpegr_mu);
+    std::vector<uint8_t> host_yuv;
+    void* planes;
+    if (c.host()) { host_yuv.resize(ybytes); planes = host_yuv.data(); }
+    else { if ((rc = stage_reserve(c.st, 8, ybytes + 64)) != 0) return rc; planes = c.st->stage[8]; }
+    if (uhdr_hip_jpeg_decode(pj, sdr_jpeg_size, planes, ybytes, &ydesc, mem_space, stream) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_DECODE_ERROR;
+    // :467-488 the gamut: the ICC profile's when there is one (and it must agree with a configured gamut), else the configured one
+    const uint8_t* icc = nullptr;
+    size_t icc_len = 0;
+    static const char kIccSig[] = "ICC_PROFILE";
+    if (jpegr::find_app_segment(pj, sdr_jpeg_size, 0xE2, kIccSig, sizeof(kIccSig), &icc, &icc_len)) {
+      const int cg = jpegr::gamut_from_icc(icc, icc_len);
+      if (cg == UHDR_HIP_CG_UNSPECIFIED || (sdr_jpeg_gamut != UHDR_HIP_CG_UNSPECIFIED && sdr_jpeg_gamut != cg)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+      ydesc.colorGamut = cg;
+    } else {
+      if (sdr_jpeg_gamut <= UHDR_HIP_CG_UNSPECIFIED || sdr_jpeg_gamut > UHDR_HIP_CG_BT2100) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+      ydesc.colorGamut = sdr_jpeg_gamut;
+    }
+    if (p010.width != w || p010.height != h) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;                           // :496-499
+    if ((rc = make_gainmap_jpeg(c, ydesc, p010, hdr_tf, 1 /* sdr_is_601 */, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;
+  }
+  return uhdr_hip_jpegr_encode_api4(sdr_jpeg, sdr_jpeg_size, sdr_jpeg_gamut, gm_jpeg.data(), gm_n, &md, out, out_capacity, out_size);
+}
+
+// JpegR::encodeJPEGR "API-x" (jpegr.cpp:562-631): SDR planes + a ready gain map + its metadata; no BT.601 re-encode on this path
+int uhdr_hip_jpegr_encode_apix(const uhdr_hip_image_t* yuv_in, const uhdr_hip_image_t* gainmap, const uhdr_hip_metadata_t* metadata, int quality,
+                               const void* exif, size_t exif_size, void* out, size_t out_capacity, size_t* out_size, int mem_space, void* stream) {
+  if (quality < 0 || quality > 100) return UHDR_HIP_ERROR_INVALID_QUALITY_FACTOR;                                 // :566-568
+  if (yuv_in == nullptr || yuv_in->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (gainmap == nullptr || gainmap->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (metadata == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if (out == nullptr || out_size == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  uhdr_hip_image_t yuv = *yuv_in;
+  default_yuv(&yuv);
+  EncodeCtx c{nullptr, stream, mem_space};
+  int rc;
+  if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
+  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  std::vector<uint8_t> gm_jpeg, icc;
+  size_t gm_n = 0;
+  if ((rc = gainmap_to_jpeg(c, *gainmap, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;                        // :590-597
+  if (!jpegr::icc_profile_srgb_transfer(yuv.colorGamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;           // :599-600
+  std::vector<uint8_t> sdr_jpeg(yuv.width * yuv.height + 65536);
+  size_t sdr_n = 0;
+  if (jpeg_to_host(c, yuv, quality, &icc, sdr_jpeg, &sdr_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;   // :602-611
+  std::vector<uint8_t> file;
+  rc = jpegr::append_gainmap(sdr_jpeg.data(), sdr_n, gm_jpeg.data(), gm_n, static_cast<const uint8_t*>(exif), exif_size, nullptr, 0, *metadata, file);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  return deliver(file, out, out_capacity, out_size);
+}
+
+// JpegR::getJPEGRInfo (jpegr.cpp:633-653)
+int uhdr_hip_jpegr_info(const void* jpegr, size_t jpegr_size, uhdr_hip_jpeg_info_t* primary, uhdr_hip_jpeg_info_t* gainmap) {
+  if (jpegr == nullptr || primary == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  const uint8_t* file = static_cast<const uint8_t*>(jpegr);
+  jpegr::Range img[2];
+  const int found = jpegr::find_images(file, jpegr_size, img);
+  if (found == 0) return UHDR_HIP_ERROR_NO_IMAGES_FOUND;
+  if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
+  auto parse = [&](const jpegr::Range& r, uhdr_hip_jpeg_info_t* info) -> int {   // parseJpegInfo :878-915
+    const uint8_t* j = file + r.begin;
+    struct { int w, h; } di;
+    if (!jpegr::has_valid_header(j, r.len) || !jpegr::dimensions(j, r.len, &di.w, &di.h)) return UHDR_HIP_ERROR_DECODE_ERROR;
+    if (di.w > 8192 || di.h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;                                         // jpegdecoderhelper.cpp:251-256
+    memset(info, 0, sizeof(*info));
+    info->offset = r.begin; info->size = r.len;
+    info->width = (size_t)di.w; info->height = (size_t)di.h;
+    jpegr::first_packets(j, r.len, &info->xmp_offset, &info->xmp_size, &info->exif_offset, &info->exif_size, &info->icc_offset, &info->icc_size);
+    if (info->xmp_size) info->xmp_offset += r.begin;
+    if (info->exif_size) info->exif_offset += r.begin;
+    if (info->icc_size) info->icc_offset += r.begin;
+    return UHDR_HIP_NO_ERROR;
+  };
+  int rc = parse(img[0], primary);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  return gainmap != nullptr ? parse(img[1], gainmap) : UHDR_HIP_NO_ERROR;
+}
+
 int uhdr_hip_lut_table(int which, float* out, size_t capacity, size_t* count) {
   if (out == nullptr || count == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   DeviceState* st = nullptr;

@@ -3,6 +3,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+#include <vector>
+
 struct uhdr_hip_metadata;
 
 namespace uhdr {
@@ -14,5 +17,16 @@ bool find_app_segment(const uint8_t* jpg, size_t n, unsigned marker, const char*
                       size_t* payload_len);
 bool metadata_from_xmp(const uint8_t* payload, size_t len, uhdr_hip_metadata* md);
 int gamut_from_icc(const uint8_t* payload, size_t len);
+std::string xmp_primary(int secondary_image_length, const char* version);
+std::string xmp_secondary(const uhdr_hip_metadata& md);
+void mpf_segment(int primary_size, int primary_offset, int secondary_size, int secondary_offset, std::vector<uint8_t>& out);
+bool icc_profile_srgb_transfer(int gamut, std::vector<uint8_t>& out);
+// exif / icc: payloads of the APP1 / APP2 segments to add (nullptr = none)
+int append_gainmap(const uint8_t* primary, size_t n1, const uint8_t* gainmap, size_t n2, const uint8_t* exif, size_t exif_len,
+                   const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata& md, std::vector<uint8_t>& out);
+void first_packets(const uint8_t* jpg, size_t n, size_t* xmp_off, size_t* xmp_len, size_t* exif_off, size_t* exif_len, size_t* icc_off,
+                   size_t* icc_len);
+bool dimensions(const uint8_t* jpg, size_t n, int* w, int* h);
+bool has_valid_header(const uint8_t* jpg, size_t n);   // JpegDecoderHelper::getCompressedImageParameters succeeding
 }  // namespace jpegr
 }  // namespace uhdr

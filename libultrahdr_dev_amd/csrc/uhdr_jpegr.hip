@@ -11,7 +11,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/uhdr_hip.h"
 #include "uhdr_jpegr.h"
@@ -190,6 +193,291 @@ int gamut_from_icc(const uint8_t* payload, size_t len) {
     if (same) return gamut[g];
   }
   return UHDR_HIP_CG_UNSPECIFIED;
+}
+
+// ====================================================================================================================
+// assembly: generateXmpForPrimaryImage / generateXmpForSecondaryImage (jpegrutils.cpp:547-611), generateMpf
+// (multipictureformat.cpp:30-92), IccHelper::writeIccProfile for the sRGB transfer (icc.cpp:410-600), JpegR::appendGainMap
+// (jpegr.cpp:951-1130).  The text layout is image_io's XmlWriter's (two-space indentation, one attribute per line); numbers
+// go through an ostream with default formatting, i.e. "%g".  Pinned: re-assembling the two JPEG streams of the reference's own
+// tests/data/sample_jpegr.jpeg reproduces that file byte for byte (tests/test_jpegr_container.py).
+// ====================================================================================================================
+namespace {
+std::string num(double v) {
+  char b[64];
+  snprintf(b, sizeof(b), "%g", v);
+  return b;
+}
+const char kXmpHead[] =
+    "<x:xmpmeta\n  xmlns:x=\"adobe:ns:meta/\"\n  x:xmptk=\"Adobe XMP Core 5.1.2\">\n  <rdf:RDF\n"
+    "    xmlns:rdf=\"http://www.w3.org/1999/02/22-rdf-syntax-ns#\">\n    <rdf:Description\n";
+void be16(std::vector<uint8_t>& b, unsigned v) { b.push_back((uint8_t)(v >> 8)); b.push_back((uint8_t)v); }
+void be32(std::vector<uint8_t>& b, uint32_t v) { be16(b, v >> 16); be16(b, v & 0xFFFFu); }
+}  // namespace
+
+std::string xmp_primary(int secondary_image_length, const char* version) {
+  std::string s = kXmpHead;
+  s += "      xmlns:Container=\"http://ns.google.com/photos/1.0/container/\"\n";
+  s += "      xmlns:Item=\"http://ns.google.com/photos/1.0/container/item/\"\n";
+  s += "      xmlns:hdrgm=\"http://ns.adobe.com/hdr-gain-map/1.0/\"\n";
+  s += std::string("      hdrgm:Version=\"") + version + "\">\n";
+  s += "      <Container:Directory>\n        <rdf:Seq>\n          <rdf:li\n            rdf:parseType=\"Resource\">\n";
+  s += "            <Container:Item\n              Item:Semantic=\"Primary\"\n              Item:Mime=\"image/jpeg\"/>\n          </rdf:li>\n";
+  s += "          <rdf:li\n            rdf:parseType=\"Resource\">\n            <Container:Item\n              Item:Semantic=\"GainMap\"\n";
+  s += "              Item:Mime=\"image/jpeg\"\n              Item:Length=\"" + std::to_string(secondary_image_length) + "\"/>\n          </rdf:li>\n";
+  s += "        </rdf:Seq>\n      </Container:Directory>\n    </rdf:Description>\n  </rdf:RDF>\n</x:xmpmeta>\n";
+  return s;
+}
+
+std::string xmp_secondary(const uhdr_hip_metadata_t& md) {
+  std::string s = kXmpHead;
+  s += "      xmlns:hdrgm=\"http://ns.adobe.com/hdr-gain-map/1.0/\"\n";
+  s += std::string("      hdrgm:Version=\"") + md.version + "\"\n";
+  s += "      hdrgm:GainMapMin=\"" + num(log2((double)md.minContentBoost)) + "\"\n";      // log2(float) binds to the double function
+  s += "      hdrgm:GainMapMax=\"" + num(log2((double)md.maxContentBoost)) + "\"\n";
+  s += "      hdrgm:Gamma=\"" + num((double)md.gamma) + "\"\n";
+  s += "      hdrgm:OffsetSDR=\"" + num((double)md.offsetSdr) + "\"\n";
+  s += "      hdrgm:OffsetHDR=\"" + num((double)md.offsetHdr) + "\"\n";
+  s += "      hdrgm:HDRCapacityMin=\"" + num(log2((double)md.hdrCapacityMin)) + "\"\n";
+  s += "      hdrgm:HDRCapacityMax=\"" + num(log2((double)md.hdrCapacityMax)) + "\"\n";
+  s += "      hdrgm:BaseRenditionIsHDR=\"False\"/>\n  </rdf:RDF>\n</x:xmpmeta>\n";
+  return s;
+}
+
+// 86 bytes: "MPF\0", big-endian TIFF header, index IFD with version / number of images / MP entries, two 16-byte entries
+void mpf_segment(int primary_size, int primary_offset, int secondary_size, int secondary_offset, std::vector<uint8_t>& b) {
+  b.clear();
+  const uint8_t sig[8] = {'M', 'P', 'F', 0, 0x4D, 0x4D, 0x00, 0x2A};
+  b.insert(b.end(), sig, sig + 8);
+  be32(b, 8);                      // index IFD offset (endianness value + this field)
+  be16(b, 3);                      // three tags
+  be16(b, 0xB000); be16(b, 7); be32(b, 4); b.insert(b.end(), {'0', '1', '0', '0'});   // version
+  be16(b, 0xB001); be16(b, 4); be32(b, 1); be32(b, 2);                                // number of images
+  be16(b, 0xB002); be16(b, 7); be32(b, 32);                                           // MP entries: 2 x 16 bytes ...
+  be32(b, (uint32_t)(b.size() - 4 + 4 + 4));                                          // ... at this offset from the endianness field
+  be32(b, 0);                      // no attribute IFD
+  be32(b, 0x030000); be32(b, (uint32_t)primary_size); be32(b, (uint32_t)primary_offset); be16(b, 0); be16(b, 0);
+  be32(b, 0x000000); be32(b, (uint32_t)secondary_size); be32(b, (uint32_t)secondary_offset); be16(b, 0); be16(b, 0);
+}
+
+// writeIccProfile(ULTRAHDR_TF_SRGB, gamut): 'desc', the three colorants, 'wtpt', three parametric curves, 'cprt'; the payload
+// starts with the "ICC_PROFILE\0" identifier, chunk count 1, chunk index 1 (what JpegEncoderHelper writes into APP2)
+bool icc_profile_srgb_transfer(int gamut, std::vector<uint8_t>& out) {
+  auto ff = [](int v) { return (float)v * 1.52587890625e-5f; };
+  const float mats[3][3][3] = {
+      {{ff(0x6FA2), ff(0x6299), ff(0x24A0)}, {ff(0x38F5), ff(0xB785), ff(0x0F84)}, {ff(0x0390), ff(0x18DA), ff(0xB6CF)}},
+      {{0.515102f, 0.291965f, 0.157153f}, {0.241182f, 0.692236f, 0.0665819f}, {-0.00104941f, 0.0418818f, 0.784378f}},
+      {{0.673459f, 0.165661f, 0.125100f}, {0.279033f, 0.675338f, 0.0456288f}, {-0.00193139f, 0.0299794f, 0.797162f}}};
+  const char* names[3] = {"sRGB", "Display P3", "Rec2020"};
+  if (gamut < UHDR_HIP_CG_BT709 || gamut > UHDR_HIP_CG_BT2100) return false;
+  auto fixed = [](float x) {   // float_round_to_fixed (icc.h:157-165)
+    float v = (float)floor((double)x * 65536.0 + 0.5);
+    v = v < 2147483520.0f ? v : 2147483520.0f;
+    v = v > -2147483520.0f ? v : -2147483520.0f;
+    return (uint32_t)(int32_t)v;
+  };
+  auto text_tag = [](const std::string& t) {
+    std::vector<uint8_t> b;
+    b.insert(b.end(), {'m', 'l', 'u', 'c'});
+    be32(b, 0); be32(b, 1); be32(b, 12); b.insert(b.end(), {'e', 'n', 'U', 'S'}); be32(b, (uint32_t)(2 * t.size())); be32(b, 28);
+    for (char c : t) { b.push_back(0); b.push_back((uint8_t)c); }
+    b.resize((((2 * t.size() + 28) + 2) >> 2) << 2, 0);
+    return b;
+  };
+  auto xyz_tag = [&](float x, float y, float z) {
+    std::vector<uint8_t> b;
+    b.insert(b.end(), {'X', 'Y', 'Z', ' '});
+    be32(b, 0); be32(b, fixed(x)); be32(b, fixed(y)); be32(b, fixed(z));
+    return b;
+  };
+  auto para_tag = [&]() {   // kSRGB_TransFun (gainmapmath.h:67-68), kGABCDEF_ParaCurveType
+    const float fn[7] = {2.4f, (float)(1 / 1.055), (float)(0.055 / 1.055), (float)(1 / 12.92), 0.04045f, 0.0f, 0.0f};
+    std::vector<uint8_t> b;
+    b.insert(b.end(), {'p', 'a', 'r', 'a'});
+    be32(b, 0); be16(b, 4); be16(b, 0);
+    for (float v : fn) be32(b, fixed(v));
+    return b;
+  };
+  std::vector<std::pair<const char*, std::vector<uint8_t>>> tags;
+  const auto& m = mats[gamut];
+  tags.emplace_back("desc", text_tag(std::string(names[gamut]) + " Gamut with sRGB Transfer"));
+  tags.emplace_back("rXYZ", xyz_tag(m[0][0], m[1][0], m[2][0]));
+  tags.emplace_back("gXYZ", xyz_tag(m[0][1], m[1][1], m[2][1]));
+  tags.emplace_back("bXYZ", xyz_tag(m[0][2], m[1][2], m[2][2]));
+  tags.emplace_back("wtpt", xyz_tag(0.9642f, 1.0000f, 0.8249f));
+  tags.emplace_back("rTRC", para_tag());
+  tags.emplace_back("gTRC", para_tag());
+  tags.emplace_back("bTRC", para_tag());
+  tags.emplace_back("cprt", text_tag("Google Inc. 2022"));
+  size_t data = 0;
+  for (auto& t : tags) data += t.second.size();
+  const size_t table = 12 * tags.size(), profile = 132 + table + data;
+  out.clear();
+  const uint8_t id[14] = {'I', 'C', 'C', '_', 'P', 'R', 'O', 'F', 'I', 'L', 'E', 0, 1, 1};
+  out.insert(out.end(), id, id + 14);
+  be32(out, (uint32_t)profile); be32(out, 0); be32(out, 0x04300000);
+  out.insert(out.end(), {'m', 'n', 't', 'r', 'R', 'G', 'B', ' ', 'X', 'Y', 'Z', ' '});
+  out.insert(out.end(), 12, 0);                                   // creation date
+  out.insert(out.end(), {'a', 'c', 's', 'p'});
+  out.insert(out.end(), 4 + 4 + 4 + 4 + 8, 0);                    // platform, flags, manufacturer, model, attributes
+  be32(out, 1);                                                   // relative colorimetric
+  be32(out, fixed(0.9642f)); be32(out, fixed(1.0000f)); be32(out, fixed(0.8249f));
+  out.insert(out.end(), 4 + 16 + 28, 0);                          // creator, profile id, reserved
+  be32(out, (uint32_t)tags.size());
+  uint32_t off = (uint32_t)(132 + table);
+  for (auto& t : tags) {
+    out.insert(out.end(), t.first, t.first + 4);
+    be32(out, off); be32(out, (uint32_t)t.second.size());
+    off += (uint32_t)t.second.size();
+  }
+  for (auto& t : tags) out.insert(out.end(), t.second.begin(), t.second.end());
+  return true;
+}
+
+// JpegDecoderHelper::extractEXIF (jpegdecoderhelper.cpp:146-188) as appendGainMap uses it: walk the header up to SOS; the position
+// is accumulated over the APP0 / APP1 segments ONLY (the markers that call saves), so an EXIF segment that follows any other kind
+// of segment gets the reference's (wrong) position -- kept, it decides which bytes copyJpegWithoutExif drops.
+// returns false where jpeg_read_header would fail (no SOI, truncated segment, no SOF before SOS, EOI before SOS)
+static bool extract_exif(const uint8_t* d, size_t n, long* exif_pos, const uint8_t** exif, size_t* exif_len) {
+  *exif_pos = -1; *exif = nullptr; *exif_len = 0;
+  if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return false;
+  size_t p = 2, pos = 2;
+  bool sof = false;
+  while (true) {
+    while (p < n && d[p] != 0xFF) ++p;            // next_marker: skip garbage, then fill bytes
+    while (p < n && d[p] == 0xFF) ++p;
+    if (p >= n) return false;
+    const unsigned m = d[p++];
+    if (m == 0x00 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+    if (m == 0xD9) return false;                   // EOI before SOS: JERR_NO_IMAGE
+    if (p + 2 > n) return false;
+    const size_t len = ((size_t)d[p] << 8) | d[p + 1];
+    if (len < 2 || p + len > n) return false;
+    if (m == 0xDA) return sof;                     // SOS: header complete
+    if (m == 0xC0 || m == 0xC1 || m == 0xC2) sof = true;
+    if ((m == 0xE0 || m == 0xE1) && *exif_pos < 0) {
+      const size_t dl = len - 2;
+      pos += 4 + dl;
+      static const uint8_t kExif[6] = {'E', 'x', 'i', 'f', 0, 0};
+      if (m == 0xE1 && dl > sizeof(kExif) && memcmp(d + p + 2, kExif, sizeof(kExif)) == 0) {
+        *exif = d + p + 2; *exif_len = dl; *exif_pos = (long)(pos - dl);
+      }
+    }
+    p += len;
+  }
+}
+
+// the packet scan of JpegDecoderHelper::decode (jpegdecoderhelper.cpp:221-249): among the APP1 / APP2 segments before SOS, the first
+// XMP, the first EXIF and the first ICC packet, tested in that order per segment ("else if").  Offsets are relative to jpg.
+void first_packets(const uint8_t* d, size_t n, size_t* xmp_off, size_t* xmp_len, size_t* exif_off, size_t* exif_len, size_t* icc_off, size_t* icc_len) {
+  static const char kXmp[] = "http://ns.adobe.com/xap/1.0/";
+  static const uint8_t kExif[6] = {'E', 'x', 'i', 'f', 0, 0};
+  static const char kIcc[] = "ICC_PROFILE";
+  *xmp_len = *exif_len = *icc_len = 0;
+  *xmp_off = *exif_off = *icc_off = 0;
+  size_t p = 2;
+  while (p + 4 <= n && !(*xmp_len && *exif_len && *icc_len)) {
+    while (p < n && d[p] != 0xFF) ++p;
+    while (p < n && d[p] == 0xFF) ++p;
+    if (p >= n) return;
+    const unsigned m = d[p++];
+    if (m == 0x00 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+    if (m == 0xD9 || m == 0xDA || p + 2 > n) return;
+    const size_t len = ((size_t)d[p] << 8) | d[p + 1];
+    if (len < 2 || p + len > n) return;
+    const size_t dl = len - 2;
+    const uint8_t* data = d + p + 2;
+    if (m == 0xE1 || m == 0xE2) {
+      if (!*xmp_len && dl > sizeof(kXmp) && memcmp(data, kXmp, sizeof(kXmp)) == 0) { *xmp_off = (size_t)(data - d); *xmp_len = dl; }
+      else if (!*exif_len && dl > sizeof(kExif) && memcmp(data, kExif, sizeof(kExif)) == 0) { *exif_off = (size_t)(data - d); *exif_len = dl; }
+      else if (!*icc_len && dl > sizeof(kIcc) && memcmp(data, kIcc, sizeof(kIcc)) == 0) { *icc_off = (size_t)(data - d); *icc_len = dl; }
+    }
+    p += len;
+  }
+}
+
+// image_width / image_height as jpeg_read_header leaves them: the first SOFn segment
+bool dimensions(const uint8_t* d, size_t n, int* w, int* h) {
+  size_t p = 2;
+  while (p + 4 <= n) {
+    while (p < n && d[p] != 0xFF) ++p;
+    while (p < n && d[p] == 0xFF) ++p;
+    if (p >= n) return false;
+    const unsigned m = d[p++];
+    if (m == 0x00 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+    if (m == 0xD9 || m == 0xDA || p + 2 > n) return false;
+    const size_t len = ((size_t)d[p] << 8) | d[p + 1];
+    if (len < 2 || p + len > n) return false;
+    if (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      if (len < 7) return false;
+      *h = (d[p + 3] << 8) | d[p + 4];
+      *w = (d[p + 5] << 8) | d[p + 6];
+      return true;
+    }
+    p += len;
+  }
+  return false;
+}
+
+bool has_valid_header(const uint8_t* jpg, size_t n) {
+  long pos; const uint8_t* e; size_t el;
+  return extract_exif(jpg, n, &pos, &e, &el);
+}
+
+// appendGainMap (jpegr.cpp:951-1130): 0 ok, else the reference's status
+int append_gainmap(const uint8_t* primary_in, size_t n1, const uint8_t* gainmap, size_t n2, const uint8_t* exif, size_t exif_len,
+                   const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata_t& md, std::vector<uint8_t>& out) {
+  if (strncmp(md.version, "1.0", sizeof(md.version)) != 0) return UHDR_HIP_ERROR_BAD_METADATA;                  // :961-964
+  if (md.maxContentBoost < md.minContentBoost) return UHDR_HIP_ERROR_BAD_METADATA;
+  if (md.hdrCapacityMax < md.hdrCapacityMin || md.hdrCapacityMin < 1.0f) return UHDR_HIP_ERROR_BAD_METADATA;
+  if (md.offsetSdr < 0.0f || md.offsetHdr < 0.0f) return UHDR_HIP_ERROR_BAD_METADATA;
+  if (md.gamma <= 0.0f) return UHDR_HIP_ERROR_BAD_METADATA;
+  if (n2 < 2) return UHDR_HIP_ERROR_BAD_PTR;
+  static const char kNs[] = "http://ns.adobe.com/xap/1.0/";   // sizeof counts the terminator, as nameSpaceLength does
+  const std::string xs = xmp_secondary(md);
+  const int xs_len = 2 + (int)sizeof(kNs) + (int)xs.size();
+  const int secondary_size = 2 + xs_len + (int)n2;
+  const std::string xp = xmp_primary(secondary_size, md.version);
+  const int xp_len = 2 + (int)sizeof(kNs) + (int)xp.size();
+
+  // :1003-1033: an EXIF segment inside the primary JPEG moves in front of the XMP segment
+  long exif_pos;
+  const uint8_t* in_exif;
+  size_t in_exif_len;
+  if (!extract_exif(primary_in, n1, &exif_pos, &in_exif, &in_exif_len)) return UHDR_HIP_ERROR_DECODE_ERROR;
+  std::vector<uint8_t> stripped;
+  const uint8_t* primary = primary_in;
+  if (exif_pos >= 0) {
+    if (exif != nullptr) return UHDR_HIP_ERROR_MULTIPLE_EXIFS_RECEIVED;
+    if ((size_t)exif_pos + in_exif_len > n1 || exif_pos < 4) return UHDR_HIP_ERROR_DECODE_ERROR;   // the reference would read out of bounds
+    stripped.assign(primary_in, primary_in + exif_pos - 4);                                          // copyJpegWithoutExif :63-73
+    stripped.insert(stripped.end(), primary_in + exif_pos + in_exif_len, primary_in + n1);
+    primary = stripped.data(); n1 = stripped.size();
+    exif = in_exif; exif_len = in_exif_len;
+  }
+  auto segment = [&](unsigned marker, size_t payload) { out.push_back(0xFF); out.push_back((uint8_t)marker); be16(out, (unsigned)(payload + 2)); };
+  out.clear();
+  out.push_back(0xFF); out.push_back(0xD8);
+  if (exif != nullptr) { segment(0xE1, exif_len); out.insert(out.end(), exif, exif + exif_len); }
+  segment(0xE1, (size_t)xp_len - 2);
+  out.insert(out.end(), kNs, kNs + sizeof(kNs));
+  out.insert(out.end(), xp.begin(), xp.end());
+  if (icc != nullptr && icc_len > 0) { segment(0xE2, icc_len); out.insert(out.end(), icc, icc + icc_len); }
+  {
+    const int pos = (int)out.size(), length = 2 + 86;
+    const int primary_size = pos + length + (int)n1;
+    std::vector<uint8_t> mpf;
+    mpf_segment(primary_size, 0, secondary_size, primary_size - pos - 8, mpf);
+    segment(0xE2, 86);
+    out.insert(out.end(), mpf.begin(), mpf.end());
+  }
+  out.insert(out.end(), primary + 2, primary + n1);
+  out.push_back(0xFF); out.push_back(0xD8);
+  segment(0xE1, (size_t)xs_len - 2);
+  out.insert(out.end(), kNs, kNs + sizeof(kNs));
+  out.insert(out.end(), xs.begin(), xs.end());
+  out.insert(out.end(), gainmap + 2, gainmap + n2);
+  return UHDR_HIP_NO_ERROR;
 }
 
 }  // namespace jpegr

@@ -247,4 +247,157 @@ bool JpegDecoderHelperHip::decompressImage(const void* image, int length) {
   return true;
 }
 
+// ---- JpegRHip: ultrahdr::JpegR's public members over uhdr_hip_jpegr_* ---------------------------------------------------------
+namespace {
+// Write()'s contract (jpegr.cpp:46-61): the file goes to dest->data, capacity dest->maxLength, dest->length receives the size
+template <class Fn>
+status_t encode_into(uhdr_compressed_ptr dest, Fn&& call) {
+  void* out = dest != nullptr ? dest->data : nullptr;
+  const size_t cap = dest != nullptr && dest->maxLength > 0 ? (size_t)dest->maxLength : 0;
+  size_t n = 0;
+  if (uhdr_hip_init(0) != UHDR_HIP_NO_ERROR) return ULTRAHDR_UNKNOWN_ERROR;
+  const int rc = call(out, cap, &n);
+  if (rc == UHDR_HIP_NO_ERROR) dest->length = (int)n;
+  return static_cast<status_t>(rc);
+}
+const void* exif_ptr(uhdr_exif_ptr e) { return e ? e->data : nullptr; }
+// "exif != nullptr && exif->data == nullptr -> BAD_PTR" (jpegr.cpp:190-193) travels as (NULL, nonzero size)
+size_t exif_len(uhdr_exif_ptr e) { return e ? (e->data ? e->length : 1) : 0; }
+}  // namespace
+
+status_t JpegRHip::encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, ultrahdr_transfer_function hdr_tf, uhdr_compressed_ptr dest, int quality,
+                               uhdr_exif_ptr exif) {
+  uhdr_hip_image_t p;
+  if (p010_image_ptr) p = to_c(*p010_image_ptr);
+  return encode_into(dest, [&](void* out, size_t cap, size_t* n) {
+    return uhdr_hip_jpegr_encode_api0(p010_image_ptr ? &p : nullptr, (int)hdr_tf, quality, exif_ptr(exif), exif_len(exif), out, cap, n, UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+
+status_t JpegRHip::encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, uhdr_uncompressed_ptr yuv420_image_ptr, ultrahdr_transfer_function hdr_tf,
+                               uhdr_compressed_ptr dest, int quality, uhdr_exif_ptr exif) {
+  uhdr_hip_image_t p, y;
+  if (p010_image_ptr) p = to_c(*p010_image_ptr);
+  if (yuv420_image_ptr) y = to_c(*yuv420_image_ptr);
+  return encode_into(dest, [&](void* out, size_t cap, size_t* n) {
+    return uhdr_hip_jpegr_encode_api1(p010_image_ptr ? &p : nullptr, yuv420_image_ptr ? &y : nullptr, (int)hdr_tf, quality, exif_ptr(exif), exif_len(exif), out,
+                                      cap, n, UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+
+status_t JpegRHip::encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_compressed_ptr yuv420jpg_image_ptr,
+                               ultrahdr_transfer_function hdr_tf, uhdr_compressed_ptr dest) {
+  uhdr_hip_image_t p, y;
+  if (p010_image_ptr) p = to_c(*p010_image_ptr);
+  if (yuv420_image_ptr) y = to_c(*yuv420_image_ptr);
+  return encode_into(dest, [&](void* out, size_t cap, size_t* n) {
+    return uhdr_hip_jpegr_encode_api2(p010_image_ptr ? &p : nullptr, yuv420_image_ptr ? &y : nullptr, yuv420jpg_image_ptr ? yuv420jpg_image_ptr->data : nullptr,
+                                      yuv420jpg_image_ptr ? (size_t)yuv420jpg_image_ptr->length : 0,
+                                      yuv420jpg_image_ptr ? (int)yuv420jpg_image_ptr->colorGamut : UHDR_HIP_CG_UNSPECIFIED, (int)hdr_tf, out, cap, n,
+                                      UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+
+status_t JpegRHip::encodeJPEGR(uhdr_uncompressed_ptr p010_image_ptr, uhdr_compressed_ptr yuv420jpg_image_ptr, ultrahdr_transfer_function hdr_tf,
+                               uhdr_compressed_ptr dest) {
+  uhdr_hip_image_t p;
+  if (p010_image_ptr) p = to_c(*p010_image_ptr);
+  return encode_into(dest, [&](void* out, size_t cap, size_t* n) {
+    return uhdr_hip_jpegr_encode_api3(p010_image_ptr ? &p : nullptr, yuv420jpg_image_ptr ? yuv420jpg_image_ptr->data : nullptr,
+                                      yuv420jpg_image_ptr ? (size_t)yuv420jpg_image_ptr->length : 0,
+                                      yuv420jpg_image_ptr ? (int)yuv420jpg_image_ptr->colorGamut : UHDR_HIP_CG_UNSPECIFIED, (int)hdr_tf, out, cap, n,
+                                      UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+
+status_t JpegRHip::encodeJPEGR(uhdr_compressed_ptr yuv420jpg_image_ptr, uhdr_compressed_ptr gainmapjpg_image_ptr, ultrahdr_metadata_ptr metadata,
+                               uhdr_compressed_ptr dest) {
+  if (yuv420jpg_image_ptr == nullptr || gainmapjpg_image_ptr == nullptr) return ERROR_ULTRAHDR_BAD_PTR;   // jpegr.cpp:505-512
+  uhdr_hip_metadata_t md;
+  if (metadata) md = to_c(*metadata);
+  void* out = dest ? dest->data : nullptr;
+  size_t n = 0;
+  const int rc = uhdr_hip_jpegr_encode_api4(yuv420jpg_image_ptr->data, (size_t)yuv420jpg_image_ptr->length, (int)yuv420jpg_image_ptr->colorGamut,
+                                            gainmapjpg_image_ptr->data, (size_t)gainmapjpg_image_ptr->length, metadata ? &md : nullptr, out,
+                                            dest && dest->maxLength > 0 ? (size_t)dest->maxLength : 0, &n);
+  if (rc == UHDR_HIP_NO_ERROR) dest->length = (int)n;
+  return static_cast<status_t>(rc);
+}
+
+status_t JpegRHip::encodeJPEGR(uhdr_uncompressed_ptr yuv420_image_ptr, uhdr_uncompressed_ptr gainmap_image_ptr, ultrahdr_metadata_ptr metadata,
+                               uhdr_compressed_ptr dest, int quality, uhdr_exif_ptr exif) {
+  uhdr_hip_image_t y, g;
+  uhdr_hip_metadata_t md;
+  if (yuv420_image_ptr) y = to_c(*yuv420_image_ptr);
+  if (gainmap_image_ptr) { g = to_c(*gainmap_image_ptr); if (g.luma_stride == 0) g.luma_stride = g.width; }
+  if (metadata) md = to_c(*metadata);
+  return encode_into(dest, [&](void* out, size_t cap, size_t* n) {
+    return uhdr_hip_jpegr_encode_apix(yuv420_image_ptr ? &y : nullptr, gainmap_image_ptr ? &g : nullptr, metadata ? &md : nullptr, quality, exif_ptr(exif),
+                                      exif && exif->data ? exif->length : 0, out, cap, n, UHDR_HIP_MEM_HOST, nullptr);
+  });
+}
+
+status_t JpegRHip::getJPEGRInfo(uhdr_compressed_ptr jpegr_image_ptr, uhdr_info_ptr info) {
+  if (jpegr_image_ptr == nullptr || jpegr_image_ptr->data == nullptr || info == nullptr) return ERROR_ULTRAHDR_BAD_PTR;   // jpegr.cpp:634-641
+  uhdr_hip_jpeg_info_t a, g;
+  const int rc = uhdr_hip_jpegr_info(jpegr_image_ptr->data, (size_t)jpegr_image_ptr->length, &a, info->gainmapImgInfo ? &g : nullptr);
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  const uint8_t* f = static_cast<const uint8_t*>(jpegr_image_ptr->data);
+  auto fill = [&](const uhdr_hip_jpeg_info_t& s, jpeg_info_struct* d) {   // parseJpegInfo jpegr.cpp:888-909
+    d->width = s.width; d->height = s.height;
+    d->imgData.assign(f + s.offset, f + s.offset + s.size);
+    if (s.icc_size) d->iccData.assign(f + s.icc_offset, f + s.icc_offset + s.icc_size);
+    if (s.exif_size) d->exifData.assign(f + s.exif_offset, f + s.exif_offset + s.exif_size);
+    if (s.xmp_size) { d->xmpData.assign(f + s.xmp_offset, f + s.xmp_offset + s.xmp_size); d->xmpData.push_back(0); }   // jpegdecoderhelper.cpp:235
+  };
+  info->width = a.width; info->height = a.height;
+  if (info->primaryImgInfo) fill(a, info->primaryImgInfo);
+  if (info->gainmapImgInfo) fill(g, info->gainmapImgInfo);
+  return ULTRAHDR_NO_ERROR;
+}
+
+status_t JpegRHip::decodeJPEGR(uhdr_compressed_ptr jpegr_image_ptr, uhdr_uncompressed_ptr dest, float max_display_boost, uhdr_exif_ptr exif,
+                               ultrahdr_output_format output_format, uhdr_uncompressed_ptr gainmap_image_ptr, ultrahdr_metadata_ptr metadata) {
+  if (jpegr_image_ptr == nullptr || jpegr_image_ptr->data == nullptr) return ERROR_ULTRAHDR_BAD_PTR;      // jpegr.cpp:658-661
+  if (dest == nullptr || dest->data == nullptr) return ERROR_ULTRAHDR_BAD_PTR;                            // :662-665
+  if (max_display_boost < 1.0f) return ERROR_ULTRAHDR_INVALID_DISPLAY_BOOST;
+  if (exif != nullptr && exif->data == nullptr) return ERROR_ULTRAHDR_BAD_PTR;                            // :670-673
+  if (gainmap_image_ptr != nullptr && gainmap_image_ptr->data == nullptr) return ERROR_ULTRAHDR_BAD_PTR;  // :674-677
+  if (output_format <= ULTRAHDR_OUTPUT_UNSPECIFIED || output_format > ULTRAHDR_OUTPUT_MAX) return ERROR_ULTRAHDR_INVALID_OUTPUT_FORMAT;
+  if (uhdr_hip_init(0) != UHDR_HIP_NO_ERROR) return ULTRAHDR_UNKNOWN_ERROR;
+  const void* file = jpegr_image_ptr->data;
+  const size_t n = (size_t)jpegr_image_ptr->length;
+  uhdr_hip_jpeg_info_t a, g;
+  int rc = uhdr_hip_jpegr_info(file, n, &a, &g);
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  if (output_format == ULTRAHDR_OUTPUT_SDR) return ERROR_ULTRAHDR_UNSUPPORTED_FEATURE;
+  if (exif != nullptr) {                                                                                   // :721-727
+    if (exif->length < a.exif_size) return ERROR_ULTRAHDR_BUFFER_TOO_SMALL;
+    std::memcpy(exif->data, static_cast<const uint8_t*>(file) + a.exif_offset, a.exif_size);
+    exif->length = a.exif_size;
+  }
+  if (gainmap_image_ptr != nullptr) {                                                                      // :731-749: first plane of the gain map's JPEG
+    JpegDecoderHelperHip dec;
+    if (!dec.decompressImage(static_cast<const uint8_t*>(file) + g.offset, (int)g.size)) return ERROR_ULTRAHDR_DECODE_ERROR;
+    gainmap_image_ptr->width = dec.getDecompressedImageWidth();
+    gainmap_image_ptr->height = dec.getDecompressedImageHeight();
+    std::memcpy(gainmap_image_ptr->data, dec.getDecompressedImagePtr(), gainmap_image_ptr->width * gainmap_image_ptr->height);
+  }
+  uhdr_hip_image_t d = to_c(*dest);
+  uhdr_hip_metadata_t md;
+  const size_t bpp = output_format == ULTRAHDR_OUTPUT_HDR_LINEAR ? 8 : output_format == ULTRAHDR_OUTPUT_HDR_LINEAR_RGB_10BIT ? 6 : 4;
+  rc = uhdr_hip_jpegr_decode(file, n, (int)output_format, max_display_boost, dest->data, a.width * a.height * bpp, &d, &md, mApplyMode, UHDR_HIP_MEM_HOST,
+                             nullptr);
+  if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
+  dest->width = d.width; dest->height = d.height;
+  dest->colorGamut = static_cast<ultrahdr_color_gamut>(d.colorGamut);
+  if (metadata != nullptr) {                                                                               // :757-766
+    metadata->version = md.version;
+    metadata->maxContentBoost = md.maxContentBoost; metadata->minContentBoost = md.minContentBoost; metadata->gamma = md.gamma;
+    metadata->offsetSdr = md.offsetSdr; metadata->offsetHdr = md.offsetHdr;
+    metadata->hdrCapacityMin = md.hdrCapacityMin; metadata->hdrCapacityMax = md.hdrCapacityMax;
+  }
+  return ULTRAHDR_NO_ERROR;
+}
+
 }  // namespace ultrahdr

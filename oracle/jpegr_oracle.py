@@ -175,3 +175,270 @@ def decode(data, output_format, max_display_boost, threads=8):
     gmap = np.ascontiguousarray(gplanes[:gw * gh].reshape(gh, gw))
     ast, out, dest = O.apply("orc_", yi, gmap, omd, output_format, max_display_boost, threads=threads)
     return ast, out, w, h, gamut, md
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# assembly side: generateXmpFor{Primary,Secondary}Image (jpegrutils.cpp:547-611), generateMpf (multipictureformat.cpp:30-92),
+# IccHelper::writeIccProfile for the sRGB transfer (icc.cpp:410-600), appendGainMap (jpegr.cpp:951-1130) and encodeJPEGR
+# API-1 (jpegr.cpp:249-381).  Pinned: re-assembling the two JPEG streams found in the reference's own sample file gives back
+# the sample file, byte for byte, and the sample's ICC segment is the sRGB/sRGB profile (tests/test_jpegr_container.py).
+# ---------------------------------------------------------------------------------------------------------------------
+_HEAD = ('<x:xmpmeta\n  xmlns:x="adobe:ns:meta/"\n  x:xmptk="Adobe XMP Core 5.1.2">\n  <rdf:RDF\n'
+         '    xmlns:rdf="http://www.w3.org/1999/02/22-rdf-syntax-ns#">\n    <rdf:Description\n')
+
+
+def _g(v):
+    return "%g" % float(v)
+
+
+def xmp_primary(secondary_length, version="1.0"):
+    item = ('          <rdf:li\n            rdf:parseType="Resource">\n            <Container:Item\n              Item:Semantic="%s"\n'
+            '              Item:Mime="image/jpeg"%s/>\n          </rdf:li>\n')
+    return (_HEAD + '      xmlns:Container="http://ns.google.com/photos/1.0/container/"\n      xmlns:Item="http://ns.google.com/photos/1.0/container/item/"\n'
+            '      xmlns:hdrgm="http://ns.adobe.com/hdr-gain-map/1.0/"\n      hdrgm:Version="%s">\n      <Container:Directory>\n        <rdf:Seq>\n' % version
+            + item % ("Primary", "") + item % ("GainMap", '\n              Item:Length="%d"' % secondary_length)
+            + '        </rdf:Seq>\n      </Container:Directory>\n    </rdf:Description>\n  </rdf:RDF>\n</x:xmpmeta>\n')
+
+
+def xmp_secondary(md):
+    l2 = lambda v: _g(math.log2(float(np.float32(v))))
+    rows = [("Version", md["version"]), ("GainMapMin", l2(md["min"])), ("GainMapMax", l2(md["max"])), ("Gamma", _g(np.float32(md["gamma"]))),
+            ("OffsetSDR", _g(np.float32(md["off_sdr"]))), ("OffsetHDR", _g(np.float32(md["off_hdr"]))), ("HDRCapacityMin", l2(md["capmin"])),
+            ("HDRCapacityMax", l2(md["capmax"])), ("BaseRenditionIsHDR", "False")]
+    return (_HEAD + '      xmlns:hdrgm="http://ns.adobe.com/hdr-gain-map/1.0/"' + "".join('\n      hdrgm:%s="%s"' % r for r in rows)
+            + "/>\n  </rdf:RDF>\n</x:xmpmeta>\n")
+
+
+def mpf(primary_size, primary_offset, secondary_size, secondary_offset):
+    b = b"MPF\0MM\0*" + struct.pack(">IH", 8, 3)
+    b += struct.pack(">HHI4s", 0xB000, 7, 4, b"0100") + struct.pack(">HHII", 0xB001, 4, 1, 2) + struct.pack(">HHI", 0xB002, 7, 32)
+    b += struct.pack(">I", len(b) - 4 + 8) + struct.pack(">I", 0)
+    b += struct.pack(">IIIHH", 0x030000, primary_size, primary_offset, 0, 0) + struct.pack(">IIIHH", 0, secondary_size, secondary_offset, 0, 0)
+    return b
+
+
+def icc_profile_srgb_transfer(gamut):
+    fx = lambda x: int(math.floor(float(np.float32(x)) * 65536.0 + 0.5)) & 0xFFFFFFFF
+    ff = lambda v: np.float32(v) * np.float32(1.52587890625e-5)
+    mats = {O.CG_BT709: ("sRGB", [[ff(0x6FA2), ff(0x6299), ff(0x24A0)], [ff(0x38F5), ff(0xB785), ff(0x0F84)], [ff(0x0390), ff(0x18DA), ff(0xB6CF)]]),
+            O.CG_P3: ("Display P3", [[0.515102, 0.291965, 0.157153], [0.241182, 0.692236, 0.0665819], [-0.00104941, 0.0418818, 0.784378]]),
+            O.CG_BT2100: ("Rec2020", [[0.673459, 0.165661, 0.125100], [0.279033, 0.675338, 0.0456288], [-0.00193139, 0.0299794, 0.797162]])}
+    name, m = mats[gamut]
+
+    def text(t):
+        b = b"mluc" + struct.pack(">IIIII", 0, 1, 12, 0x656E5553, 2 * len(t)) + struct.pack(">I", 28) + t.encode("utf-16-be")
+        return b.ljust(((2 * len(t) + 28 + 2) >> 2) << 2, b"\0")
+
+    xyz = lambda x, y, z: b"XYZ " + struct.pack(">IIII", 0, fx(x), fx(y), fx(z))
+    para = b"para" + struct.pack(">IHH", 0, 4, 0) + b"".join(struct.pack(">I", fx(v)) for v in
+                                                            (2.4, np.float32(1 / 1.055), np.float32(0.055 / 1.055), np.float32(1 / 12.92), 0.04045, 0.0, 0.0))
+    tags = [(b"desc", text(name + " Gamut with sRGB Transfer")), (b"rXYZ", xyz(m[0][0], m[1][0], m[2][0])), (b"gXYZ", xyz(m[0][1], m[1][1], m[2][1])),
+            (b"bXYZ", xyz(m[0][2], m[1][2], m[2][2])), (b"wtpt", xyz(0.9642, 1.0, 0.8249)), (b"rTRC", para), (b"gTRC", para), (b"bTRC", para),
+            (b"cprt", text("Google Inc. 2022"))]
+    table = 12 * len(tags)
+    size = 132 + table + sum(len(t[1]) for t in tags)
+    hdr = struct.pack(">III4s4s4s", size, 0, 0x04300000, b"mntr", b"RGB ", b"XYZ ") + b"\0" * 12 + b"acsp" + b"\0" * 24
+    hdr += struct.pack(">IIII", 1, fx(0.9642), fx(1.0), fx(0.8249)) + b"\0" * 48 + struct.pack(">I", len(tags))
+    out, off = b"ICC_PROFILE\0\x01\x01" + hdr, 132 + table
+    for sig, body in tags:
+        out += sig + struct.pack(">II", off, len(body))
+        off += len(body)
+    return out + b"".join(t[1] for t in tags)
+
+
+def _header_segments(d):
+    """jpeg_read_header's walk: [(marker, data offset, data length)] up to SOS, or None where it would fail"""
+    if len(d) < 4 or d[0] != 0xFF or d[1] != 0xD8:
+        return None
+    p, out, sof = 2, [], False
+    while True:
+        while p < len(d) and d[p] != 0xFF:
+            p += 1
+        while p < len(d) and d[p] == 0xFF:
+            p += 1
+        if p >= len(d):
+            return None
+        m = d[p]
+        p += 1
+        if m in (0x00, 0x01) or 0xD0 <= m <= 0xD7:
+            continue
+        if m == 0xD9 or p + 2 > len(d):
+            return None
+        ln = (d[p] << 8) | d[p + 1]
+        if ln < 2 or p + ln > len(d):
+            return None
+        if m == 0xDA:
+            return out if sof else None
+        if m in (0xC0, 0xC1, 0xC2):
+            sof = True
+        out.append((m, p + 2, ln - 2))
+        p += ln
+
+
+def extract_exif(d):
+    """JpegDecoderHelper::extractEXIF (jpegdecoderhelper.cpp:146-188): (ok, exif_pos, exif bytes); the position counts the saved
+    (APP0 / APP1) segments only"""
+    segs = _header_segments(d)
+    if segs is None:
+        return False, -1, None
+    pos = 2
+    for m, off, ln in segs:
+        if m not in (0xE0, 0xE1):
+            continue
+        pos += 4 + ln
+        if m == 0xE1 and ln > 6 and d[off:off + 6] == b"Exif\0\0":
+            return True, pos - ln, d[off:off + ln]
+    return True, -1, None
+
+
+def append_gainmap(primary, gainmap, md, exif=None, icc=None):
+    """-> bytes, or a negative status"""
+    if md["version"] != "1.0" or md["max"] < md["min"] or md["capmax"] < md["capmin"] or md["capmin"] < 1.0 or md["off_sdr"] < 0 or md["off_hdr"] < 0 \
+            or md["gamma"] <= 0:
+        return -10010
+    ns = XMP_NS
+    xs = xmp_secondary(md).encode()
+    xs_len = 2 + len(ns) + len(xs)
+    secondary_size = 2 + xs_len + len(gainmap)
+    xp = xmp_primary(secondary_size, md["version"]).encode()
+    ok, epos, inside = extract_exif(primary)
+    if not ok:
+        return -20002
+    if epos >= 0:
+        if exif is not None:
+            return -20007
+        primary = primary[:epos - 4] + primary[epos + len(inside):]          # copyJpegWithoutExif, jpegr.cpp:63-73
+        exif = inside
+    out = b"\xff\xd8"
+    if exif is not None:
+        out += b"\xff\xe1" + struct.pack(">H", 2 + len(exif)) + exif
+    out += b"\xff\xe1" + struct.pack(">H", 2 + len(ns) + len(xp)) + ns + xp
+    if icc:
+        out += b"\xff\xe2" + struct.pack(">H", 2 + len(icc)) + icc
+    pos, length = len(out), 2 + 86
+    primary_size = pos + length + len(primary)
+    out += b"\xff\xe2" + struct.pack(">H", length) + mpf(primary_size, 0, secondary_size, primary_size - pos - 8)
+    out += primary[2:] + b"\xff\xd8\xff\xe1" + struct.pack(">H", xs_len) + ns + xs + gainmap[2:]
+    return out
+
+
+def _md(omd):
+    return dict(version="1.0", max=omd.maxContentBoost, min=omd.minContentBoost, gamma=omd.gamma, off_sdr=omd.offsetSdr, off_hdr=omd.offsetHdr,
+                capmin=omd.hdrCapacityMin, capmax=omd.hdrCapacityMax)
+
+
+def _gainmap_jpeg(p010, yuv_img, w, h, hdr_gamut, hdr_tf, sdr_is_601, threads):
+    st, gmap, omd = O.generate("orc_", yuv_img, O.p010_image(p010, w, h, hdr_gamut), hdr_tf, sdr_is_601=sdr_is_601, threads=threads)
+    assert st == 0
+    return O.jpeg_encode("orc", np.ascontiguousarray(gmap.reshape(-1)), None, w // 4, h // 4, 85), _md(omd)
+
+
+def _finish_from_planes(enc, ls, w, h, sdr_gamut, quality, gm_jpeg, md, exif):
+    cs = ls >> 1
+    if sdr_gamut != O.CG_P3:
+        import ctypes as C
+        img = O.yuv420_image(enc, w, h, sdr_gamut, ls, cs)
+        assert O.load().orc_convertYuv(C.byref(img), sdr_gamut, O.CG_P3) == 0
+    sdr_jpeg = O.jpeg_encode("orc", enc[:ls * h], enc[ls * h:], w, h, quality, ls, cs, icc=icc_profile_srgb_transfer(sdr_gamut))
+    return append_gainmap(sdr_jpeg, gm_jpeg, md, exif=exif)
+
+
+def encode_api0(p010, w, h, hdr_gamut, hdr_tf, quality, exif=None, threads=8):
+    """encodeJPEGR API-0 (jpegr.cpp:186-247), tightly packed P010"""
+    import ctypes as C
+    ls = (w + 15) // 16 * 16
+    enc = np.zeros(ls * h * 3 // 2, np.uint8)
+    src, dst = O.p010_image(p010, w, h, hdr_gamut), O.yuv420_image(enc, w, h, hdr_gamut, ls, ls >> 1)
+    assert O.load().orc_toneMap(C.byref(src), C.byref(dst)) == 0
+    gm_jpeg, md = _gainmap_jpeg(p010, dst, w, h, hdr_gamut, hdr_tf, False, threads)
+    return _finish_from_planes(enc, ls, w, h, hdr_gamut, quality, gm_jpeg, md, exif)
+
+
+def encode_api1(p010, yuv, w, h, sdr_gamut, hdr_gamut, hdr_tf, quality, exif=None, threads=8):
+    """encodeJPEGR API-1 (jpegr.cpp:249-381), tightly packed inputs: -> JPEG/R bytes"""
+    gm_jpeg, md = _gainmap_jpeg(p010, O.yuv420_image(yuv, w, h, sdr_gamut), w, h, hdr_gamut, hdr_tf, False, threads)
+    enc, ls = yuv.copy(), w
+    if sdr_gamut != O.CG_P3:
+        ls = (w + 15) // 16 * 16
+        cs, cw, ch = ls >> 1, w // 2, h // 2
+        enc = np.zeros(ls * h * 3 // 2, np.uint8)
+        enc[:ls * h].reshape(h, ls)[:, :w] = yuv[:w * h].reshape(h, w)
+        enc[ls * h:ls * h + cs * ch].reshape(ch, cs)[:, :cw] = yuv[w * h:w * h + cw * ch].reshape(ch, cw)
+        enc[ls * h + cs * ch:].reshape(ch, cs)[:, :cw] = yuv[w * h + cw * ch:].reshape(ch, cw)
+    return _finish_from_planes(enc, ls, w, h, sdr_gamut, quality, gm_jpeg, md, exif)
+
+
+def encode_api4(sdr_jpeg, sdr_jpeg_gamut, gm_jpeg, md):
+    """encodeJPEGR API-4 (jpegr.cpp:502-560)"""
+    if _header_segments(sdr_jpeg) is None:
+        return -20002
+    icc = None
+    if app_segment(sdr_jpeg, 0xE2, ICC_ID) is None:
+        if not 0 <= sdr_jpeg_gamut <= 2:
+            return -10003
+        icc = icc_profile_srgb_transfer(sdr_jpeg_gamut)
+    return append_gainmap(sdr_jpeg, gm_jpeg, md, icc=icc)
+
+
+def encode_api2(p010, yuv, w, h, sdr_gamut, hdr_gamut, sdr_jpeg, sdr_jpeg_gamut, hdr_tf, threads=8):
+    """encodeJPEGR API-2 (jpegr.cpp:384-437)"""
+    gm_jpeg, md = _gainmap_jpeg(p010, O.yuv420_image(yuv, w, h, sdr_gamut), w, h, hdr_gamut, hdr_tf, False, threads)
+    return encode_api4(sdr_jpeg, sdr_jpeg_gamut, gm_jpeg, md)
+
+
+def encode_api3(p010, w, h, hdr_gamut, sdr_jpeg, sdr_jpeg_gamut, hdr_tf, threads=8):
+    """encodeJPEGR API-3 (jpegr.cpp:439-500)"""
+    st, planes, jw, jh, gray = O.jpeg_decode("orc", sdr_jpeg)
+    if st <= 0 or gray:
+        return -20002
+    icc = app_segment(sdr_jpeg, 0xE2, ICC_ID)
+    if icc is not None:
+        cg = gamut_from_icc(icc)
+        if cg == O.CG_UNSPECIFIED or (sdr_jpeg_gamut != O.CG_UNSPECIFIED and sdr_jpeg_gamut != cg):
+            return -10003
+    else:
+        if not 0 <= sdr_jpeg_gamut <= 2:
+            return -10003
+        cg = sdr_jpeg_gamut
+    if (jw, jh) != (w, h):
+        return -10006
+    gm_jpeg, md = _gainmap_jpeg(p010, O.yuv420_image(planes, w, h, cg), w, h, hdr_gamut, hdr_tf, True, threads)
+    return encode_api4(sdr_jpeg, sdr_jpeg_gamut, gm_jpeg, md)
+
+
+def encode_apix(yuv, w, h, sdr_gamut, gmap, md, quality, exif=None):
+    """encodeJPEGR "API-x" (jpegr.cpp:562-631): no BT.601 re-encode on this path"""
+    gm_jpeg = O.jpeg_encode("orc", np.ascontiguousarray(gmap.reshape(-1)), None, gmap.shape[1], gmap.shape[0], 85)
+    sdr_jpeg = O.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, quality, icc=icc_profile_srgb_transfer(sdr_gamut))
+    return append_gainmap(sdr_jpeg, gm_jpeg, md, exif=exif)
+
+
+def info(data):
+    """getJPEGRInfo (jpegr.cpp:633-653): -> status or [dict per image: offset, size, width, height, icc, exif, xmp (offset, size) ranges]"""
+    imgs = find_images(data)
+    if not imgs:
+        return -20006
+    if len(imgs) == 1:
+        return -20003
+    out = []
+    for begin, ln in imgs[:2]:
+        j = data[begin:begin + ln]
+        segs = _header_segments(j)
+        if segs is None:
+            return -20002
+        sof = [(off, n) for m, off, n in segs if 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC)]
+        hgt, wid = struct.unpack(">HH", j[sof[0][0] + 1:sof[0][0] + 5])
+        if wid > 8192 or hgt > 8192:
+            return -20002
+        e = dict(offset=begin, size=ln, width=wid, height=hgt, icc=(0, 0), exif=(0, 0), xmp=(0, 0))
+        for m, off, n in segs:                                   # jpegdecoderhelper.cpp:221-249
+            if m not in (0xE1, 0xE2):
+                continue
+            if e["xmp"][1] == 0 and n > len(XMP_NS) and j[off:off + len(XMP_NS)] == XMP_NS:
+                e["xmp"] = (begin + off, n)
+            elif e["exif"][1] == 0 and n > 6 and j[off:off + 6] == b"Exif\0\0":
+                e["exif"] = (begin + off, n)
+            elif e["icc"][1] == 0 and n > len(ICC_ID) and j[off:off + len(ICC_ID)] == ICC_ID:
+                e["icc"] = (begin + off, n)
+        out.append(e)
+    return out

@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
@@ -134,6 +135,74 @@ int main(int argc, char** argv) {
   CHECK(dec.decompressImage(enc_map.getCompressedImagePtr(), (int)enc_map.getCompressedImageSize()) && dec.isSingleChannel());
   dump(out + "/map_q85_decoded.bin", dec.getDecompressedImagePtr(), dec.getDecompressedImageSize());
   CHECK(!dec.decompressImage("not a jpeg", 10));
+  // ---- JpegRHip: the calls of the reference's own encode / decode tests (tests/jpegr_test.cpp: EncodeAPI0..4AndDecodeTest) -------------
+  {
+    JpegRHip codec;
+    std::vector<uint8_t> file(w * h * 3), file2(w * h * 3);
+    ultrahdr_compressed_struct jpgr{file.data(), 0, (int)file.size(), ULTRAHDR_COLORGAMUT_UNSPECIFIED};
+    ultrahdr_uncompressed_struct raw_p010{}, raw_yuv{};                      // packed, defaults: strides 0 / chroma nullptr (jpegr.cpp:261-275)
+    raw_p010.data = p010.data(); raw_p010.width = w; raw_p010.height = h; raw_p010.colorGamut = ULTRAHDR_COLORGAMUT_BT2100;
+    raw_yuv.data = yuv.data(); raw_yuv.width = w; raw_yuv.height = h; raw_yuv.colorGamut = ULTRAHDR_COLORGAMUT_BT709;
+    // API-0
+    CHECK(codec.encodeJPEGR(&raw_p010, ULTRAHDR_TF_HLG, &jpgr, 101, nullptr) == ERROR_ULTRAHDR_INVALID_QUALITY_FACTOR);
+    CHECK(codec.encodeJPEGR(static_cast<uhdr_uncompressed_ptr>(nullptr), ULTRAHDR_TF_HLG, &jpgr, 90, nullptr) == ERROR_ULTRAHDR_BAD_PTR);
+    CHECK(codec.encodeJPEGR(&raw_p010, ULTRAHDR_TF_HLG, &jpgr, 90, nullptr) == ULTRAHDR_NO_ERROR && jpgr.length > 0);
+    dump(out + "/api0.jpgr", jpgr.data, jpgr.length);
+    // API-1, with EXIF
+    uint8_t exif_bytes[16] = {'E', 'x', 'i', 'f', 0, 0, 'M', 'M', 0, 42, 0, 0, 0, 8, 0, 0};
+    ultrahdr_exif_struct exif{exif_bytes, sizeof(exif_bytes)};
+    CHECK(codec.encodeJPEGR(&raw_p010, &raw_yuv, ULTRAHDR_TF_HLG, &jpgr, 90, &exif) == ULTRAHDR_NO_ERROR);
+    dump(out + "/api1.jpgr", jpgr.data, jpgr.length);
+    ultrahdr_compressed_struct tiny{file2.data(), 0, 100, ULTRAHDR_COLORGAMUT_UNSPECIFIED};
+    CHECK(codec.encodeJPEGR(&raw_p010, &raw_yuv, ULTRAHDR_TF_HLG, &tiny, 90, nullptr) == ERROR_ULTRAHDR_INSUFFICIENT_RESOURCE);
+    // getJPEGRInfo on it
+    jpeg_info_struct pinfo, ginfo;
+    jpegr_info_struct info{0, 0, &pinfo, &ginfo};
+    CHECK(codec.getJPEGRInfo(&jpgr, &info) == ULTRAHDR_NO_ERROR && info.width == w && info.height == h);
+    CHECK(ginfo.width == w / 4 && ginfo.height == h / 4 && pinfo.exifData.size() == sizeof(exif_bytes) && !pinfo.iccData.empty() && !ginfo.xmpData.empty());
+    CHECK(pinfo.imgData.size() + ginfo.imgData.size() == (size_t)jpgr.length);
+    // decodeJPEGR: HDR rendition + exif + gain map + metadata
+    std::vector<uint8_t> dec_out(w * h * 8), gm_plane(w * h / 16), exif_back(64);
+    ultrahdr_uncompressed_struct decoded{}, gm_img{};
+    decoded.data = dec_out.data(); gm_img.data = gm_plane.data();
+    ultrahdr_exif_struct exif_out{exif_back.data(), exif_back.size()};
+    ultrahdr_metadata_struct md_out;
+    CHECK(codec.decodeJPEGR(&jpgr, &decoded, FLT_MAX, &exif_out, ULTRAHDR_OUTPUT_HDR_HLG, &gm_img, &md_out) == ULTRAHDR_NO_ERROR);
+    CHECK(decoded.width == w && decoded.height == h && decoded.colorGamut == ULTRAHDR_COLORGAMUT_BT709 && gm_img.width == w / 4 && gm_img.height == h / 4);
+    CHECK(exif_out.length == sizeof(exif_bytes) && memcmp(exif_back.data(), exif_bytes, sizeof(exif_bytes)) == 0);
+    CHECK(md_out.version == kGainMapVersion && md_out.minContentBoost == 1.0f && md_out.hdrCapacityMin == 1.0f);
+    dump(out + "/api1_decoded_hlg.bin", dec_out.data(), w * h * 4);
+    dump(out + "/api1_decoded_map.bin", gm_plane.data(), gm_plane.size());
+    ultrahdr_exif_struct small_exif{exif_back.data(), 4};
+    CHECK(codec.decodeJPEGR(&jpgr, &decoded, FLT_MAX, &small_exif) == ERROR_ULTRAHDR_BUFFER_TOO_SMALL);
+    CHECK(codec.decodeJPEGR(&jpgr, &decoded, 0.5f) == ERROR_ULTRAHDR_INVALID_DISPLAY_BOOST);
+    CHECK(codec.decodeJPEGR(&jpgr, &decoded, FLT_MAX, nullptr, ULTRAHDR_OUTPUT_SDR) == ERROR_ULTRAHDR_UNSUPPORTED_FEATURE);
+    // API-2 / API-3 around the SDR JPEG made earlier (its ICC payload is not a profile -> gamut has to come from the struct... and is rejected)
+    ultrahdr_compressed_struct sdr_jpg{enc_sdr.getCompressedImagePtr(), (int)enc_sdr.getCompressedImageSize(), (int)enc_sdr.getCompressedImageSize(),
+                                       ULTRAHDR_COLORGAMUT_BT709};
+    ultrahdr_compressed_struct jpgr2{file2.data(), 0, (int)file2.size(), ULTRAHDR_COLORGAMUT_UNSPECIFIED};
+    JpegEncoderHelperHip enc_plain;                                       // the same frame without any ICC segment
+    CHECK(enc_plain.compressImage(yuv.data(), yuv.data() + w * h, (int)w, (int)h, (int)w, (int)(w / 2), 95, nullptr, 0));
+    ultrahdr_compressed_struct plain_jpg{enc_plain.getCompressedImagePtr(), (int)enc_plain.getCompressedImageSize(), (int)enc_plain.getCompressedImageSize(),
+                                         ULTRAHDR_COLORGAMUT_BT709};
+    CHECK(codec.encodeJPEGR(&raw_p010, &raw_yuv, &plain_jpg, ULTRAHDR_TF_HLG, &jpgr2) == ULTRAHDR_NO_ERROR);
+    dump(out + "/api2.jpgr", jpgr2.data, jpgr2.length);
+    CHECK(codec.encodeJPEGR(&raw_p010, &plain_jpg, ULTRAHDR_TF_HLG, &jpgr2) == ULTRAHDR_NO_ERROR);
+    dump(out + "/api3.jpgr", jpgr2.data, jpgr2.length);
+    plain_jpg.colorGamut = ULTRAHDR_COLORGAMUT_UNSPECIFIED;
+    CHECK(codec.encodeJPEGR(&raw_p010, &plain_jpg, ULTRAHDR_TF_HLG, &jpgr2) == ERROR_ULTRAHDR_INVALID_COLORGAMUT);
+    // API-4: the two compressed streams of the API-1 file + the decoded metadata give the file back minus its EXIF-less-ness
+    ultrahdr_compressed_struct pj{pinfo.imgData.data(), (int)pinfo.imgData.size(), (int)pinfo.imgData.size(), ULTRAHDR_COLORGAMUT_BT709};
+    ultrahdr_compressed_struct gj{ginfo.imgData.data(), (int)ginfo.imgData.size(), (int)ginfo.imgData.size(), ULTRAHDR_COLORGAMUT_UNSPECIFIED};
+    CHECK(codec.encodeJPEGR(&pj, &gj, &md_out, &jpgr2) == ULTRAHDR_NO_ERROR);
+    dump(out + "/api4.jpgr", jpgr2.data, jpgr2.length);
+    md_out.version = "1.1";
+    CHECK(codec.encodeJPEGR(&pj, &gj, &md_out, &jpgr2) == ERROR_ULTRAHDR_BAD_METADATA);
+    // API-x: the planes + the gain map made at the top
+    ultrahdr_compressed_struct jpgr3{file2.data(), 0, (int)file2.size(), ULTRAHDR_COLORGAMUT_UNSPECIFIED};
+    CHECK(codec.encodeJPEGR(&raw_yuv, &map, &metadata, &jpgr3, 90, nullptr) == ULTRAHDR_NO_ERROR);
+    dump(out + "/apix.jpgr", jpgr3.data, jpgr3.length);
+  }
   printf("shim_test ok\n");
   return 0;
 }

@@ -72,6 +72,28 @@ def test_cpp_shim_on_reference_fixture(hip, orc, tmp_path):
     assert st > 0 and np.array_equal(np.fromfile(tmp_path / "sdr_q95_decoded.bin", np.uint8), planes)
     st, planes, dw, dh, gray = orc.jpeg_decode("orc", open(tmp_path / "map_q85.jpg", "rb").read())
     assert st > 0 and gray and np.array_equal(np.fromfile(tmp_path / "map_q85_decoded.bin", np.uint8), planes)
+    # JpegRHip: every encodeJPEGR overload and decodeJPEGR against the CPU restatement (oracle/jpegr_oracle.py, pinned to the reference's
+    # sample file by tests/test_jpegr_container.py), on the reference's own 1280x720 fixture pair
+    from oracle import jpegr_oracle as J
+    p010 = np.fromfile(os.path.join(g, "raw_p010_image.p010"), np.uint16)
+    rd = lambda n: open(tmp_path / n, "rb").read()
+    exif = b"Exif\0\0MM\0*\0\0\0\x08\0\0"
+    assert rd("api0.jpgr") == J.encode_api0(p010, w, h, 2, 1, 90)
+    api1 = J.encode_api1(p010, yuv, w, h, 0, 2, 1, 90, exif=exif)
+    assert rd("api1.jpgr") == api1
+    st, ref, ow, oh, gamut, md = J.decode(api1, orc.OUT_HDR_HLG, 3.4028234663852886e38)
+    assert st == 0 and np.array_equal(np.fromfile(tmp_path / "api1_decoded_hlg.bin", np.uint8), ref)
+    gj = api1[J.find_images(api1)[1][0]:]
+    assert np.array_equal(np.fromfile(tmp_path / "api1_decoded_map.bin", np.uint8), orc.jpeg_decode("orc", gj)[1])
+    plain = orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, 95)
+    assert rd("api2.jpgr") == J.encode_api2(p010, yuv, w, h, 0, 2, plain, 0, 1)
+    assert rd("api3.jpgr") == J.encode_api3(p010, w, h, 2, plain, 0, 1)
+    i1 = J.info(api1)
+    pj, gjj = api1[:i1[0]["size"]], api1[i1[1]["offset"]:]
+    assert rd("api4.jpgr") == J.encode_api4(pj, 0, gjj, md) and rd("api4.jpgr")[:len(api1)] != api1     # EXIF lifted, XMP segments now nested: a different file
+    mdx = dict(version="1.0", max=np.float32(mb), min=np.float32(1.0), gamma=np.float32(1.0), off_sdr=np.float32(0), off_hdr=np.float32(0),
+               capmin=np.float32(1.0), capmax=np.float32(mb))
+    assert rd("apix.jpgr") == J.encode_apix(yuv, w, h, 0, gmap, mdx, 90)
 
 
 def test_hbm_synthetic_frames_match_the_survey_lcg(hip, orc):

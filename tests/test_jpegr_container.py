@@ -127,3 +127,285 @@ def test_gpu_decodes_files_assembled_from_the_device_encoder(hip, orc):
     assert _gpu_decode(lib, hip, bad, hip.OUTPUT_HDR_HLG, FLT_MAX, 0, True)[0] == hip.ERROR_BAD_METADATA       # applyGainMap's own check
     assert _gpu_decode(lib, hip, data, hip.OUTPUT_SDR, FLT_MAX, 0, True)[0] == hip.ERROR_UNSUPPORTED_FEATURE
     assert _gpu_decode(lib, hip, gj + pj, hip.OUTPUT_HDR_HLG, FLT_MAX, 0, True)[0] == -20002                # primary is not 4:2:0: DECODE_ERROR
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# assembly side (encodeJPEGR API-1)
+# ---------------------------------------------------------------------------------------------------------------------
+def _sample_streams():
+    """the two JPEG streams as they were before appendGainMap wrapped them: SOI + what follows the container segments"""
+    data = open(SAMPLE, "rb").read()
+    xmp_len = (data[4] << 8) | data[5]
+    mpf_at = 4 + xmp_len
+    mpf_len = (data[mpf_at + 2] << 8) | data[mpf_at + 3]
+    primary = b"\xff\xd8" + data[mpf_at + 2 + mpf_len:42326]
+    g = data[42326:]
+    gx = (g[4] << 8) | g[5]
+    return data, primary, b"\xff\xd8" + g[4 + gx:]
+
+
+def _append(lib, api, primary, gainmap, md, exif=None, icc=None, cap=None):
+    p, g = np.frombuffer(primary, np.uint8), np.frombuffer(gainmap, np.uint8)
+    e = None if exif is None else np.frombuffer(exif, np.uint8)
+    i = None if icc is None else np.frombuffer(icc, np.uint8)
+    out = np.zeros(len(primary) + len(gainmap) + 8192 if cap is None else cap, np.uint8)
+    n = C.c_size_t()
+    rc = lib.uhdr_hip_jpegr_append_gainmap(C.c_void_p(p.ctypes.data), p.size, C.c_void_p(g.ctypes.data), g.size, None if e is None else C.c_void_p(e.ctypes.data),
+                                           0 if e is None else e.size, None if i is None else C.c_void_p(i.ctypes.data), 0 if i is None else i.size, C.byref(md),
+                                           C.c_void_p(out.ctypes.data) if out.size else None, out.size, C.byref(n))
+    return rc, out[:n.value].tobytes() if rc == 0 else n.value
+
+
+SAMPLE_MD = dict(version="1.0", max=np.float32(10.0), min=np.float32(1.0), gamma=np.float32(1.0), off_sdr=np.float32(0.0), off_hdr=np.float32(0.0),
+                 capmin=np.float32(1.0), capmax=np.float32(10.0))
+EXIF = b"Exif\0\0MM\0*\0\0\0\x08\0\x01\x01\x12\0\x03\0\0\0\x01\0\x06\0\0\0\0\0\0"
+
+
+def test_reassembling_the_sample_file_reproduces_it_byte_for_byte(orc):
+    """appendGainMap's XMP and MPF writers (product library, host code -- no GPU involved -- and the Python restatement)
+    against the reference's own output: tests/data/sample_jpegr.jpeg"""
+    from libultrahdr_dev_amd import api
+    from oracle import jpegr_oracle as J
+    data, primary, gainmap = _sample_streams()
+    assert J.append_gainmap(primary, gainmap, SAMPLE_MD) == data
+    lib = api.load()
+    hmd = api.metadata(10.0)
+    assert _append(lib, api, primary, gainmap, hmd) == (0, data)
+    assert _append(lib, api, primary, gainmap, hmd, cap=0) == (api.ERROR_INSUFFICIENT_RESOURCE, len(data))
+    assert _append(lib, api, primary, gainmap, api.metadata(10.0, version=b"1.1"))[0] == api.ERROR_BAD_METADATA
+    n = C.c_size_t()
+    # the ICC segment inside the sample's primary JPEG is writeIccProfile(TF_SRGB, BT709)
+    i = data.find(b"ICC_PROFILE\0")
+    seg_len = (data[i - 2] << 8) | data[i - 1]
+    want = data[i:i - 2 + seg_len]
+    assert J.icc_profile_srgb_transfer(orc.CG_BT709) == want
+    icc = np.zeros(4096, np.uint8)
+    assert lib.uhdr_hip_icc_profile(api.TF_SRGB, api.CG_BT709, C.c_void_p(icc.ctypes.data), icc.size, C.byref(n)) == 0 and icc[:n.value].tobytes() == want
+    for gamut in (api.CG_P3, api.CG_BT2100):       # the other two gamuts: product == restatement, and the decoder's gamut reader recognises them
+        assert lib.uhdr_hip_icc_profile(api.TF_SRGB, gamut, C.c_void_p(icc.ctypes.data), icc.size, C.byref(n)) == 0
+        assert icc[:n.value].tobytes() == J.icc_profile_srgb_transfer(gamut) and J.gamut_from_icc(icc[:n.value].tobytes()) == gamut
+    assert lib.uhdr_hip_icc_profile(api.TF_HLG, api.CG_BT709, C.c_void_p(icc.ctypes.data), icc.size, C.byref(n)) == api.ERROR_UNSUPPORTED_FEATURE
+
+
+def test_append_gainmap_exif_and_icc_handling(orc):
+    """appendGainMap's EXIF / ICC arguments and the EXIF segment it lifts out of the primary JPEG (jpegr.cpp:1003-1071); host code,
+    product == restatement.  What the restatement rests on: the segment order documented at jpegr.cpp:917-949 and the sample pin above."""
+    from libultrahdr_dev_amd import api
+    from oracle import jpegr_oracle as J
+    lib = api.load()
+    data, primary, gainmap = _sample_streams()
+    hmd = api.metadata(10.0)
+    icc = J.icc_profile_srgb_transfer(orc.CG_P3)
+    seg = lambda m, b: bytes((0xFF, m)) + struct.pack(">H", len(b) + 2) + b
+    with_exif = primary[:2] + seg(0xE1, EXIF) + primary[2:]                            # EXIF right after SOI
+    after_app0 = primary[:2] + seg(0xE0, b"JFIF\0\1\1\0\0\1\0\1\0\0") + seg(0xE1, EXIF) + primary[2:]
+    after_app2 = primary[:2] + seg(0xE2, b"X" * 10) + seg(0xE1, EXIF) + primary[2:]     # an unsaved segment in front: the reference's position is off
+    for prim, ex, ic in ((primary, EXIF, None), (primary, None, icc), (primary, EXIF, icc), (with_exif, None, None), (after_app0, None, icc),
+                         (after_app2, None, None)):
+        want = J.append_gainmap(prim, gainmap, SAMPLE_MD, exif=ex, icc=ic)
+        assert isinstance(want, bytes) and _append(lib, api, prim, gainmap, hmd, ex, ic) == (0, want)
+    plain = J.append_gainmap(primary, gainmap, SAMPLE_MD, exif=EXIF)
+    assert J.append_gainmap(with_exif, gainmap, SAMPLE_MD) == plain                     # lifted EXIF lands where an external one would
+    assert plain[:4] == b"\xff\xd8\xff\xe1" and plain[6:12] == b"Exif\0\0"
+    assert _append(lib, api, with_exif, gainmap, hmd, EXIF)[0] == -20007 == J.append_gainmap(with_exif, gainmap, SAMPLE_MD, exif=EXIF)
+    assert _append(lib, api, primary[:200], gainmap, hmd)[0] == api.ERROR_DECODE_ERROR == J.append_gainmap(primary[:200], gainmap, SAMPLE_MD)
+    assert _append(lib, api, b"\0\0" + primary[2:], gainmap, hmd)[0] == api.ERROR_DECODE_ERROR
+    # files with EXIF + ICC up front still split and parse (decode side of the same container)
+    both = J.append_gainmap(primary, gainmap, SAMPLE_MD, exif=EXIF, icc=icc)
+    imgs = J.find_images(both)
+    assert len(imgs) == 2 and both[imgs[1][0]:imgs[1][0] + imgs[1][1]][-len(gainmap) + 2:] == gainmap[2:]
+
+
+def test_api4_and_info_on_host(orc):
+    """encodeJPEGR API-4 (jpegr.cpp:502-560) and getJPEGRInfo (:633-653): host-only entry points of the product library"""
+    from libultrahdr_dev_amd import api
+    from oracle import jpegr_oracle as J
+    lib = api.load()
+    data, primary, gainmap = _sample_streams()
+    hmd = api.metadata(10.0)
+
+    def api4(prim, gamut, md=hmd, cap=1 << 17):
+        p, g = np.frombuffer(prim, np.uint8), np.frombuffer(gainmap, np.uint8)
+        out, n = np.zeros(cap, np.uint8), C.c_size_t()
+        rc = lib.uhdr_hip_jpegr_encode_api4(C.c_void_p(p.ctypes.data), p.size, gamut, C.c_void_p(g.ctypes.data), g.size, None if md is None else C.byref(md),
+                                            C.c_void_p(out.ctypes.data), out.size, C.byref(n))
+        return rc, out[:n.value].tobytes() if rc == 0 else None
+    assert api4(primary, api.CG_UNSPECIFIED) == (0, data)                       # the sample's primary carries an ICC profile: nothing added
+    i = primary.find(b"ICC_PROFILE\0")
+    seg_len = (primary[i - 2] << 8) | primary[i - 1]
+    no_icc = primary[:i - 4] + primary[i - 2 + seg_len:]
+    assert J.app_segment(no_icc, 0xE2, J.ICC_ID) is None
+    for gamut in (api.CG_BT709, api.CG_P3, api.CG_BT2100):
+        want = J.encode_api4(no_icc, gamut, gainmap, SAMPLE_MD)
+        assert api4(no_icc, gamut) == (0, want) and J.gamut_from_icc(J.app_segment(want, 0xE2, J.ICC_ID)) == gamut
+    assert api4(no_icc, api.CG_UNSPECIFIED)[0] == api.ERROR_INVALID_COLORGAMUT == J.encode_api4(no_icc, -1, gainmap, SAMPLE_MD)
+    assert api4(primary[:100], api.CG_BT709)[0] == api.ERROR_DECODE_ERROR == J.encode_api4(primary[:100], 0, gainmap, SAMPLE_MD)
+    assert api4(primary, api.CG_BT709, md=None)[0] == api.ERROR_BAD_PTR
+    assert api4(primary, api.CG_BT709, cap=100)[0] == api.ERROR_INSUFFICIENT_RESOURCE
+
+    def info(blob, want_gainmap=True):
+        b = np.frombuffer(blob, np.uint8)
+        a, g = api.JpegInfo(), api.JpegInfo()
+        rc = lib.uhdr_hip_jpegr_info(C.c_void_p(b.ctypes.data), b.size, C.byref(a), C.byref(g) if want_gainmap else None)
+        conv = lambda x: dict(offset=x.offset, size=x.size, width=x.width, height=x.height, icc=(x.icc_offset, x.icc_size), exif=(x.exif_offset, x.exif_size),
+                              xmp=(x.xmp_offset, x.xmp_size))
+        return rc if rc != 0 else [conv(a), conv(g)][:2 if want_gainmap else 1]
+    got = info(data)
+    assert got == J.info(data)
+    assert (got[0]["width"], got[0]["height"], got[0]["offset"], got[0]["size"]) == (1280, 720, 0, 42326) and got[1]["size"] == 3727
+    assert (got[1]["width"], got[1]["height"]) == (320, 180)
+    assert data[got[0]["icc"][0]:][:12] == b"ICC_PROFILE\0" and got[0]["icc"][1] == 602 and got[0]["exif"] == (0, 0)
+    assert data[got[1]["xmp"][0]:][:29] == J.XMP_NS and b"hdrgm:GainMapMax" in data[got[1]["xmp"][0]:got[1]["xmp"][0] + got[1]["xmp"][1]]
+    assert info(data, False) == J.info(data)[:1]
+    both = J.append_gainmap(primary, gainmap, SAMPLE_MD, exif=EXIF)
+    assert info(both) == J.info(both) and info(both)[0]["exif"][1] == len(EXIF)
+    assert info(primary) == -20003 == J.info(primary) and info(b"\0" * 64) == -20006 == J.info(b"\0" * 64)
+
+
+class _Enc:
+    """calls the encodeJPEGR entry points with tightly packed numpy inputs living on the host or on the device"""
+
+    def __init__(self, hip, device):
+        from tests.gpu_util import stream_ptr, to_dev
+        self.hip, self.lib, self.device = hip, hip.load(), device
+        self.ms, self.stream = (hip.MEM_DEVICE, stream_ptr()) if device else (hip.MEM_HOST, None)
+        self._keep, self._to_dev = [], to_dev
+
+    def _img(self, maker, arr, w, h, gamut, defaults=True, **kw):
+        if self.device:
+            d = self._to_dev(arr)
+            self._keep.append(d)
+            return maker(d.data_ptr(), w, h, gamut, **kw)
+        im = maker(arr.ctypes.data, w, h, gamut, **kw)
+        if defaults and not kw:                      # the reference's "0 / nullptr means packed" defaults (jpegr.cpp:261-275)
+            im.chroma_data, im.luma_stride, im.chroma_stride = None, 0, 0
+        return im
+
+    def p010(self, arr, w, h, gamut, **kw):
+        return self._img(self.hip.p010_image, arr, w, h, gamut, **kw)
+
+    def yuv(self, arr, w, h, gamut, **kw):
+        return self._img(self.hip.yuv420_image, arr, w, h, gamut, **kw)
+
+    def run(self, name, *args, cap=1 << 22):
+        out, n = np.zeros(cap, np.uint8), C.c_size_t()
+        conv = []
+        for a in args:
+            if isinstance(a, bytes):
+                b = np.frombuffer(a, np.uint8)
+                self._keep.append(b)
+                conv += [C.c_void_p(b.ctypes.data), b.size]
+            elif a is None:
+                conv += [None, 0]
+            elif isinstance(a, (self.hip.Image, self.hip.Metadata)):
+                conv.append(C.byref(a))
+            else:
+                conv.append(a)
+        tail = [C.c_void_p(out.ctypes.data), out.size, C.byref(n)] + ([] if name == "api4" else [self.ms, self.stream])
+        rc = getattr(self.lib, "uhdr_hip_jpegr_encode_" + name)(*conv, *tail)
+        return rc, (out[:n.value].tobytes() if rc == 0 else n.value)
+
+
+ENC_CASES = (((640, 480), 0, 1, 95), ((200, 120), 1, 2, 80), ((72, 40), 2, 0, 100))      # (w, h), SDR gamut, hdr_tf, quality
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [True, False])
+def test_gpu_encode_api0_api1_equal_the_restatement_and_round_trip(hip, orc, device):
+    """encodeJPEGR API-0 / API-1 on the device (BASELINE configs[0]: 640x480 P010 + YUV420) == the CPU restatement, byte for byte; the
+    files then decode through uhdr_hip_jpegr_decode"""
+    from oracle import jpegr_oracle as J
+    from tests.test_gpu_parity import smooth_frame
+    e = _Enc(hip, device)
+    for (w, h), sg, tf, q in ENC_CASES:
+        p010, yuv = smooth_frame(w, h, w)
+        for exif in (None, EXIF):
+            want = J.encode_api1(p010, yuv, w, h, sg, hip.CG_BT2100, tf, q, exif=exif)
+            rc, got = e.run("api1", e.p010(p010, w, h, hip.CG_BT2100), e.yuv(yuv, w, h, sg), tf, q, exif)
+            assert rc == 0 and got == want, ("api1", w, h, sg, tf)
+        st, ref, ow, oh, gamut, md = J.decode(got, orc.OUT_HDR_HLG, FLT_MAX)
+        rc, dec, dest, _ = _gpu_decode(e.lib, hip, got, hip.OUTPUT_HDR_HLG, FLT_MAX, hip.APPLY_EXACT, device)
+        assert rc == st == 0 and (dest.width, dest.height, dest.colorGamut) == (w, h, sg) and np.array_equal(dec, ref)
+        want = J.encode_api0(p010, w, h, sg, tf, q, exif=EXIF)                # the HDR gamut is also the SDR gamut on this path
+        rc, got = e.run("api0", e.p010(p010, w, h, sg), tf, q, EXIF)
+        assert rc == 0 and got == want, ("api0", w, h, sg, tf)
+        assert e.run("api0", e.p010(p010, w, h, sg), tf, q, None, cap=64) == (hip.ERROR_INSUFFICIENT_RESOURCE, len(J.encode_api0(p010, w, h, sg, tf, q)))
+    # strided inputs with separate chroma planes: same file as the packed ones
+    w, h, ls = 104, 56, 128
+    p010, yuv = smooth_frame(w, h, 5)
+    sp = np.zeros(ls * h * 3 // 2, np.uint16)
+    sp[:ls * h].reshape(h, ls)[:, :w] = p010[:w * h].reshape(h, w)
+    sp[ls * h:].reshape(h // 2, ls)[:, :w] = p010[w * h:].reshape(h // 2, w)
+    sy = np.full(ls * h * 3 // 2, 0x55, np.uint8)
+    sy[:ls * h].reshape(h, ls)[:, :w] = yuv[:w * h].reshape(h, w)
+    cw, ch, cs = w // 2, h // 2, ls // 2
+    sy[ls * h:ls * h + cs * ch].reshape(ch, cs)[:, :cw] = yuv[w * h:w * h + cw * ch].reshape(ch, cw)
+    sy[ls * h + cs * ch:].reshape(ch, cs)[:, :cw] = yuv[w * h + cw * ch:].reshape(ch, cw)
+    want = J.encode_api1(p010, yuv, w, h, hip.CG_BT709, hip.CG_BT2100, hip.TF_HLG, 90)
+    rc, got = e.run("api1", e.p010(sp, w, h, hip.CG_BT2100, luma_stride=ls), e.yuv(sy, w, h, hip.CG_BT709, luma_stride=ls), hip.TF_HLG, 90, None)
+    assert rc == 0 and got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [True, False])
+def test_gpu_encode_api2_api3_apix_equal_the_restatement(hip, orc, device):
+    """encodeJPEGR API-2 / API-3 (gain map for a given SDR JPEG; API-3 decodes it on the device and treats the planes as BT.601) and
+    API-x (ready gain map) == the CPU restatement, byte for byte"""
+    from oracle import jpegr_oracle as J
+    from tests.test_gpu_parity import smooth_frame
+    e = _Enc(hip, device)
+    for (w, h), sg, tf, q in ENC_CASES:
+        p010, yuv = smooth_frame(w, h, w + 1)
+        for with_icc in (True, False):
+            sdr_jpeg = orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, q, icc=J.icc_profile_srgb_transfer(sg) if with_icc else None)
+            want = J.encode_api2(p010, yuv, w, h, sg, hip.CG_BT2100, sdr_jpeg, sg, tf)
+            rc, got = e.run("api2", e.p010(p010, w, h, hip.CG_BT2100), e.yuv(yuv, w, h, sg), sdr_jpeg, sg, tf)
+            assert rc == 0 and got == want, ("api2", w, h, with_icc)
+            for cfg in (sg, hip.CG_UNSPECIFIED):
+                want = J.encode_api3(p010, w, h, hip.CG_BT2100, sdr_jpeg, cfg, tf)
+                rc, got = e.run("api3", e.p010(p010, w, h, hip.CG_BT2100), sdr_jpeg, cfg, tf)
+                if isinstance(want, bytes):
+                    assert rc == 0 and got == want, ("api3", w, h, with_icc, cfg)
+                else:
+                    assert rc == want == hip.ERROR_INVALID_COLORGAMUT and not with_icc
+        # the SDR JPEG's ICC gamut disagreeing with the configured one (jpegr.cpp:470-478), and a size mismatch (:496-499)
+        sdr_jpeg = orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, q, icc=J.icc_profile_srgb_transfer(sg))
+        assert e.run("api3", e.p010(p010, w, h, hip.CG_BT2100), sdr_jpeg, (sg + 1) % 3, tf)[0] == hip.ERROR_INVALID_COLORGAMUT
+        p2, _ = smooth_frame(w + 8, h, 3)
+        assert e.run("api3", e.p010(p2, w + 8, h, hip.CG_BT2100), sdr_jpeg, sg, tf)[0] == hip.ERROR_RESOLUTION_MISMATCH
+        assert e.run("api3", e.p010(p010, w, h, hip.CG_BT2100), sdr_jpeg[:len(sdr_jpeg) // 2], sg, tf)[0] == hip.ERROR_DECODE_ERROR
+        # API-x
+        gmap = (np.arange((w // 4) * (h // 4), dtype=np.uint32) * 7 % 251).astype(np.uint8).reshape(h // 4, w // 4)
+        md = dict(version="1.0", max=np.float32(6.5), min=np.float32(0.5), gamma=np.float32(1.0), off_sdr=np.float32(0.015625), off_hdr=np.float32(0.015625),
+                  capmin=np.float32(1.0), capmax=np.float32(6.5))
+        hmd = hip.metadata(6.5, 0.5)
+        hmd.offsetSdr = hmd.offsetHdr = 0.015625
+        hmd.hdrCapacityMin = 1.0
+        want = J.encode_apix(yuv, w, h, sg, gmap, md, q, exif=EXIF)
+        g = e._img(lambda ptr, gw, gh, _g: hip.mono_image(ptr, gw, gh), gmap.reshape(-1), w // 4, h // 4, -1, defaults=False)
+        rc, got = e.run("apix", e.yuv(yuv, w, h, sg), g, hmd, q, EXIF)
+        assert rc == 0 and got == want, ("apix", w, h)
+        assert J.metadata_from_xmp(J.app_segment(got[J.find_images(got)[1][0]:], 0xE1, J.XMP_NS))["min"] == np.float32(0.5)
+
+
+@pytest.mark.gpu
+def test_gpu_encode_status_codes_in_the_reference_order(hip):
+    """areInputArgumentsValid (jpegr.cpp:75-183) and the per-overload checks"""
+    from tests.test_gpu_parity import smooth_frame
+    e = _Enc(hip, False)
+    p010, yuv = smooth_frame(64, 48, 1)
+    P = lambda w=64, h=48, g=hip.CG_BT2100, **kw: e.p010(p010, w, h, g, **kw)
+    Y = lambda w=64, h=48, g=hip.CG_BT709, **kw: e.yuv(yuv, w, h, g, **kw)
+    api1 = lambda p, y, tf=hip.TF_HLG, q=90: e.run("api1", p, y, tf, q, None)[0]
+    assert api1(P(), Y()) == 0
+    assert e.lib.uhdr_hip_jpegr_encode_api1(C.byref(P()), None, 1, 90, None, 0, None, 0, None, 0, None) == hip.ERROR_BAD_PTR
+    assert api1(P(), Y(), q=101) == hip.ERROR_INVALID_QUALITY_FACTOR == api1(P(63), Y(), q=-1)          # quality before anything about the images
+    assert api1(P(63), Y()) == hip.ERROR_UNSUPPORTED_WIDTH_HEIGHT == api1(P(64, 47), Y()) == api1(P(4, 4), Y()) == api1(P(8194, 48), Y())
+    assert api1(P(g=hip.CG_UNSPECIFIED), Y()) == hip.ERROR_INVALID_COLORGAMUT == api1(P(), Y(g=3))
+    assert api1(P(luma_stride=32), Y()) == hip.ERROR_INVALID_STRIDE == api1(P(), Y(luma_stride=32)) == api1(P(), Y(chroma_stride=16))
+    assert api1(P(), Y(), tf=hip.TF_SRGB) == hip.ERROR_INVALID_TRANS_FUNC == api1(P(), Y(), tf=-1) == api1(P(), Y(32), tf=4)   # before the YUV checks
+    assert api1(P(), Y(32)) == hip.ERROR_RESOLUTION_MISMATCH == api1(P(), Y(64, 32))
+    assert e.run("api0", P(), hip.TF_PQ, 101, None)[0] == hip.ERROR_INVALID_QUALITY_FACTOR and e.run("api0", P(63), hip.TF_PQ, 90, None)[0] == -10002
+    assert e.lib.uhdr_hip_jpegr_encode_api0(C.byref(P()), 1, 90, None, 12, C.c_void_p(p010.ctypes.data), 64, C.byref(C.c_size_t()), 0, None) == hip.ERROR_BAD_PTR
+    assert e.run("api2", P(), Y(), b"\xff\xd8\xff\xd9", 0, hip.TF_HLG)[0] == hip.ERROR_DECODE_ERROR
+    assert e.run("api3", P(), b"\xff\xd8\xff\xd9", 0, hip.TF_HLG)[0] == hip.ERROR_DECODE_ERROR

@@ -314,6 +314,10 @@ typedef struct uhdr_hip_jpeg_info {
 } uhdr_hip_jpeg_info_t;
 int uhdr_hip_jpegr_info(const void* jpegr, size_t jpegr_size, uhdr_hip_jpeg_info_t* primary, uhdr_hip_jpeg_info_t* gainmap);
 
+/* getMetadataFromXMP (lib/src/jpegrutils.cpp:436-545) on the gain-map image of a JPEG/R file, as uhdr_dec_probe does after
+ * getJPEGRInfo (lib/src/ultrahdr_api.cpp:1038-1108).  Host code.  METADATA_ERROR when the packet is missing or malformed. */
+int uhdr_hip_jpegr_metadata(const void* jpegr, size_t jpegr_size, uhdr_hip_metadata_t* metadata);
+
 /* ---- batches (device memory only, asynchronous on `stream`) ------------------------------ */
 /* The reference processes one image per call; a batch is n independent calls with identical
  * (hdr_tf, sdr_is_601 | metadata, output_format, max_display_boost).  Images of equal size share

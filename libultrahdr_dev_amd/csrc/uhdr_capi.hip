@@ -1083,6 +1083,22 @@ int uhdr_hip_jpegr_info(const void* jpegr, size_t jpegr_size, uhdr_hip_jpeg_info
   return gainmap != nullptr ? parse(img[1], gainmap) : UHDR_HIP_NO_ERROR;
 }
 
+int uhdr_hip_jpegr_metadata(const void* jpegr, size_t jpegr_size, uhdr_hip_metadata_t* metadata) {
+  if (jpegr == nullptr || metadata == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  const uint8_t* file = static_cast<const uint8_t*>(jpegr);
+  jpegr::Range img[2];
+  const int found = jpegr::find_images(file, jpegr_size, img);
+  if (found == 0) return UHDR_HIP_ERROR_NO_IMAGES_FOUND;
+  if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
+  const uint8_t* xmp = nullptr;
+  size_t xmp_len = 0;
+  static const char kXmpNs[] = "http://ns.adobe.com/xap/1.0/";
+  if (!jpegr::find_app_segment(file + img[1].begin, img[1].len, 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) ||
+      !jpegr::metadata_from_xmp(xmp, xmp_len, metadata))
+    return UHDR_HIP_ERROR_METADATA_ERROR;
+  return UHDR_HIP_NO_ERROR;
+}
+
 int uhdr_hip_lut_table(int which, float* out, size_t capacity, size_t* count) {
   if (out == nullptr || count == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   DeviceState* st = nullptr;

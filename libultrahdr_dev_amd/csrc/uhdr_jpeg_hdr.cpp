@@ -1,0 +1,113 @@
+// uhdr_jpeg_hdr.cpp -- the host-side JPEG header parser of the device decoder (baseline sequential, 8 bit, Huffman, 4:2:0 or
+// single plane, no restart intervals).  Everything it returns sizes or indexes device buffers, so it sees the untrusted file first;
+// plain C++ on purpose: tests/cpp/fuzz_host_parsers.cpp builds it with AddressSanitizer / UBSan on the CPU.
+// Follows what jpeg_read_header + the checks of JpegDecoderHelper::decode accept (lib/src/jpegdecoderhelper.cpp:190-300).
+#include <cstring>
+
+#include "uhdr_jpeg.h"
+
+namespace uhdr {
+namespace jpeg {
+
+static unsigned rd16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
+  if (jpg == nullptr || n < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return -1;
+  memset(info, 0, sizeof(*info));
+  static const uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                  41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                  30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  (void)nat;
+  uint16_t quant[4][64];   // zigzag order, as stored in the file
+  bool have_q[4] = {false, false, false, false};
+  HuffSpec huff[2][4];
+  memset(huff, 0, sizeof(huff));
+  int nc = 0, hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, cid[3] = {0, 0, 0};
+  size_t pos = 2;
+  for (;;) {
+    while (pos + 1 < n && jpg[pos] == 0xFF && jpg[pos + 1] == 0xFF) pos++;
+    if (pos + 4 > n || jpg[pos] != 0xFF) return -1;
+    const unsigned m = jpg[pos + 1];
+    const size_t len = rd16(jpg + pos + 2);
+    const uint8_t* seg = jpg + pos + 4;
+    if (len < 2 || pos + 2 + len > n) return -1;
+    if (m == 0xDB) {
+      for (size_t o = 0; o + 1 <= len - 2;) {
+        const int pq = seg[o] >> 4, id = seg[o] & 15;
+        const size_t sz = pq ? 128 : 64;
+        if (id > 3 || o + 1 + sz > len - 2) return -1;
+        for (int i = 0; i < 64; ++i) quant[id][i] = pq ? (uint16_t)rd16(seg + o + 1 + 2 * i) : seg[o + 1 + i];
+        have_q[id] = true;
+        o += 1 + sz;
+      }
+    } else if (m == 0xC4) {
+      for (size_t o = 0; o + 17 <= len - 2;) {
+        const int cls = seg[o] >> 4, id = seg[o] & 15;
+        int cnt = 0;
+        for (int i = 0; i < 16; ++i) cnt += seg[o + 1 + i];
+        if (cls > 1 || id > 3 || cnt > 256 || o + 17 + (size_t)cnt > len - 2) return -1;
+        HuffSpec& h = huff[cls][id];
+        memset(&h, 0, sizeof(h));
+        uint32_t code = 0, p = 0;
+        for (int l = 1; l <= 16; ++l) {   // T.81 Annex C
+          h.first_code[l] = (uint16_t)code;
+          h.first_val[l] = (uint16_t)p;
+          h.count[l] = seg[o + l];
+          code += h.count[l];
+          p += h.count[l];
+          code <<= 1;
+        }
+        memcpy(h.vals, seg + o + 17, (size_t)cnt);
+        h.present = 1;
+        o += 17 + (size_t)cnt;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {
+      if (len < 8 || seg[0] != 8) return -2;
+      info->h = (int)rd16(seg + 1); info->w = (int)rd16(seg + 3); nc = seg[5];
+      if (nc != 1 && nc != 3) return -2;
+      if (len < (size_t)(8 + 3 * nc)) return -1;
+      for (int c = 0; c < nc; ++c) { cid[c] = seg[6 + 3 * c]; hs[c] = seg[7 + 3 * c] >> 4; vs[c] = seg[7 + 3 * c] & 15; tq[c] = seg[8 + 3 * c]; }
+    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+      return -2;   // progressive, lossless, arithmetic: libjpeg reads some of these, this decoder does not
+    } else if (m == 0xDD) {
+      if (rd16(seg) != 0) return -2;   // restart intervals
+    } else if (m == 0xDA) {
+      if (nc == 0 || seg[0] != nc || len < (size_t)(6 + 2 * nc)) return -2;
+      info->gray = nc == 1;
+      if (!info->gray && !(hs[0] == 2 && vs[0] == 2 && hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1)) return -1;   // the reference fails too, jpegdecoderhelper.cpp:283-289
+      if (info->w <= 0 || info->h <= 0) return -1;
+      for (int c = 0; c < nc; ++c) {
+        if (seg[1 + 2 * c] != cid[c]) return -2;
+        const int td = seg[2 + 2 * c] >> 4, ta = seg[2 + 2 * c] & 15;
+        if (td > 3 || ta > 3 || !huff[0][td].present || !huff[1][ta].present || tq[c] > 3 || !have_q[tq[c]]) return -1;
+        memcpy(info->quant[c], quant[tq[c]], sizeof(quant[0]));
+        if (c <= 1) {   // luma tables in slots 0 (DC) / 1 (AC), chroma in 2 / 3; Cr must share Cb's tables
+          info->tables.huff[2 * c] = huff[0][td];
+          info->tables.huff[2 * c + 1] = huff[1][ta];
+          info->td[c] = td; info->ta[c] = ta;
+        } else if (td != info->td[1] || ta != info->ta[1]) {
+          return -2;
+        }
+      }
+      info->scan_offset = pos + 2 + len;
+      // the entropy-coded segment ends at the first marker that is neither a stuffed zero nor a fill byte
+      size_t e = info->scan_offset;
+      for (;;) {   // memchr: the segment is megabytes long and 0xFF is rare in it
+        const void* f = e + 1 < n ? memchr(jpg + e, 0xFF, n - 1 - e) : nullptr;
+        if (f == nullptr) return -1;
+        e = (size_t)(static_cast<const uint8_t*>(f) - jpg);
+        if (jpg[e + 1] != 0x00 && jpg[e + 1] != 0xFF) break;
+        e += jpg[e + 1] == 0x00 ? 2 : 1;
+      }
+      if ((jpg[e + 1] & 0xF8) == 0xD0) return -2;   // RSTn without DRI cannot happen in a valid file
+      info->scan_bytes = e - info->scan_offset;
+      return 0;
+    } else if (m == 0xD9) {
+      return -1;
+    }
+    pos += 2 + len;
+  }
+}
+
+}  // namespace jpeg
+}  // namespace uhdr

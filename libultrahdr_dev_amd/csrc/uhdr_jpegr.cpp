@@ -1,12 +1,10 @@
-// uhdr_jpegr.hip -- the decode surface of JpegR on the device: JpegR::decodeJPEGR (lib/src/jpegr.cpp:655-822) for the HDR
-// output formats.  A JPEG/R file is two concatenated JPEGs (primary SDR image, gain map); the gain map's APP1 carries the
-// hdrgm:* XMP attributes.  Host work here is container bookkeeping only (marker walking, a dozen XMP attributes, three ICC
-// colorant tags); both images are decompressed by the device decoder (uhdr_jpeg_dec.hip) into device memory and combined by
-// the applyGainMap kernels without touching the host.
+// uhdr_jpegr.cpp -- host-side bookkeeping of the JPEG/R container, both directions (plain C++: also built under AddressSanitizer by
+// tests/cpp/fuzz_host_parsers.cpp).  A JPEG/R file is two concatenated JPEGs (primary SDR image, gain map); the gain map's APP1
+// carries the hdrgm:* XMP attributes.  Nothing here touches pixels: marker walking, a dozen XMP attributes, three ICC colorant
+// tags, and the writers of the same; the images themselves are (de)compressed and combined on the device (uhdr_capi.hip).
 //   extractPrimaryImageAndGainMap  jpegr.cpp:823-876   (image ranges; the reference uses image_io's JpegScanner)
 //   getMetadataFromXMP             jpegrutils.cpp:436-545 (+ the XMPXmlHandler getters :213-330)
 //   IccHelper::readIccColorGamut   icc.cpp:615-685
-#include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// uhdr_jpegr.h -- JPEG/R container bookkeeping (uhdr_jpegr.hip)
+// uhdr_jpegr.h -- JPEG/R container bookkeeping (uhdr_jpegr.cpp)
 #pragma once
 #include <stddef.h>
 #include <stdint.h>

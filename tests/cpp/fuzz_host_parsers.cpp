@@ -1,0 +1,103 @@
+// fuzz_host_parsers.cpp -- mutation fuzzing of the HOST-side parsers that see untrusted bytes before anything is launched on the
+// device: the JPEG/R container scan, XMP / ICC readers, EXIF lifting in appendGainMap, and the JPEG header parser whose output
+// sizes every device buffer of the decoder.  Built with AddressSanitizer + UBSan on the CPU (the reference ships libFuzzer targets
+// for the same surface, fuzzer/ultrahdr_dec_fuzzer.cpp); no GPU is touched.
+// usage: fuzz_host_parsers <seed file>... <iterations>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/uhdr_hip.h"
+#include "../../libultrahdr_dev_amd/csrc/uhdr_jpeg.h"
+#include "../../libultrahdr_dev_amd/csrc/uhdr_jpegr.h"
+
+using namespace uhdr;
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd() {
+  rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+  return (uint32_t)(rng_state >> 16);
+}
+
+static void exercise(const std::vector<uint8_t>& in) {
+  // exact-size heap copy so that any read past the end is an ASan report
+  uint8_t* d = static_cast<uint8_t*>(malloc(in.size() ? in.size() : 1));
+  memcpy(d, in.data(), in.size());
+  const size_t n = in.size();
+  jpegr::Range img[2];
+  const int found = jpegr::find_images(d, n, img);
+  for (int i = 0; i < found && i < 2; ++i) {
+    if (img[i].begin + img[i].len > n) { fprintf(stderr, "range out of file\n"); abort(); }
+    const uint8_t* j = d + img[i].begin;
+    const uint8_t* payload = nullptr;
+    size_t plen = 0;
+    static const char kXmp[] = "http://ns.adobe.com/xap/1.0/";
+    static const char kIcc[] = "ICC_PROFILE";
+    uhdr_hip_metadata_t md;
+    if (jpegr::find_app_segment(j, img[i].len, 0xE1, kXmp, sizeof(kXmp), &payload, &plen)) (void)jpegr::metadata_from_xmp(payload, plen, &md);
+    if (jpegr::find_app_segment(j, img[i].len, 0xE2, kIcc, sizeof(kIcc), &payload, &plen)) (void)jpegr::gamut_from_icc(payload, plen);
+    size_t a, b, c, e, f, g;
+    jpegr::first_packets(j, img[i].len, &a, &b, &c, &e, &f, &g);
+    if (a + b > img[i].len || c + e > img[i].len || f + g > img[i].len) { fprintf(stderr, "packet out of image\n"); abort(); }
+    int w, h;
+    (void)jpegr::dimensions(j, img[i].len, &w, &h);
+    jpeg::DecInfo info;
+    if (jpeg::parse_header(j, img[i].len, &info) == 0) {
+      if (info.scan_offset + info.scan_bytes > img[i].len || info.w <= 0 || info.h <= 0 || info.w > 65535 || info.h > 65535) { fprintf(stderr, "bad DecInfo\n"); abort(); }
+    }
+  }
+  // the whole buffer as a "primary JPEG" for appendGainMap's EXIF lifting
+  uhdr_hip_metadata_t md;
+  memset(&md, 0, sizeof(md));
+  strcpy(md.version, "1.0");
+  md.maxContentBoost = 4.0f; md.minContentBoost = 1.0f; md.gamma = 1.0f; md.hdrCapacityMin = 1.0f; md.hdrCapacityMax = 4.0f;
+  static const uint8_t gm[4] = {0xFF, 0xD8, 0xFF, 0xD9};
+  std::vector<uint8_t> out;
+  (void)jpegr::append_gainmap(d, n, gm, sizeof(gm), nullptr, 0, nullptr, 0, md, out);
+  // and raw bytes straight into the text / tag readers
+  uhdr_hip_metadata_t m2;
+  (void)jpegr::metadata_from_xmp(d, n, &m2);
+  (void)jpegr::gamut_from_icc(d, n);
+  free(d);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  std::vector<std::vector<uint8_t>> seeds;
+  for (int i = 1; i < argc - 1; ++i) {
+    FILE* f = fopen(argv[i], "rb");
+    if (!f) { perror(argv[i]); return 2; }
+    std::vector<uint8_t> b;
+    uint8_t buf[65536];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof(buf), f)) > 0) b.insert(b.end(), buf, buf + k);
+    fclose(f);
+    seeds.push_back(b);
+  }
+  const long iters = atol(argv[argc - 1]);
+  for (const auto& s : seeds) exercise(s);
+  for (long it = 0; it < iters; ++it) {
+    std::vector<uint8_t> v = seeds[rnd() % seeds.size()];
+    const int kind = rnd() % 6;
+    const int edits = 1 + rnd() % 8;
+    // most structure lives in the first KBs (markers, XMP, ICC, tables): bias the edits there
+    auto where = [&](size_t n) { return (rnd() & 3) ? rnd() % (n < 4096 ? n : 4096) : rnd() % n; };
+    for (int e = 0; e < edits && !v.empty(); ++e) {
+      const size_t p = where(v.size());
+      switch (kind) {
+        case 0: v[p] = (uint8_t)rnd(); break;
+        case 1: v[p] = 0xFF; break;
+        case 2: v[p] ^= (uint8_t)(1u << (rnd() & 7)); break;
+        case 3: v.resize(p); break;                                           // truncate
+        case 4: { size_t k = rnd() % 64; if (k > v.size() - p) k = v.size() - p; v.erase(v.begin() + p, v.begin() + p + k); } break;
+        case 5: { uint8_t ins[8]; for (auto& x : ins) x = (uint8_t)rnd(); v.insert(v.begin() + p, ins, ins + 1 + rnd() % 8); } break;
+      }
+    }
+    exercise(v);
+  }
+  printf("fuzz ok: %ld iterations over %zu seeds\n", iters, seeds.size());
+  return 0;
+}

@@ -227,8 +227,9 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
  * the memory space given by mem_space.  *desc is filled (data = out, chroma_data, strides, pixelFormat YUV420 or
  * MONOCHROME) when the header is readable, also on ERROR_INSUFFICIENT_RESOURCE (out_capacity too small: width*height*3/2
  * resp. width*height bytes are needed).  Huffman decoding (self-synchronising parallel decoder), dequantisation and IDCT
- * run on the device.  ERROR_UNSUPPORTED_FEATURE: progressive / arithmetic / restart-interval files and samplings other
- * than 4:2:0 (the last the reference rejects too, :256-262); UNKNOWN_ERROR: malformed file.  The call waits for the stream. */
+ * run on the device.  ERROR_UNSUPPORTED_FEATURE: progressive / arithmetic / restart-interval files (libjpeg reads them, this
+ * decoder does not); UNKNOWN_ERROR: malformed file, or a sampling other than 4:2:0 / single plane, where the reference's call
+ * returns false as well (:283-289).  The call waits for the stream. */
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
                          int mem_space, void* stream);
 

@@ -131,9 +131,11 @@ def test_decoder_is_byte_exact_on_the_corpus(hip, orc, tmp_path, device):
         assert rc == 0 and st > 0, (name, rc, st)
         assert (desc.width, desc.height) == (w, h) and (desc.pixelFormat == hip.PIX_FMT_MONOCHROME) == bool(gray), name
         assert np.array_equal(got, want), (name, int((got != want).sum()))
-    for k in ("prog", "rst", "rst_rows", "s444"):      # outside the device decoder (and, for 4:4:4, outside the reference)
+    for k in ("prog", "rst", "rst_rows"):      # files libjpeg reads and the device decoder does not: said out loud
         if k in extra:
             assert _gpu_decode(lib, hip, extra[k], device)[0] == hip.ERROR_UNSUPPORTED_FEATURE, k
+    if "s444" in extra:                          # 4:4:4: the reference's decompressImage fails as well (jpegdecoderhelper.cpp:283-289)
+        assert _gpu_decode(lib, hip, extra["s444"], device)[0] == hip.UNKNOWN_ERROR
 
 
 def test_decoder_rejects_malformed_input(hip, orc):

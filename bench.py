@@ -221,6 +221,32 @@ def other_configs(lib, stream):
     ms = (time.perf_counter() - t0) / 10 * 1e3
     out["JPEG decode 4K YUV420 q95 (the file encoded above; host bytes in, device planes out)"] = {
         "ms": round(ms, 3), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1), "jpeg_bytes": int(jbytes.size)}
+    # the whole codec calls -- encodeJPEGR API-1 / API-0 (device planes in, JPEG/R file on the host out) and
+    # decodeJPEGR (host file in, device HDR rendition out), 4K and BASELINE configs[0]'s 640x480
+    for cw, ch in ((W, H), (640, 480)):
+        cp, cy = (sm if (cw, ch) == (W, H) and sm is not None else synth.smooth_frame(cw, ch, 78))
+        cpi, cyi = api.p010_image(cp.data_ptr(), cw, ch, api.CG_BT2100), api.yuv420_image(cy.data_ptr(), cw, ch, api.CG_BT709)
+        fbuf, fn_ = np.zeros(cw * ch * 3, np.uint8), C.c_size_t()
+
+        def wall(fn, iters=10):
+            for _ in range(3):
+                assert fn() == 0
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            return (time.perf_counter() - t0) / iters * 1e3
+        t_api0 = wall(lambda: lib.uhdr_hip_jpegr_encode_api0(C.byref(cpi), api.TF_HLG, 95, None, 0, C.c_void_p(fbuf.ctypes.data), fbuf.size, C.byref(fn_),
+                                                              api.MEM_DEVICE, stream))
+        t_api1 = wall(lambda: lib.uhdr_hip_jpegr_encode_api1(C.byref(cpi), C.byref(cyi), api.TF_HLG, 95, None, 0, C.c_void_p(fbuf.ctypes.data), fbuf.size,
+                                                              C.byref(fn_), api.MEM_DEVICE, stream))
+        fbytes = fbuf[:fn_.value].copy()
+        rend = torch.zeros(cw * ch * 4, dtype=torch.uint8, device="cuda")
+        rdesc, rmd = api.Image(), api.Metadata()
+        t_dec = wall(lambda: lib.uhdr_hip_jpegr_decode(C.c_void_p(fbytes.ctypes.data), fbytes.size, api.OUTPUT_HDR_HLG, api.FLT_MAX, C.c_void_p(rend.data_ptr()),
+                                                       rend.numel(), C.byref(rdesc), C.byref(rmd), api.APPLY_FAST, api.MEM_DEVICE, stream))
+        out["JPEG/R %dx%d HLG q95: encodeJPEGR API-0 / API-1, decodeJPEGR -> RGBA1010102 (wall clock per call)" % (cw, ch)] = {
+            "encode_api0_ms": round(t_api0, 3), "encode_api1_ms": round(t_api1, 3), "decode_ms": round(t_dec, 3), "file_bytes": int(fbytes.size),
+            "encode_api1_MPix/s": round(cw * ch / 1e6 / (t_api1 * 1e-3), 1), "decode_MPix/s": round(cw * ch / 1e6 / (t_dec * 1e-3), 1)}
     # configs[4]: 7680x4320 decode-side apply
     w8, h8 = 7680, 4320
     _, y8 = synth.lcg_frame(w8, h8, 1234)
@@ -299,8 +325,35 @@ def cpu_baseline(batch, fmt, nframes):
         same_dec = rc == 0 and dst > 0 and np.array_equal(gp.cpu().numpy(), dplanes)
         jpeg = {"libjpeg_4k_yuv420_q95_ms": round(t_cpu * 1e3, 2), "MPix/s": round(mpix / t_cpu, 1), "bytes": len(data), "threads": 1,
                 "gpu_bytes_identical": bool(same), "libjpeg_decode_ms": round(t_dec * 1e3, 2), "gpu_decoded_planes_identical": bool(same_dec)}
+    # ... and the whole encodeJPEGR API-1 call on the CPU: the restatement of oracle/jpegr_oracle.py (gain map on all cores, convertYuv,
+    # both JPEG compressions single-threaded as in the reference, container) on the same 4K frame pair; files cross-checked
+    jpegr = None
+    try:
+        from oracle import jpegr_oracle as J
+        smp, smy = synth.smooth_frame(W, H, 77)
+        hp, hy = smp.cpu().numpy().view(np.uint16), smy.cpu().numpy()
+        t0 = time.perf_counter()
+        want = J.encode_api1(hp, hy, W, H, O.CG_BT709, O.CG_BT2100, O.TF_HLG, 95, threads=ncpu)
+        t_enc = time.perf_counter() - t0
+        fbuf, fn_ = np.zeros(W * H * 3, np.uint8), C.c_size_t()
+        cpi, cyi = api.p010_image(smp.data_ptr(), W, H, api.CG_BT2100), api.yuv420_image(smy.data_ptr(), W, H, api.CG_BT709)
+        rc = batch.lib.uhdr_hip_jpegr_encode_api1(C.byref(cpi), C.byref(cyi), api.TF_HLG, 95, None, 0, C.c_void_p(fbuf.ctypes.data), fbuf.size, C.byref(fn_),
+                                                  api.MEM_DEVICE, None)
+        t0 = time.perf_counter()
+        dst, dref, _, _, _, _ = J.decode(want, O.OUT_HDR_HLG, api.FLT_MAX, threads=ncpu)
+        t_dec = time.perf_counter() - t0
+        rend = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
+        rdesc, rmd = api.Image(), api.Metadata()
+        wb = np.frombuffer(want, np.uint8)
+        rc2 = batch.lib.uhdr_hip_jpegr_decode(C.c_void_p(wb.ctypes.data), wb.size, api.OUTPUT_HDR_HLG, api.FLT_MAX, C.c_void_p(rend.data_ptr()), rend.numel(),
+                                              C.byref(rdesc), C.byref(rmd), api.APPLY_EXACT, api.MEM_DEVICE, None)
+        jpegr = {"encode_api1_4k_cpu_ms": round(t_enc * 1e3, 1), "decode_4k_cpu_ms": round(t_dec * 1e3, 1), "file_bytes": len(want),
+                 "gpu_file_identical": bool(rc == 0 and fbuf[:fn_.value].tobytes() == want),
+                 "gpu_decoded_rendition_identical (EXACT mode)": bool(rc2 == 0 and dst == 0 and np.array_equal(rend.cpu().numpy(), dref))}
+    except OSError:
+        pass
     return {
-        "jpeg_encode_cpu": jpeg,
+        "jpeg_encode_cpu": jpeg, "jpegr_codec_cpu": jpegr,
         "value": round(nframes * mpix / (t_gen + t_app), 3), "unit": "MPix/s", "cores": ncpu, "kind": "port",
         "sample": "%d of the batch's 4K frames, generate+apply(%s), oracle/uhdr_oracle.c -O2 -ffp-contract=off, "
                   "%d row-band threads" % (nframes, "HLG" if fmt == api.OUTPUT_HDR_HLG else "PQ", ncpu),

@@ -444,8 +444,24 @@ int uhdr_hip_init(int device) {
     build_idw_tables(4, t);
     HIP_TRY(upload_idw4(t.data()));
     // the reference fills its LUTs at static-initialisation time (gainmapmath.cpp:21-64); here: once per device
-    HIP_TRY(hipMalloc(&st.lut, sizeof(float) * kLutTotal));
+    HIP_TRY(hipMalloc(&st.lut, sizeof(float) * kLutBufferFloats));
     HIP_TRY(launch_build_luts(st.lut, nullptr));
+    {
+      // FAST apply's sRGB EOTF (gainmapmath.cpp:149-155) as line segments: cell j holds the x with round(x * 32767) >> 3 == j,
+      // i.e. [(8j - 0.5) / 32767, (8j + 7.5) / 32767); the chord, lowered by half its largest deviation (the function is convex
+      // on a cell but for the one holding the junction), evaluated as c0 + c1 * x
+      std::vector<float> line(2 * kSrgbLineCells);
+      auto f = [](double x) { return x <= (double)0.04045f ? x / (double)12.92f : std::pow((x + (double)0.055f) / (double)1.055f, 2.4); };
+      for (uint32_t j = 0; j < kSrgbLineCells; ++j) {
+        const double lo = std::max(0.0, (8.0 * j - 0.5) / 32767.0), hi = std::min(1.0, (8.0 * j + 7.5) / 32767.0);
+        const double c1 = (f(hi) - f(lo)) / (hi - lo);
+        double c0 = f(lo) - c1 * lo, dev = 0.0;
+        for (int k = 1; k < 16; ++k) { const double x = lo + (hi - lo) * k / 16.0; const double d = f(x) - (c0 + c1 * x); if (std::fabs(d) > std::fabs(dev)) dev = d; }
+        c0 += 0.5 * dev;
+        line[2 * j] = (float)c0; line[2 * j + 1] = (float)c1;
+      }
+      HIP_TRY(hipMemcpy(st.lut + kSrgbLine, line.data(), line.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(jpeg::upload_tables());
     st.ready = true;
@@ -1233,6 +1249,7 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
     if ((rc = idw_for_scale(st, scale, &idw)) != UHDR_HIP_NO_ERROR) return rc;
     AppConsts c = apply_consts(y0, m0, *metadata, max_display_boost, idw);
     c.lut = apply_mode == UHDR_HIP_APPLY_LUT ? st->lut : nullptr;
+    c.srgb_line = st->lut + kSrgbLine;
     AppBatch b;
     int m = 0;
     bool fast = true;

@@ -12,6 +12,9 @@ constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4
 constexpr uint32_t kLutSrgbInvN = 1024, kLutHlgInvN = 4096, kLutPqInvN = 4096, kLutHlgN = 65536, kLutPqN = 65536;
 constexpr uint32_t kLutSrgbInv = 0, kLutHlgInv = kLutSrgbInv + kLutSrgbInvN, kLutPqInv = kLutHlgInv + kLutHlgInvN,
                    kLutHlg = kLutPqInv + kLutPqInvN, kLutPq = kLutHlg + kLutHlgN, kLutTotal = kLutPq + kLutPqN;
+// FAST apply only (not one of the reference's tables): the sRGB EOTF as 4096 line segments (c0, c1), cell = round(x * 32767) >> 3,
+// appended to the LUT buffer by uhdr_hip_init (see k_apply_s4)
+constexpr uint32_t kSrgbLineCells = 4096, kSrgbLine = kLutTotal, kLutBufferFloats = kLutTotal + 2 * kSrgbLineCells;
 constexpr uint32_t kGainLutN = 1024;  // kGainFactorNumEntries, gainmapmath.h:149-150
 
 // ---- generate ----------------------------------------------------------------------------------
@@ -65,6 +68,7 @@ struct AppConsts {
   double log2_min_d, log2_max_d;  // log2((double)minContentBoost), log2((double)maxContentBoost)
   const float* idw;               // device: 4 tables (std, NR, NB, C) of scale*scale*4 floats
   const float* lut;               // device LUT buffer (LUT mode only)
+  const float* srgb_line;         // device: kSrgbLineCells x (c0, c1), FAST scale-4 kernel
   float lut_boost_factor;         // GainLUT(metadata, displayBoost): displayBoost > 0 ? displayBoost / max : 1 (gainmapmath.h:162)
   AppFast fast;
 };

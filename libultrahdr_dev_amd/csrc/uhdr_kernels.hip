@@ -68,6 +68,15 @@ __device__ __forceinline__ f2 pk_fma_sat(f2 a, f2 b, f2 c) {
   return r;
 }
 
+// a * b + (c.lo, c.lo) or (c.hi, c.hi), clamped: VOP3P's op_sel broadcasts one half of the third operand for free
+template <int HI>
+__device__ __forceinline__ f2 pk_fma_sat_bc(f2 a, f2 b, f2 c) {
+  f2 r;
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0] clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 #ifdef UHDR_GEN_COUNT   // instrumentation build only (scripts/dbg_filter_rate.py): how often do waves leave the fast path?
 __device__ unsigned long long g_gen_count[4];   // wave-tiles, wave-tiles on the exact path, exact statistics passes, doubtful pixels
 extern "C" hipError_t uhdr_hip_debug_counters(unsigned long long* out, int reset) {
@@ -769,6 +778,32 @@ __device__ __forceinline__ f2 srgb_eotf2(f2 e) {
   return pk_fma(x * x, t, lin);
 }
 
+// The same two values from the line-segment table in LDS (AppConsts::srgb_line): the EOTF's log2 + exp2 per value is half of
+// this kernel's special-function issue, and the LDS pipe is otherwise idle.  v_cvt_pknorm_i16_f32 turns BOTH clamped inputs into
+// round(x * 32767) in one issue slot; bits 14..3 of each half are the cell and, as they stand, the byte offset of its (c0, c1)
+// pair: one v_and each (the upper half through SDWA's WORD_1 select), one ds_read_b64 and one fma per value.
+// |error| <= 2e-8 absolute (cell width 2^-12, f'' <= 2.3): below the f32 rounding of the result.
+#ifndef UHDR_APPLY_SRGB_LDS
+#define UHDR_APPLY_SRGB_LDS 1
+#endif
+#ifndef UHDR_APPLY_CELLS
+#define UHDR_APPLY_CELLS (UHDR_APPLY_SRGB_LDS ? 8 : 1)
+#endif
+__device__ __forceinline__ f2 srgb_eotf2_lds(f2 e, const char* lut) {
+  typedef short s2 __attribute__((ext_vector_type(2)));
+  const s2 q = __builtin_amdgcn_cvt_pknorm_i16(e.x, e.y);
+  const uint32_t d = __builtin_bit_cast(uint32_t, q);
+  uint32_t hi_off;
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(hi_off) : "v"(0x7FF8u), "v"(d));
+  const float2 a = *reinterpret_cast<const float2*>(lut + (d & 0x7FF8u));
+  const float2 b = *reinterpret_cast<const float2*>(lut + hi_off);
+  // two plain fmas on purpose (asm: the vectoriser would re-pack them behind three v_movs that shuffle the operands into pairs)
+  f2 o;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.x) : "v"(a.y), "v"(e.x), "v"(a.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.y) : "v"(b.y), "v"(e.y), "v"(b.x));
+  return o;
+}
+
 // OETF of two linear values, scaled to 10-bit code units where the format is 10 bit.  UNBOUNDED: the inputs
 // may exceed 1.0 (max_display_boost < maxContentBoost), so max(e, j) - j cannot be had from a [0,1] clamp and
 // the HLG junction is selected per lane instead.
@@ -808,24 +843,30 @@ __device__ __forceinline__ f2 hlg_oetf2_of_product(f2 lin, f2 factor, f2 factor1
 
 struct PairOut { f2 r, g, b; };
 
-// two horizontally adjacent pixels sharing one chroma sample
-template <int FMT, bool UNBOUNDED>
-__device__ __forceinline__ PairOut apply_pair(f2 yf, float crv, float gsum, float cbu, f2 E) {
-  // p3YuvToRgb (gainmapmath.cpp:198-202); the clamp rides on the packed add
-  const f2 r = pk_add_sat(yf, splat(crv));
-  const f2 g = pk_add_sat(yf, splat(-gsum));
-  const f2 b = pk_add_sat(yf, splat(cbu));
+// two horizontally adjacent pixels sharing one chroma sample.  yraw: the two luma bytes as floats; crv2 / ngs2 / cbu2: the chroma
+// terms of this and the neighbouring pair, of which half HI is ours
+template <int FMT, bool UNBOUNDED, int HI>
+__device__ __forceinline__ PairOut apply_pair(f2 yraw, f2 crv2, f2 ngs2, f2 cbu2, f2 E, const char* lut) {
+  // p3YuvToRgb (gainmapmath.cpp:198-202): y / 255 + chroma term in one packed fma, the clamp rides on it
+  const f2 r = pk_fma_sat_bc<HI>(yraw, splat(k255), crv2);
+  const f2 g = pk_fma_sat_bc<HI>(yraw, splat(k255), ngs2);
+  const f2 b = pk_fma_sat_bc<HI>(yraw, splat(k255), cbu2);
   const f2 factor = exp2_2(E);  // applyGain's 2^(logBoost*displayBoost/max) / displayBoost
+#if UHDR_APPLY_SRGB_LDS
+  const f2 lr = srgb_eotf2_lds(r, lut), lg = srgb_eotf2_lds(g, lut), lb = srgb_eotf2_lds(b, lut);
+#else
+  const f2 lr = srgb_eotf2(r), lg = srgb_eotf2(g), lb = srgb_eotf2(b);
+#endif
   PairOut o;
   if (FMT == 3 && !UNBOUNDED) {
     const f2 factor12 = factor * splat(12.0f);
-    o.r = hlg_oetf2_of_product(srgb_eotf2(r), factor, factor12);
-    o.g = hlg_oetf2_of_product(srgb_eotf2(g), factor, factor12);
-    o.b = hlg_oetf2_of_product(srgb_eotf2(b), factor, factor12);
+    o.r = hlg_oetf2_of_product(lr, factor, factor12);
+    o.g = hlg_oetf2_of_product(lg, factor, factor12);
+    o.b = hlg_oetf2_of_product(lb, factor, factor12);
   } else {
-    o.r = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(r) * factor);
-    o.g = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(g) * factor);
-    o.b = oetf2_scaled<FMT, UNBOUNDED>(srgb_eotf2(b) * factor);
+    o.r = oetf2_scaled<FMT, UNBOUNDED>(lr * factor);
+    o.g = oetf2_scaled<FMT, UNBOUNDED>(lg * factor);
+    o.b = oetf2_scaled<FMT, UNBOUNDED>(lb * factor);
   }
   return o;
 }
@@ -846,18 +887,19 @@ __device__ __forceinline__ uint32_t pack10_scaled(float r, float g, float b) {
 template <int FMT, bool INTERIOR, bool MASK>
 __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
                                            const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
-                                           float e1, float e2, float e3, float e4, int tbl) {
-  float crv[2][2], gsum[2][2], cbu[2][2];
+                                           float e1, float e2, float e3, float e4, int tbl, const char* lut) {
+  // chroma terms of the cell's 2x2 samples, one packed register per row of two: kCr * (V - 128) / 255 etc. as one fma each on the
+  // byte values (constants pre-multiplied; within an ulp of the reference's two-step rounding, which FAST mode does not promise)
+  constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
+  f2 crv2[2], ngs2[2], cbu2[2];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const float u = (float)((int)((uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
-      const float v = (float)((int)((vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
-      crv[r][k] = kP3Cr * v;
-      gsum[r][k] = __builtin_fmaf(kP3GCb, u, kP3GCr * v);
-      cbu[r][k] = kP3Cb * u;
-    }
+  for (int r = 0; r < 2; ++r) {
+    const f2 uf = (f2){(float)(uu[r] & 0xffu), (float)((uu[r] >> 8) & 0xffu)};
+    const f2 vf = (f2){(float)(vv[r] & 0xffu), (float)((vv[r] >> 8) & 0xffu)};
+    crv2[r] = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
+    cbu2[r] = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
+    ngs2[r] = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
+  }
   const float* wt = c_idw4 + tbl * 64;  // border cells only: per-lane table (gainmapmath.cpp:710-716)
 #pragma unroll
   for (int oy = 0; oy < 4; ++oy) {
@@ -874,9 +916,9 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
         w2 = (f2){p0[2], p0[6]} * splat(c.fast.A); w3 = (f2){p0[3], p0[7]} * splat(c.fast.A);
       }
       const f2 E = pk_fma(splat(e4), w3, pk_fma(splat(e3), w2, pk_fma(splat(e2), w1, pk_fma(splat(e1), w0, splat(c.fast.B)))));
-      const uint32_t yw = yrow[oy] >> (16 * pr);
-      const f2 yf = (f2){(float)(yw & 0xffu), (float)((yw >> 8) & 0xffu)} * splat(k255);
-      po[pr] = apply_pair<FMT, MASK>(yf, crv[oy >> 1][pr], gsum[oy >> 1][pr], cbu[oy >> 1][pr], E);
+      const f2 yraw = pr ? (f2){(float)((yrow[oy] >> 16) & 0xffu), (float)(yrow[oy] >> 24)} : (f2){(float)(yrow[oy] & 0xffu), (float)((yrow[oy] >> 8) & 0xffu)};
+      po[pr] = pr ? apply_pair<FMT, MASK, 1>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, lut)
+                  : apply_pair<FMT, MASK, 0>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, lut);
     }
     const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
     if (FMT == 2 || FMT == 3) {
@@ -904,11 +946,31 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
   }
 }
 
+// Each block copies the 32 KiB line-segment table into LDS once and then walks kApplyCellsPerThread cells per thread.
+constexpr uint32_t kApplyCellsPerThread = UHDR_APPLY_CELLS;
+#ifndef UHDR_APPLY_MIN_BLOCKS
+#define UHDR_APPLY_MIN_BLOCKS 4
+#endif
 template <int FMT, bool MASK>
-__global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBatch b) {
+__global__ void __launch_bounds__(256, UHDR_APPLY_MIN_BLOCKS) k_apply_s4(const AppConsts c, const AppBatch b) {
+#if UHDR_APPLY_SRGB_LDS
+  __shared__ float2 s_line[kSrgbLineCells];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(c.srgb_line);
+    uint4* dst = reinterpret_cast<uint4*>(s_line);
+#pragma unroll
+    for (uint32_t k = 0; k < kSrgbLineCells / 2u / 256u; ++k) dst[k * 256u + threadIdx.x] = src[k * 256u + threadIdx.x];
+  }
+  __syncthreads();
+  const char* lut = reinterpret_cast<const char*>(s_line);
+#else
+  const char* lut = nullptr;
+#endif
   const AppImage& im = b.img[blockIdx.y];
   const uint32_t total = c.map_w * c.map_h;
-  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll 1
+  for (uint32_t it = 0; it < kApplyCellsPerThread; ++it) {
+  const uint32_t idx = (blockIdx.x * kApplyCellsPerThread + it) * 256u + threadIdx.x;
   if (idx >= total) return;
   const uint32_t cy = idx / c.map_w;
   const uint32_t cx = idx - cy * c.map_w;
@@ -936,10 +998,11 @@ __global__ void __launch_bounds__(256) k_apply_s4(const AppConsts c, const AppBa
   const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
   // all waves but those touching the last column/row of cells take the SGPR-weight path
   if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) {
-    if (MASK) apply_cell<FMT, true, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0);
-    else apply_cell<FMT, true, false>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0);
+    if (MASK) apply_cell<FMT, true, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0, lut);
+    else apply_cell<FMT, true, false>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0, lut);
   } else {
-    apply_cell<FMT, false, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, tbl);
+    apply_cell<FMT, false, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, tbl, lut);
+  }
   }
 }
 
@@ -1069,8 +1132,9 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     const uint32_t total = c.map_w * c.map_h;
     // channels can only reach 1024 (and wrap through the reference's & 0x3ff) when the display boost is
     // capped below the content boost
-    if (c.display_boost < c.max_boost) hipLaunchKernelGGL((k_apply_s4<FMT, true>), dim3((total + 255u) / 256u, n), dim3(256), 0, s, c, b);
-    else hipLaunchKernelGGL((k_apply_s4<FMT, false>), dim3((total + 255u) / 256u, n), dim3(256), 0, s, c, b);
+    const uint32_t per_block = 256u * kApplyCellsPerThread;
+    if (c.display_boost < c.max_boost) hipLaunchKernelGGL((k_apply_s4<FMT, true>), dim3((total + per_block - 1u) / per_block, n), dim3(256), 0, s, c, b);
+    else hipLaunchKernelGGL((k_apply_s4<FMT, false>), dim3((total + per_block - 1u) / per_block, n), dim3(256), 0, s, c, b);
   } else {
     const size_t total = (size_t)c.width * c.height;
     const dim3 grid((unsigned)((total + 255u) / 256u), n);

@@ -15,6 +15,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLT_MAX = 3.4028234663852886e38
 SAMPLE = os.path.join(ROOT, "tests", "golden", "sample_jpegr.jpeg")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def _xmp_segment(attrs):
@@ -463,3 +464,81 @@ def test_host_parsers_survive_mutated_files_under_asan(orc, tmp_path):
                            os.path.join(csrc, "uhdr_jpeg_hdr.cpp"), "-o", exe])
     r = subprocess.run([exe, SAMPLE] + seeds + ["60000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def _strided_p010(p010, w, h, ls, cs, separate):
+    """the fixture re-laid with luma stride ls and chroma stride cs (elements); separate: chroma in its own buffer (the reference's
+    UhdrUnCompressedStructWrapper::setChromaMode(false), tests/jpegr_test.cpp:190-230)"""
+    y = np.full(ls * h, 0xABCD, np.uint16)
+    y.reshape(h, ls)[:, :w] = p010[:w * h].reshape(h, w)
+    c = np.full(cs * (h // 2), 0xABCD, np.uint16)
+    c.reshape(h // 2, cs)[:, :w] = p010[w * h:].reshape(h // 2, w)
+    return (y, c) if separate else (np.concatenate([y, c]), None)
+
+
+def _strided_yuv(yuv, w, h, ls, cs, separate):
+    y = np.full(ls * h, 0x5A, np.uint8)
+    y.reshape(h, ls)[:, :w] = yuv[:w * h].reshape(h, w)
+    cw, ch = w // 2, h // 2
+    c = np.full(cs * ch * 2, 0x5A, np.uint8)
+    c[:cs * ch].reshape(ch, cs)[:, :cw] = yuv[w * h:w * h + cw * ch].reshape(ch, cw)
+    c[cs * ch:].reshape(ch, cs)[:, :cw] = yuv[w * h + cw * ch:].reshape(ch, cw)
+    return (y, c) if separate else (np.concatenate([y, c]), None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p010_gamut", [0, 1, 2])
+@pytest.mark.parametrize("sdr_gamut", [0, 1, 2])
+def test_gpu_encode_is_invariant_to_strides_and_chroma_pointers(hip, orc, p010_gamut, sdr_gamut):
+    """the reference's JpegRAPIEncodeAndDecodeTest (tests/jpegr_test.cpp:1434-1801): the 1280x720 fixture pair over the 3x3 gamut
+    combinations through API-0 and API-1, re-laid with the luma / chroma strides and separate chroma buffers that test uses; every
+    variant must give the file of the packed layout (the reference's memcmp), and that file is the CPU restatement's"""
+    from oracle import jpegr_oracle as J
+    w, h, q = 1280, 720, 90
+    p010 = np.fromfile(os.path.join(GOLDEN, "raw_p010_image.p010"), np.uint16)
+    yuv = np.fromfile(os.path.join(GOLDEN, "raw_yuv420_image.yuv420"), np.uint8)
+    lib = hip.load()
+
+    def p_img(ls, cs, separate, give_cs=True):
+        a, c = _strided_p010(p010, w, h, ls or w, (cs or ls or w) if separate else (ls or w), separate)
+        im = hip.p010_image(a.ctypes.data, w, h, p010_gamut)
+        im.luma_stride, im.chroma_stride = ls, cs if give_cs else 0
+        im.chroma_data = c.ctypes.data if separate else None
+        return im, (a, c)
+
+    def y_img(ls, cs, separate):
+        a, c = _strided_yuv(yuv, w, h, ls or w, (cs or (ls or w) // 2) if separate else (ls or w) // 2, separate)
+        im = hip.yuv420_image(a.ctypes.data, w, h, sdr_gamut)
+        im.luma_stride, im.chroma_stride = ls, cs
+        im.chroma_data = c.ctypes.data if separate else None
+        return im, (a, c)
+
+    out, n = np.zeros(w * h * 3, np.uint8), C.c_size_t()
+
+    def api0(pi):
+        rc = lib.uhdr_hip_jpegr_encode_api0(C.byref(pi[0]), hip.TF_HLG, q, None, 0, C.c_void_p(out.ctypes.data), out.size, C.byref(n), hip.MEM_HOST, None)
+        assert rc == 0
+        return out[:n.value].tobytes()
+
+    def api1(pi, yi):
+        rc = lib.uhdr_hip_jpegr_encode_api1(C.byref(pi[0]), C.byref(yi[0]), hip.TF_HLG, q, None, 0, C.c_void_p(out.ctypes.data), out.size, C.byref(n), hip.MEM_HOST, None)
+        assert rc == 0
+        return out[:n.value].tobytes()
+
+    # the P010 layouts of EncodeAPI0AndDecodeTest (:1485-1582): luma stride; luma + chroma strides with a chroma pointer; chroma stride
+    # alone with a chroma pointer; both strides but no chroma pointer (the chroma stride is then ignored, jpegr.cpp:265-270)
+    p_layouts = [(0, 0, False), (w + 18, 0, False), (w + 18, w + 28, True), (0, w + 34, True), (w, w + 38, False)]
+    base0 = api0(p_img(*p_layouts[0]))
+    assert base0 == J.encode_api0(p010, w, h, p010_gamut, hip.TF_HLG, q)
+    for lay in p_layouts[1:]:
+        assert api0(p_img(*lay)) == base0, lay
+    # EncodeAPI1AndDecodeTest (:1611-1801): the same on either input
+    y_layouts = [(0, 0, False), (w + 14, 0, False), (w + 46, w // 2 + 34, True), (0, w // 2 + 38, True), (w + 26, 0, True)]
+    base1 = api1(p_img(*p_layouts[0]), y_img(*y_layouts[0]))
+    assert base1 == J.encode_api1(p010, yuv, w, h, sdr_gamut, p010_gamut, hip.TF_HLG, q)
+    for lay in p_layouts[1:]:
+        assert api1(p_img(*lay), y_img(*y_layouts[0])) == base1, ("p010", lay)
+    for lay in y_layouts[1:]:
+        if lay[2] and lay[1] == 0:
+            continue                   # a chroma pointer with chroma_stride 0 fails validation (:150-155): not a layout
+        assert api1(p_img(*p_layouts[0]), y_img(*lay)) == base1, ("yuv", lay)

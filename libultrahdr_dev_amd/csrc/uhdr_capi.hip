@@ -1007,15 +1007,15 @@ int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_in, const void* sdr_
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   uhdr_hip_image_t p010 = *p010_in;
   default_p010(&p010);
-  EncodeCtx c{nullptr, stream, mem_space};
-  if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
   const uint8_t* pj = static_cast<const uint8_t*>(sdr_jpeg);
 
-  // :457-462 decode; a header probe first for the size
+  // :457-462 decode; a header probe first for the size (host work: an unreadable file is reported without a device)
   uhdr_hip_image_t ydesc;
   rc = uhdr_hip_jpeg_decode(pj, sdr_jpeg_size, nullptr, 0, &ydesc, UHDR_HIP_MEM_DEVICE, stream);
   if (rc == UHDR_HIP_ERROR_UNSUPPORTED_FEATURE) return rc;
   if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE || ydesc.pixelFormat != UHDR_HIP_PIX_FMT_YUV420) return UHDR_HIP_ERROR_DECODE_ERROR;
+  EncodeCtx c{nullptr, stream, mem_space};
+  if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
   const size_t w = ydesc.width, h = ydesc.height, ybytes = w * h + 2 * (w * h / 4);
   uhdr_hip_metadata_t md;
   std::vector<uint8_t> gm_jpeg;

@@ -542,3 +542,94 @@ def test_gpu_encode_is_invariant_to_strides_and_chroma_pointers(hip, orc, p010_g
         if lay[2] and lay[1] == 0:
             continue                   # a chroma pointer with chroma_stride 0 fails validation (:150-155): not a layout
         assert api1(p_img(*p_layouts[0]), y_img(*lay)) == base1, ("yuv", lay)
+
+
+def test_invalid_argument_matrices_need_no_gpu():
+    """the reference's EncodeAPI0..4WithInvalidArgs / DecodeAPIWithInvalidArgs (tests/jpegr_test.cpp:386-1399; it only asserts != NO_ERROR,
+    here the status each check returns, read off areInputArgumentsValid jpegr.cpp:75-183 and the overloads).  All of these are
+    decided on the host before the device is looked at, so they run in the CPU suite."""
+    from libultrahdr_dev_amd import api
+    lib = api.load()
+    W, H = 32, 32
+    p010 = np.zeros(W * H * 3 // 2 + 4096, np.uint16)
+    yuv = np.zeros(W * H * 3 // 2 + 4096, np.uint8)
+    out, n = np.zeros(1 << 16, np.uint8), C.c_size_t()
+    O = (C.c_void_p(out.ctypes.data), out.size, C.byref(n))
+
+    def P(w=W, h=H, g=api.CG_BT2100, **kw):
+        return api.p010_image(p010.ctypes.data, w, h, g, **kw)
+
+    def Y(w=W, h=H, g=api.CG_BT709, **kw):
+        return api.yuv420_image(yuv.ctypes.data, w, h, g, **kw)
+    jpg = np.frombuffer(b"\xff\xd8\xff\xd9" + bytes(60), np.uint8)
+    J = (C.c_void_p(jpg.ctypes.data), jpg.size)
+    bad_dims = [P(W - 1), P(W, H - 1), P(0), P(W, 0), P(4, 4), P(8194, H), P(W, 8194)]
+    bad_gamut = [P(g=api.CG_UNSPECIFIED), P(g=3)]
+    bad_stride = [P(luma_stride=W - 2), P(luma_stride=W + 64, chroma_stride=W - 2, chroma_ptr=p010.ctypes.data)]
+    bad_tf = [api.TF_SRGB, -1, 4]
+
+    # API-0 (:386-537)
+    a0 = lambda p, tf=api.TF_HLG, q=90, o=O: lib.uhdr_hip_jpegr_encode_api0(None if p is None else C.byref(p), tf, q, None, 0, *o, api.MEM_HOST, None)
+    assert a0(P(), q=-1) == a0(P(), q=101) == api.ERROR_INVALID_QUALITY_FACTOR
+    nodata_p, nodata_y = P(), Y()
+    nodata_p.data = None
+    nodata_y.data = None
+    assert a0(None) == api.ERROR_BAD_PTR == a0(nodata_p)
+    assert all(a0(p) == api.ERROR_UNSUPPORTED_WIDTH_HEIGHT for p in bad_dims)
+    assert all(a0(p) == api.ERROR_INVALID_COLORGAMUT for p in bad_gamut)
+    assert all(a0(p) == api.ERROR_INVALID_STRIDE for p in bad_stride)
+    assert a0(P(), o=(None, 0, C.byref(n))) == api.ERROR_BAD_PTR
+    assert all(a0(P(), tf=t) == api.ERROR_INVALID_TRANS_FUNC for t in bad_tf)
+    assert lib.uhdr_hip_jpegr_encode_api0(C.byref(P()), api.TF_HLG, 90, None, 8, *O, api.MEM_HOST, None) == api.ERROR_BAD_PTR      # exif struct without data
+
+    # API-2 (:814-1099) and API-3 (:1101-1265)
+    a2 = lambda p, y, j=J, tf=api.TF_HLG, o=O: lib.uhdr_hip_jpegr_encode_api2(None if p is None else C.byref(p), None if y is None else C.byref(y), *j, api.CG_BT709,
+                                                                               tf, *o, api.MEM_HOST, None)
+    a3 = lambda p, j=J, tf=api.TF_HLG, o=O: lib.uhdr_hip_jpegr_encode_api3(None if p is None else C.byref(p), *j, api.CG_BT709, tf, *o, api.MEM_HOST, None)
+    assert a2(P(), None) == a2(P(), Y(), j=(None, 0)) == a2(None, Y()) == api.ERROR_BAD_PTR == a3(None) == a3(P(), j=(None, 0))
+    for p in bad_dims:
+        assert a2(p, Y()) == a3(p) == api.ERROR_UNSUPPORTED_WIDTH_HEIGHT
+    for p in bad_gamut:
+        assert a2(p, Y()) == a3(p) == api.ERROR_INVALID_COLORGAMUT
+    for p in bad_stride:
+        assert a2(p, Y()) == a3(p) == api.ERROR_INVALID_STRIDE
+    for t in bad_tf:
+        assert a2(P(), Y(), tf=t) == a3(P(), tf=t) == api.ERROR_INVALID_TRANS_FUNC
+    assert a2(P(), Y(), o=(None, 0, C.byref(n))) == a3(P(), o=(None, 0, C.byref(n))) == api.ERROR_BAD_PTR
+    assert a2(P(), nodata_y) == api.ERROR_BAD_PTR
+    assert a2(P(), Y(luma_stride=W - 2)) == a2(P(), Y(chroma_stride=W // 2 - 2, chroma_ptr=yuv.ctypes.data)) == api.ERROR_INVALID_STRIDE
+    assert a2(P(), Y(W + 2)) == a2(P(), Y(W, H + 2)) == api.ERROR_RESOLUTION_MISMATCH
+    assert a2(P(), Y(g=api.CG_UNSPECIFIED)) == a2(P(), Y(g=3)) == api.ERROR_INVALID_COLORGAMUT
+    assert a3(P()) == api.ERROR_DECODE_ERROR                                     # "\xff\xd8\xff\xd9": no image in it
+
+    # API-4 (:1267-1360)
+    md = api.metadata(4.0)
+    a4 = lambda j=J, g=J, m=md, o=O: lib.uhdr_hip_jpegr_encode_api4(*j, api.CG_BT709, *g, None if m is None else C.byref(m), *o)
+    assert a4(j=(None, 0)) == a4(g=(None, 0)) == a4(o=(None, 0, C.byref(n))) == api.ERROR_BAD_PTR
+    assert a4() == api.ERROR_DECODE_ERROR
+    _, primary, gainmap = _sample_streams()
+    pj, gj = np.frombuffer(primary, np.uint8), np.frombuffer(gainmap, np.uint8)
+    PJ, GJ = (C.c_void_p(pj.ctypes.data), pj.size), (C.c_void_p(gj.ctypes.data), gj.size)
+    big = np.zeros(1 << 17, np.uint8)
+    BO = (C.c_void_p(big.ctypes.data), big.size, C.byref(n))
+    assert a4(PJ, GJ, md, BO) == 0 and a4(PJ, GJ, None, BO) == api.ERROR_BAD_PTR
+    for field, val in (("version", b"1.1"), ("maxContentBoost", 0.5), ("hdrCapacityMax", 0.5), ("hdrCapacityMin", 0.5), ("offsetSdr", -1.0), ("offsetHdr", -1.0),
+                       ("gamma", 0.0), ("gamma", -1.0)):
+        bad = api.metadata(4.0)
+        setattr(bad, field, val)
+        assert a4(PJ, GJ, bad, BO) == api.ERROR_BAD_METADATA, field
+
+    # decodeJPEGR (:1362-1399): nothing below reaches the device either
+    data = np.fromfile(SAMPLE, np.uint8)
+    dest, dmd = api.Image(), api.Metadata()
+    dec = lambda buf=data, fmt=api.OUTPUT_HDR_LINEAR, boost=api.FLT_MAX, d=dest: lib.uhdr_hip_jpegr_decode(
+        None if buf is None else C.c_void_p(buf.ctypes.data), 0 if buf is None else buf.size, fmt, boost, None, 0, None if d is None else C.byref(d), C.byref(dmd),
+        api.APPLY_FAST, api.MEM_HOST, None)
+    assert dec(buf=None) == dec(d=None) == api.ERROR_BAD_PTR
+    assert dec(boost=0.5) == api.ERROR_INVALID_DISPLAY_BOOST
+    assert dec(fmt=-1) == dec(fmt=5) == api.ERROR_INVALID_OUTPUT_FORMAT
+    assert dec(buf=np.zeros(64, np.uint8)) == api.ERROR_NO_IMAGES_FOUND and dec(buf=pj) == api.ERROR_GAIN_MAP_IMAGE_NOT_FOUND
+    assert dec(buf=np.concatenate([pj, gj])) == api.ERROR_METADATA_ERROR          # two JPEGs, no gain-map XMP
+    assert dec(fmt=api.OUTPUT_SDR) == api.ERROR_UNSUPPORTED_FEATURE
+    assert dec() == api.ERROR_INSUFFICIENT_RESOURCE and (dest.width, dest.height, dest.colorGamut) == (1280, 720, api.CG_BT709)   # the size query
+    assert abs(dmd.maxContentBoost - 10.0) < 1e-4 and dmd.version == b"1.0"

@@ -542,6 +542,27 @@ def test_gpu_encode_is_invariant_to_strides_and_chroma_pointers(hip, orc, p010_g
         if lay[2] and lay[1] == 0:
             continue                   # a chroma pointer with chroma_stride 0 fails validation (:150-155): not a layout
         assert api1(p_img(*p_layouts[0]), y_img(*lay)) == base1, ("yuv", lay)
+    # EncodeAPI2AndDecodeTest / EncodeAPI3AndDecodeTest (:1815-2248): the gain map for a given SDR JPEG, same layouts
+    sdr_jpeg = np.frombuffer(orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, q, icc=J.icc_profile_srgb_transfer(sdr_gamut)), np.uint8)
+
+    def api2(pi, yi):
+        rc = lib.uhdr_hip_jpegr_encode_api2(C.byref(pi[0]), C.byref(yi[0]), C.c_void_p(sdr_jpeg.ctypes.data), sdr_jpeg.size, sdr_gamut, hip.TF_HLG,
+                                            C.c_void_p(out.ctypes.data), out.size, C.byref(n), hip.MEM_HOST, None)
+        assert rc == 0
+        return out[:n.value].tobytes()
+
+    def api3(pi):
+        rc = lib.uhdr_hip_jpegr_encode_api3(C.byref(pi[0]), C.c_void_p(sdr_jpeg.ctypes.data), sdr_jpeg.size, sdr_gamut, hip.TF_HLG, C.c_void_p(out.ctypes.data), out.size,
+                                            C.byref(n), hip.MEM_HOST, None)
+        assert rc == 0
+        return out[:n.value].tobytes()
+    base2, base3 = api2(p_img(*p_layouts[0]), y_img(*y_layouts[0])), api3(p_img(*p_layouts[0]))
+    assert base2 == J.encode_api2(p010, yuv, w, h, sdr_gamut, p010_gamut, sdr_jpeg.tobytes(), sdr_gamut, hip.TF_HLG)
+    assert base3 == J.encode_api3(p010, w, h, p010_gamut, sdr_jpeg.tobytes(), sdr_gamut, hip.TF_HLG)
+    for lay in p_layouts[1:]:
+        assert api2(p_img(*lay), y_img(*y_layouts[0])) == base2 and api3(p_img(*lay)) == base3, ("p010", lay)
+    for lay in y_layouts[1:4]:
+        assert api2(p_img(*p_layouts[0]), y_img(*lay)) == base2, ("yuv", lay)
 
 
 def test_invalid_argument_matrices_need_no_gpu():

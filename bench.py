@@ -271,6 +271,7 @@ def cpu_baseline(batch, fmt, nframes):
     ncpu = os.cpu_count() or 1
     torch.cuda.synchronize()
     t_gen = t_app = t_gen4 = t_app4 = 0.0
+    t_ref1 = None
     worst, ndiff, nch = 0, 0, 0
     for i in range(nframes):
         p010 = batch.p010[i].cpu().numpy().view(np.uint16)
@@ -291,6 +292,16 @@ def cpu_baseline(batch, fmt, nframes):
             O.apply("orc_", yi, omap, omd, fmt, api.FLT_MAX, threads=0)
             t2 = time.perf_counter()
             t_gen4, t_app4 = t1 - t0, t2 - t1
+        if i == 0 and O.load_ref() is not None:
+            # the reference's own gainmapmath.cpp object code (oracle/_ref, compiled in place from /root/reference; the per-pixel loops of
+            # ultrahdr.cpp restated around it, one thread) on the same frame: the oracle's speed is the reference's speed
+            t0 = time.perf_counter()
+            rst, rmap, _ = O.generate("ref_", yi, pi, O.TF_HLG)
+            t1 = time.perf_counter()
+            rst2, rref, _ = O.apply("ref_", yi, rmap, omd, fmt, api.FLT_MAX)
+            t2 = time.perf_counter()
+            assert rst == 0 and rst2 == 0 and np.array_equal(rmap, omap) and np.array_equal(rref, ref), "oracle != reference object code"
+            t_ref1 = (t1 - t0, t2 - t1)
         gmap = batch.maps[i].cpu().numpy().reshape(omap.shape)
         assert np.array_equal(gmap, omap), "GPU gain map differs from the CPU oracle on frame %d" % i
         out = batch.outs[i].cpu().numpy().view(np.uint32)
@@ -359,6 +370,7 @@ def cpu_baseline(batch, fmt, nframes):
                   "%d row-band threads" % (nframes, "HLG" if fmt == api.OUTPUT_HDR_HLG else "PQ", ncpu),
         "generate_mpix_s": round(nframes * mpix / t_gen, 3), "apply_mpix_s": round(nframes * mpix / t_app, 3),
         "ref_policy_4_threads_mpix_s": round(mpix / (t_gen4 + t_app4), 3),
+        "reference_object_code_1_thread_mpix_s": None if t_ref1 is None else round(mpix / (t_ref1[0] + t_ref1[1]), 3),
         "gpu_vs_cpu_parity": {"map_bit_exact": True, "apply_worst_lsb": worst,
                               "apply_channels_differing": round(ndiff / max(nch, 1), 6)},
     }

@@ -227,7 +227,7 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
  * the memory space given by mem_space.  *desc is filled (data = out, chroma_data, strides, pixelFormat YUV420 or
  * MONOCHROME) when the header is readable, also on ERROR_INSUFFICIENT_RESOURCE (out_capacity too small: width*height*3/2
  * resp. width*height bytes are needed).  Huffman decoding (self-synchronising parallel decoder), dequantisation and IDCT
- * run on the device.  ERROR_UNSUPPORTED_FEATURE: progressive / arithmetic / restart-interval files (libjpeg reads them, this
+ * run on the device; restart intervals (DRI / RSTn) are read.  ERROR_UNSUPPORTED_FEATURE: progressive / arithmetic-coded files (libjpeg reads them, this
  * decoder does not); UNKNOWN_ERROR: malformed file, or a sampling other than 4:2:0 / single plane, where the reference's call
  * returns false as well (:283-289).  The call waits for the stream. */
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
@@ -241,8 +241,7 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
  * and colorGamut; *metadata (optional) the parsed metadata.  Status values are the reference's: BAD_PTR,
  * INVALID_DISPLAY_BOOST (max_display_boost < 1), INVALID_OUTPUT_FORMAT, NO_IMAGES_FOUND, GAIN_MAP_IMAGE_NOT_FOUND, DECODE_ERROR,
  * METADATA_ERROR, then applyGainMap's own; plus ERROR_INSUFFICIENT_RESOURCE when dest_capacity is too small (*dest is filled)
- * and ERROR_UNSUPPORTED_FEATURE for ULTRAHDR_OUTPUT_SDR (libjpeg's RGB conversion is not built) and for progressive /
- * restart-interval JPEGs. */
+ * and ERROR_UNSUPPORTED_FEATURE for ULTRAHDR_OUTPUT_SDR (libjpeg's RGB conversion is not built) and for progressive JPEGs. */
 #define UHDR_HIP_ERROR_INVALID_DISPLAY_BOOST (-10008)
 #define UHDR_HIP_ERROR_INVALID_OUTPUT_FORMAT (-10009)
 #define UHDR_HIP_ERROR_DECODE_ERROR (-20002)

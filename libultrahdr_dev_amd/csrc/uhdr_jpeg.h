@@ -60,14 +60,20 @@ struct DecPlane {
   int aligned8;
 };
 struct DecInfo {
-  int w, h, gray;
-  uint16_t quant[3][64];     // per component, zigzag order (as stored in the file)
-  DecTables tables;
-  int td[2], ta[2];
-  size_t scan_offset, scan_bytes;   // the entropy-coded segment inside the file
+  int w = 0, h = 0, gray = 0;
+  uint16_t quant[3][64] = {};     // per component, zigzag order (as stored in the file)
+  DecTables tables = {};
+  int td[2] = {0, 0}, ta[2] = {0, 0};
+  size_t scan_offset = 0, scan_bytes = 0;   // the entropy-coded segment inside the file
+  // restart intervals (DRI / RSTn, T.81 B.2.4.4 + E.2.4): MCUs per interval (0 = none) and, from a host scan of the segment, where
+  // each interval starts in the UNSTUFFED stream (stuffed zeros and the RSTn markers themselves removed), and that stream's length
+  uint32_t restart_interval = 0;
+  std::vector<uint32_t> interval_start;
+  uint32_t raw_bytes = 0;
 };
 struct DecLayout {
   size_t src, raw, kept, kept_off, lut, adv, st_a, st_b, dirty_a, dirty_b, nblocks, first_block, coef, dc[3], flags, scan_tmp, scan_tmp_bytes;
+  size_t sub_start, sub_end, sub_key;   // restart-interval files only
   uint32_t nchunks, nsub_max, nblk, mcus_x;
 };
 struct DecJob {
@@ -75,6 +81,12 @@ struct DecJob {
   const uint16_t* lut;       // 4 x 65536 (length << 8 | symbol)
   const uint16_t* adv;       // 4 x 65536 position-only entries (see k_jd_build_lut)
   uint32_t total_bits, nsub, nblk, mcus_x;
+  // restart-interval files: subsequence i covers bits [sub_start[i], sub_end[i]) of restart interval sub_key[i] (it never spans
+  // two intervals); restart_blocks = blocks per interval.  NULL / 0: one interval, subsequence i = bits [512 i, 512 (i + 1))
+  const uint32_t* sub_start;
+  const uint32_t* sub_end;
+  const uint32_t* sub_key;
+  uint32_t restart_blocks;
   int gray;
   uint32_t dc_tbl[2], ac_tbl[2];
   int16_t* coef;             // nblk x 64, zigzag order

@@ -22,12 +22,17 @@
 //   k_jd_write       final decode from the true start states: DC differences and AC values into zeroed coefficient blocks
 //   (three masked scans turn DC differences into DC values per component)
 //   k_jd_idct        one thread per block: dequantise, "islow" IDCT, +128, clamp, store cropped to the plane
-// Files with restart intervals, progressive or arithmetic-coded files and samplings other than 4:2:0 / grayscale return
-// UHDR_HIP_ERROR_UNSUPPORTED_FEATURE (the reference's encoder never writes the first three; it rejects the last itself).
+// Restart intervals (DRI / RSTn) make the job easier, not harder: every interval is a byte-aligned bit string of its own whose
+// start state is known, so its first subsequence plays the role of subsequence 0, nothing is carried across an interval boundary,
+// and the block index and the DC predictors restart with it (segmented scans).  The host finds the markers while it looks for the
+// end of the segment (parse_header) and the unstuffing pass drops them like the stuffed zeros.
+// Progressive or arithmetic-coded files return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE (libjpeg reads them, the reference's encoder
+// never writes them); samplings other than 4:2:0 / grayscale fail as they do in the reference.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
 #include <cstring>
+#include <vector>
 
 #include "uhdr_jpeg.h"
 
@@ -41,7 +46,13 @@ constexpr uint32_t kSubBits = UHDR_JD_SUBBITS;   // bits per subsequence
 constexpr uint32_t kUnstuffChunk = 64;  // bytes per thread in the unstuffing passes
 
 // ---- unstuffing ----------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, uint32_t n, uint32_t* kept) {
+// a byte of the entropy-coded segment that is not part of the bit string: the zero stuffed after a 0xFF, and (files with restart
+// intervals) both bytes of an RSTn marker
+__device__ __forceinline__ bool dropped_byte(const uint8_t* src, uint32_t n, uint32_t at, uint8_t v, uint8_t prev, int rst) {
+  if (prev == 0xFF && (v == 0 || (rst && (v & 0xF8) == 0xD0))) return true;
+  return rst && v == 0xFF && at + 1u < n && (src[at + 1u] & 0xF8) == 0xD0;
+}
+__global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, uint32_t n, uint32_t* kept, int rst) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t b0 = t * kUnstuffChunk;
   if (b0 >= n) return;
@@ -50,13 +61,13 @@ __global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, ui
   uint8_t prev = b0 ? src[b0 - 1] : 0;
   for (uint32_t i = 0; i < len; ++i) {
     const uint8_t v = src[b0 + i];
-    k += !(v == 0 && prev == 0xFF);
+    k += !dropped_byte(src, n, b0 + i, v, prev, rst);
     prev = v;
   }
   kept[t] = k;
 }
 // a workgroup compacts its 16 KiB into LDS and writes the run out as aligned dwords (its start in `dst` is arbitrary)
-__global__ void __launch_bounds__(256) k_jd_unstuff_copy(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst) {
+__global__ void __launch_bounds__(256) k_jd_unstuff_copy(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst, int rst) {
   __shared__ uint8_t s_buf[256 * kUnstuffChunk + 8];
   __shared__ uint32_t s_len;
   const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
@@ -79,7 +90,7 @@ __global__ void __launch_bounds__(256) k_jd_unstuff_copy(const uint8_t* src, uin
       for (uint32_t k = 0; k < 16u; ++k) {
         const uint8_t by = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
         if (k4 * 16u + k < len) {
-          if (!(by == 0 && prev == 0xFF)) s_buf[lo++] = by;
+          if (!dropped_byte(src, n, b0 + k4 * 16u + k, by, prev, rst)) s_buf[lo++] = by;
           prev = by;
         }
       }
@@ -250,6 +261,17 @@ __device__ __forceinline__ void load_fast_lut(const DecJob& j, uint16_t (*s_lut)
   __syncthreads();
 }
 
+// Where subsequence i lies.  Without restart intervals: bits [512 i, 512 (i + 1)) of one bit string, and only subsequence 0 knows
+// its start state.  With them every interval is its own bit string (byte aligned, DC predictors reset, T.81 E.2.4): its first
+// subsequence starts from the known state too and nothing is carried across an interval boundary.
+__device__ __forceinline__ uint32_t sub_begin(const DecJob& j, uint32_t i) { return j.sub_start ? j.sub_start[i] : i * kSubBits; }
+__device__ __forceinline__ uint32_t sub_end_bit(const DecJob& j, uint32_t i) {
+  if (j.sub_end) return j.sub_end[i];
+  return (i + 1u) * kSubBits < j.total_bits ? (i + 1u) * kSubBits : j.total_bits;
+}
+__device__ __forceinline__ bool sub_is_first(const DecJob& j, uint32_t i) { return i == 0u || (j.sub_key && j.sub_key[i] != j.sub_key[i - 1u]); }
+__device__ __forceinline__ bool sub_is_last(const DecJob& j, uint32_t i) { return i + 1u == j.nsub || (j.sub_key && j.sub_key[i + 1u] != j.sub_key[i]); }
+
 // ROUND 0: start from the guess (subsequence start, block 0, coefficient 0); ROUND 1: start from the end state of the
 // previous subsequence as of the last round.  Both: decode until the subsequence's end is crossed, record the state.
 // Only subsequences whose start state changed in the previous round are decoded again (dirty_in).
@@ -260,16 +282,16 @@ __global__ void __launch_bounds__(256) k_jd_sync(const DecJob j, const DState* p
   load_fast_adv(j, s_adv);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= j.nsub) return;
-  if (ROUND == 1 && (i == 0u || !dirty_in[i])) {
+  const bool first = sub_is_first(j, i);
+  if (ROUND == 1 && (first || !dirty_in[i])) {
     next[i] = prev[i];
     dirty_out[i + 1u] = 0;
     return;
   }
   DState s;
-  if (i == 0u) { s.p = 0u; s.cz = 0u; }
-  else if (ROUND == 0) { s.p = i * kSubBits; s.cz = 0u; }
+  if (first || ROUND == 0) { s.p = sub_begin(j, i); s.cz = 0u; }
   else s = prev[i - 1u];
-  const uint32_t end = (i + 1u) * kSubBits < j.total_bits ? (i + 1u) * kSubBits : j.total_bits;
+  const uint32_t end = sub_end_bit(j, i);
   Reader rd;
   rd.init(j.raw, s.p);
   uint32_t nb = 0;
@@ -291,20 +313,26 @@ __global__ void __launch_bounds__(256) k_jd_write(const DecJob j, const DState* 
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= j.nsub) return;
   DState s;
-  if (i == 0u) { s.p = 0u; s.cz = 0u; } else s = st[i - 1u];
-  const uint32_t end = (i + 1u) * kSubBits < j.total_bits ? (i + 1u) * kSubBits : j.total_bits;
+  if (sub_is_first(j, i)) { s.p = sub_begin(j, i); s.cz = 0u; } else s = st[i - 1u];
+  const uint32_t end = sub_end_bit(j, i);
   Reader rd;
   rd.init(j.raw, s.p);
-  uint32_t blk = first_block[i];
+  // first_block: blocks completed before this subsequence, counted from the start of its restart interval (of the scan without them)
+  uint32_t blk = first_block[i], blk_end = j.nblk;
+  if (j.sub_key) {
+    const uint32_t k = j.sub_key[i];
+    blk += k * j.restart_blocks;
+    blk_end = (k + 1u) * j.restart_blocks < j.nblk ? (k + 1u) * j.restart_blocks : j.nblk;
+  }
   bool bd, has;
   int zp = 0, v = 0;
-  while (s.p < end && blk < j.nblk) {
+  while (s.p < end && blk < blk_end) {   // (stops in front of the 1-bits that pad an interval to its byte boundary)
     const bool ok = step<1>(j, s_lut, rd, s, bd, zp, v, has);
     if (!ok) *error = 1u;
     if (has) j.coef[(size_t)blk * 64u + (uint32_t)zp] = (int16_t)v;
     blk += bd;
   }
-  if (i == j.nsub - 1u && (blk != j.nblk || s.p > j.total_bits)) *error = 1u;   // the scan must end exactly after the last block
+  if (sub_is_last(j, i) && (blk != blk_end || s.p > end)) *error = 1u;   // an interval (the scan) must end exactly after its last block
 }
 
 // ---- DC prediction: value = running sum of the differences of the same component ---------------------------------------
@@ -315,6 +343,10 @@ struct DcPick {
     const int c = gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
     return c == comp ? (int)coef[(size_t)b * 64u] : 0;
   }
+};
+struct BlkKey {   // restart interval a block belongs to: the DC predictors start from zero in each (T.81 F.1.1.5.1 / E.2.4)
+  uint32_t per;
+  __host__ __device__ uint32_t operator()(uint32_t b) const { return b / per; }
 };
 __global__ void __launch_bounds__(256) k_jd_dc_apply(const DecJob j, const int* sum0, const int* sum1, const int* sum2) {
   const uint32_t b = blockIdx.x * 256u + threadIdx.x;
@@ -411,7 +443,8 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   l->nblk = l->mcus_x * mcus_y * (info.gray ? 1u : 6u);
   const size_t nbytes = info.scan_bytes;
   l->nchunks = (uint32_t)((nbytes + kUnstuffChunk - 1) / kUnstuffChunk);
-  l->nsub_max = (uint32_t)((nbytes * 8 + kSubBits - 1) / kSubBits) + 1u;
+  const uint32_t nint = (uint32_t)info.interval_start.size();   // 0 without restart intervals; each interval may end in a short subsequence
+  l->nsub_max = (uint32_t)((nbytes * 8 + kSubBits - 1) / kSubBits) + 1u + nint;
   size_t o = 0;
   l->src = o; o += up(nbytes + 16);
   l->raw = o; o += up(nbytes + 64);
@@ -430,6 +463,12 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   l->dc[1] = o; o += up((size_t)l->nblk * 4);
   l->dc[2] = o; o += up((size_t)l->nblk * 4);
   l->flags = o; o += 256;   // [0] changed, [1] error, [2] raw byte count
+  l->sub_start = l->sub_end = l->sub_key = 0;
+  if (nint) {
+    l->sub_start = o; o += up((size_t)l->nsub_max * 4);
+    l->sub_end = o; o += up((size_t)l->nsub_max * 4);
+    l->sub_key = o; o += up((size_t)(l->nsub_max + 1) * 4);
+  }
   size_t t1 = 0, t2 = 0, t3 = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nchunks + 1));
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nsub_max + 1));
@@ -437,6 +476,16 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
     hipcub::CountingInputIterator<uint32_t> cnt(0u);
     hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{nullptr, 0, 0});
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, t3, it, (int*)nullptr, (int)l->nblk);
+  }
+  if (nint) {   // the segmented forms of the last two
+    size_t t4 = 0, t5 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t4, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nsub_max + 1));
+    hipcub::CountingInputIterator<uint32_t> cnt(0u);
+    hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{nullptr, 0, 0});
+    hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{1u});
+    (void)hipcub::DeviceScan::InclusiveSumByKey(nullptr, t5, keys, it, (int*)nullptr, (int)l->nblk);
+    t2 = t2 > t4 ? t2 : t4;
+    t3 = t3 > t5 ? t3 : t5;
   }
   l->scan_tmp_bytes = up((t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3)) + 256);
   l->scan_tmp = o; o += l->scan_tmp_bytes;
@@ -457,10 +506,11 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
   JD_TRY(hipMemsetAsync(raw, 0, ((size_t)nbytes + 64 + 255) / 256 * 256, s));
   JD_TRY(hipMemsetAsync(kept + l.nchunks, 0, 4, s));
   const dim3 gu((l.nchunks + 255u) / 256u), b256(256);
-  hipLaunchKernelGGL(k_jd_unstuff_count, gu, b256, 0, s, src, nbytes, kept);
+  const int rst = info.restart_interval != 0 ? 1 : 0;
+  hipLaunchKernelGGL(k_jd_unstuff_count, gu, b256, 0, s, src, nbytes, kept, rst);
   size_t tmp = l.scan_tmp_bytes;
   JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, kept, kept_off, (int)(l.nchunks + 1u), s));
-  hipLaunchKernelGGL(k_jd_unstuff_copy, gu, b256, 0, s, src, nbytes, kept_off, raw);
+  hipLaunchKernelGGL(k_jd_unstuff_copy, gu, b256, 0, s, src, nbytes, kept_off, raw, rst);
   uint32_t raw_bytes = 0;
   JD_TRY(hipMemcpyAsync(&raw_bytes, kept_off + l.nchunks, 4, hipMemcpyDeviceToHost, s));
   hipLaunchKernelGGL(k_jd_build_lut, dim3(4u * 65536u / 256u), b256, 0, s, info.tables, reinterpret_cast<uint16_t*>(ws + l.lut),
@@ -474,6 +524,28 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
   j.adv = reinterpret_cast<const uint16_t*>(ws + l.adv);
   j.total_bits = raw_bytes * 8u;
   j.nsub = (j.total_bits + kSubBits - 1u) / kSubBits;
+  if (rst) {
+    // one table row per subsequence: the intervals found by the host scan, cut into 512-bit pieces
+    if (raw_bytes != info.raw_bytes) return -1;   // (fill bytes in front of a marker: host and device disagree, nobody writes those)
+    const size_t nint = info.interval_start.size();
+    std::vector<uint32_t> sb, se, sk;
+    for (size_t k = 0; k < nint; ++k) {
+      const uint32_t b0 = info.interval_start[k] * 8u, b1 = (k + 1 < nint ? info.interval_start[k + 1] : raw_bytes) * 8u;
+      if (b1 <= b0) return -1;   // an empty interval
+      for (uint32_t b = b0; b < b1; b += kSubBits) { sb.push_back(b); se.push_back(b + kSubBits < b1 ? b + kSubBits : b1); sk.push_back((uint32_t)k); }
+    }
+    j.nsub = (uint32_t)sb.size();
+    if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
+    sk.push_back(0xFFFFFFFFu);
+    JD_TRY(hipMemcpyAsync(ws + l.sub_start, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, s));
+    JD_TRY(hipMemcpyAsync(ws + l.sub_end, se.data(), se.size() * 4, hipMemcpyHostToDevice, s));
+    JD_TRY(hipMemcpyAsync(ws + l.sub_key, sk.data(), sk.size() * 4, hipMemcpyHostToDevice, s));
+    JD_TRY(hipStreamSynchronize(s));   // the vectors go out of scope
+    j.sub_start = reinterpret_cast<const uint32_t*>(ws + l.sub_start);
+    j.sub_end = reinterpret_cast<const uint32_t*>(ws + l.sub_end);
+    j.sub_key = reinterpret_cast<const uint32_t*>(ws + l.sub_key);
+    j.restart_blocks = info.restart_interval * (info.gray ? 1u : 6u);
+  }
   if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
   j.gray = info.gray;
   j.nblk = l.nblk;
@@ -504,7 +576,8 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
   }
   uint32_t* first_block = reinterpret_cast<uint32_t*>(ws + l.first_block);
   tmp = l.scan_tmp_bytes;
-  JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, nblocks, first_block, (int)j.nsub, s));
+  if (rst) JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(ws + l.scan_tmp, tmp, j.sub_key, nblocks, first_block, (int)j.nsub, hipcub::Equality(), s));
+  else JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, nblocks, first_block, (int)j.nsub, s));
   JD_TRY(hipMemsetAsync(j.coef, 0, (size_t)j.nblk * 128, s));
   hipLaunchKernelGGL(k_jd_write, gs, b256, 0, s, j, (const DState*)sa, (const uint32_t*)first_block, flags + 1);
   int* dc[3] = {reinterpret_cast<int*>(ws + l.dc[0]), reinterpret_cast<int*>(ws + l.dc[1]), reinterpret_cast<int*>(ws + l.dc[2])};
@@ -512,7 +585,12 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
     hipcub::CountingInputIterator<uint32_t> cnt(0u);
     hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{j.coef, c, info.gray});
     tmp = l.scan_tmp_bytes;
-    JD_TRY(hipcub::DeviceScan::InclusiveSum(ws + l.scan_tmp, tmp, it, dc[c], (int)j.nblk, s));
+    if (rst) {
+      hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{j.restart_blocks});
+      JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(ws + l.scan_tmp, tmp, keys, it, dc[c], (int)j.nblk, hipcub::Equality(), s));
+    } else {
+      JD_TRY(hipcub::DeviceScan::InclusiveSum(ws + l.scan_tmp, tmp, it, dc[c], (int)j.nblk, s));
+    }
   }
   const dim3 gb256((j.nblk + 255u) / 256u);
   hipLaunchKernelGGL(k_jd_dc_apply, gb256, b256, 0, s, j, (const int*)dc[0], (const int*)dc[1], (const int*)dc[2]);

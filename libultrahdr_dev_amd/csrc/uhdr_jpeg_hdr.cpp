@@ -13,7 +13,7 @@ static unsigned rd16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
 
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
   if (jpg == nullptr || n < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return -1;
-  memset(info, 0, sizeof(*info));
+  *info = DecInfo();
   static const uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                   41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                   30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
@@ -70,7 +70,8 @@ int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
     } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
       return -2;   // progressive, lossless, arithmetic: libjpeg reads some of these, this decoder does not
     } else if (m == 0xDD) {
-      if (rd16(seg) != 0) return -2;   // restart intervals
+      if (len < 4) return -1;
+      info->restart_interval = rd16(seg);
     } else if (m == 0xDA) {
       if (nc == 0 || seg[0] != nc || len < (size_t)(6 + 2 * nc)) return -2;
       info->gray = nc == 1;
@@ -90,17 +91,34 @@ int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
         }
       }
       info->scan_offset = pos + 2 + len;
-      // the entropy-coded segment ends at the first marker that is neither a stuffed zero nor a fill byte
+      // the entropy-coded segment ends at the first marker that is neither a stuffed zero, a fill byte nor (in a file with restart
+      // intervals) an RSTn; the same walk notes where every restart interval begins once those bytes are gone
       size_t e = info->scan_offset;
+      uint32_t stuffed = 0, markers = 0;
+      if (info->restart_interval != 0) info->interval_start.push_back(0u);
       for (;;) {   // memchr: the segment is megabytes long and 0xFF is rare in it
         const void* f = e + 1 < n ? memchr(jpg + e, 0xFF, n - 1 - e) : nullptr;
         if (f == nullptr) return -1;
         e = (size_t)(static_cast<const uint8_t*>(f) - jpg);
-        if (jpg[e + 1] != 0x00 && jpg[e + 1] != 0xFF) break;
-        e += jpg[e + 1] == 0x00 ? 2 : 1;
+        const uint8_t b = jpg[e + 1];
+        if (b == 0x00) { ++stuffed; e += 2; continue; }
+        if (b == 0xFF) { e += 1; continue; }
+        if ((b & 0xF8) == 0xD0) {
+          if (info->restart_interval == 0) return -2;   // RSTn without DRI cannot happen in a valid file
+          ++markers;
+          e += 2;
+          info->interval_start.push_back((uint32_t)(e - info->scan_offset - stuffed - 2u * markers));
+          continue;
+        }
+        break;
       }
-      if ((jpg[e + 1] & 0xF8) == 0xD0) return -2;   // RSTn without DRI cannot happen in a valid file
       info->scan_bytes = e - info->scan_offset;
+      info->raw_bytes = (uint32_t)(info->scan_bytes - stuffed - 2u * markers);
+      if (info->restart_interval != 0) {   // every interval but the last holds restart_interval MCUs: their number is fixed by the image size
+        const uint64_t mcus = info->gray ? (uint64_t)((info->w + 7) / 8) * (uint64_t)((info->h + 7) / 8)
+                                         : (uint64_t)((info->w + 15) / 16) * (uint64_t)((info->h + 15) / 16);
+        if (info->interval_start.size() != (mcus + info->restart_interval - 1) / info->restart_interval) return -1;
+      }
       return 0;
     } else if (m == 0xD9) {
       return -1;

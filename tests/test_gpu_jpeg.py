@@ -125,17 +125,76 @@ def test_decoder_is_byte_exact_on_the_corpus(hip, orc, tmp_path, device):
     from tests.test_jpeg_oracle import jpeg_corpus
     lib = hip.load()
     corpus, extra = jpeg_corpus(orc, tmp_path)
-    for name, data in corpus + [(k, extra[k]) for k in ("opt", "gray_opt") if k in extra]:
+    for name, data in corpus + [(k, extra[k]) for k in ("opt", "gray_opt", "rst", "rst_rows") if k in extra]:
         rc, got, desc = _gpu_decode(lib, hip, data, device)
         st, want, w, h, gray = orc.jpeg_decode("orc", data)
         assert rc == 0 and st > 0, (name, rc, st)
         assert (desc.width, desc.height) == (w, h) and (desc.pixelFormat == hip.PIX_FMT_MONOCHROME) == bool(gray), name
         assert np.array_equal(got, want), (name, int((got != want).sum()))
-    for k in ("prog", "rst", "rst_rows"):      # files libjpeg reads and the device decoder does not: said out loud
-        if k in extra:
-            assert _gpu_decode(lib, hip, extra[k], device)[0] == hip.ERROR_UNSUPPORTED_FEATURE, k
+    if "prog" in extra:      # a file libjpeg reads and the device decoder does not: said out loud
+        assert _gpu_decode(lib, hip, extra["prog"], device)[0] == hip.ERROR_UNSUPPORTED_FEATURE
     if "s444" in extra:                          # 4:4:4: the reference's decompressImage fails as well (jpegdecoderhelper.cpp:283-289)
         assert _gpu_decode(lib, hip, extra["s444"], device)[0] == hip.UNKNOWN_ERROR
+
+
+_PIL_RESTART = r"""
+import io, sys, numpy as np
+from PIL import Image
+d = np.load(sys.argv[1]); out = {}
+y, u, v = d["y"], d["u"], d["v"]
+ycc = np.stack([y, np.repeat(np.repeat(u, 2, 0), 2, 1), np.repeat(np.repeat(v, 2, 0), 2, 1)], -1)
+im, g = Image.fromarray(ycc, mode="YCbCr"), Image.fromarray(y, mode="L")
+def enc(img, **kw):
+    b = io.BytesIO(); img.save(b, "JPEG", **kw); return np.frombuffer(b.getvalue(), np.uint8)
+out["rows_q95"] = enc(im, quality=95, subsampling=2, restart_marker_rows=1)
+out["rows2_q75_opt"] = enc(im, quality=75, subsampling=2, restart_marker_rows=2, optimize=True)
+out["blocks1_q90"] = enc(im, quality=90, subsampling=2, restart_marker_blocks=1)        # an interval per MCU
+out["blocks7_q100"] = enc(im, quality=100, subsampling=2, restart_marker_blocks=7)
+out["blocks4096_q85"] = enc(im, quality=85, subsampling=2, restart_marker_blocks=4096)  # long intervals: synchronisation inside them
+out["gray_rows_q90"] = enc(g, quality=90, restart_marker_rows=1)
+out["gray_blocks3_q50"] = enc(g, quality=50, restart_marker_blocks=3)
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (200, 120), (16, 16)])
+def test_decoder_reads_restart_intervals(hip, orc, tmp_path, size):
+    """files with DRI / RSTn markers (libjpeg-turbo through Pillow writes them; cameras do): planes identical to the CPU restatement,
+    which tests/test_jpeg_oracle.py holds equal to libjpeg on such files; then corrupted copies must come back with a status"""
+    import subprocess, sys
+    from tests.test_jpeg_oracle import _content
+    lib = hip.load()
+    w, h = size
+    y, u, v = _content("smooth", w, h, np.random.RandomState(w))
+    np.savez(tmp_path / "in.npz", y=y, u=u, v=v)
+    try:
+        subprocess.check_call([sys.executable, "-c", _PIL_RESTART, str(tmp_path / "in.npz"), str(tmp_path / "out.npz")], stderr=subprocess.DEVNULL)
+    except (subprocess.CalledProcessError, OSError):
+        pytest.skip("Pillow not usable here")
+    res = np.load(tmp_path / "out.npz")
+    for name in res.files:
+        data = res[name].tobytes()
+        assert b"\xff\xdd" in data[:2000]
+        st, want, dw, dh, gray = orc.jpeg_decode("orc", data)
+        assert st > 0 and (dw, dh) == (w, h), name
+        for device in (True, False):
+            rc, got, desc = _gpu_decode(lib, hip, data, device)
+            assert rc == 0 and (desc.width, desc.height) == (w, h), (name, rc)
+            assert np.array_equal(got, want), (name, int((got != want).sum()))
+    # damage: a marker removed, a marker added, a truncated file, bytes flipped inside an interval -- a status, never a fault
+    data = bytearray(res["rows_q95"].tobytes())
+    sos = data.find(b"\xff\xda")
+    first_rst = data.find(b"\xff\xd0", sos)
+    rng = np.random.RandomState(5)
+    variants = [bytes(data[:first_rst] + data[first_rst + 2:]), bytes(data[:first_rst] + b"\xff\xd3" + data[first_rst:]), bytes(data[:len(data) * 2 // 3])]
+    for _ in range(12):
+        d = bytearray(data)
+        for _ in range(4):
+            d[rng.randint(sos + 14, len(d) - 2)] = rng.randint(0, 256)
+        variants.append(bytes(d))
+    for k, bad in enumerate(variants):
+        rc, got, desc = _gpu_decode(lib, hip, bad, True)
+        assert rc in (0, hip.UNKNOWN_ERROR, hip.ERROR_UNSUPPORTED_FEATURE), (k, rc)
 
 
 def test_decoder_rejects_malformed_input(hip, orc):

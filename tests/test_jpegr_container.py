@@ -457,6 +457,15 @@ def test_host_parsers_survive_mutated_files_under_asan(orc, tmp_path):
     for name, blob in (("small.jpgr", small), ("primary.jpg", primary), ("gray.jpg", gray)):
         (tmp_path / name).write_bytes(blob)
         seeds.append(str(tmp_path / name))
+    try:      # a file with restart intervals for the marker walk of the header parser, when Pillow can write one here
+        import io
+        from PIL import Image
+        b = io.BytesIO()
+        Image.fromarray(y[:w * h].reshape(h, w), mode="L").save(b, "JPEG", quality=80, restart_marker_blocks=2)
+        (tmp_path / "rst.jpg").write_bytes(b.getvalue())
+        seeds.append(str(tmp_path / "rst.jpg"))
+    except Exception:
+        pass
     exe = str(tmp_path / "fuzz")
     csrc = os.path.join(ROOT, "libultrahdr_dev_amd", "csrc")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__",

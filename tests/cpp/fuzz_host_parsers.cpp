@@ -47,6 +47,9 @@ static void exercise(const std::vector<uint8_t>& in) {
     jpeg::DecInfo info;
     if (jpeg::parse_header(j, img[i].len, &info) == 0) {
       if (info.scan_offset + info.scan_bytes > img[i].len || info.w <= 0 || info.h <= 0 || info.w > 65535 || info.h > 65535) { fprintf(stderr, "bad DecInfo\n"); abort(); }
+      if (info.raw_bytes > info.scan_bytes) { fprintf(stderr, "raw > scan\n"); abort(); }
+      for (size_t k = 0; k < info.interval_start.size(); ++k)   // what the device decoder indexes its bit string with
+        if (info.interval_start[k] > info.raw_bytes || (k && info.interval_start[k] < info.interval_start[k - 1])) { fprintf(stderr, "bad interval table\n"); abort(); }
     }
   }
   // the whole buffer as a "primary JPEG" for appendGainMap's EXIF lifting

@@ -511,11 +511,9 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
   size_t tmp = l.scan_tmp_bytes;
   JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, kept, kept_off, (int)(l.nchunks + 1u), s));
   hipLaunchKernelGGL(k_jd_unstuff_copy, gu, b256, 0, s, src, nbytes, kept_off, raw, rst);
-  uint32_t raw_bytes = 0;
-  JD_TRY(hipMemcpyAsync(&raw_bytes, kept_off + l.nchunks, 4, hipMemcpyDeviceToHost, s));
+  const uint32_t raw_bytes = info.raw_bytes;   // the host counted the stuffed zeros and markers while it looked for the segment's end: no round trip
   hipLaunchKernelGGL(k_jd_build_lut, dim3(4u * 65536u / 256u), b256, 0, s, info.tables, reinterpret_cast<uint16_t*>(ws + l.lut),
                      reinterpret_cast<uint16_t*>(ws + l.adv));
-  JD_TRY(hipStreamSynchronize(s));
 
   DecJob j;
   memset(&j, 0, sizeof(j));
@@ -526,7 +524,6 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
   j.nsub = (j.total_bits + kSubBits - 1u) / kSubBits;
   if (rst) {
     // one table row per subsequence: the intervals found by the host scan, cut into 512-bit pieces
-    if (raw_bytes != info.raw_bytes) return -1;   // (fill bytes in front of a marker: host and device disagree, nobody writes those)
     const size_t nint = info.interval_start.size();
     std::vector<uint32_t> sb, se, sk;
     for (size_t k = 0; k < nint; ++k) {
@@ -560,15 +557,17 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
   uint8_t* db = ws + l.dirty_b;
   uint32_t* nblocks = reinterpret_cast<uint32_t*>(ws + l.nblocks);
   hipLaunchKernelGGL(k_jd_sync<0>, gs, b256, 0, s, j, (const DState*)nullptr, sa, (const uint8_t*)nullptr, da, nblocks, flags);
-  // rounds until a round changes nothing; kRoundsPerCheck rounds are enqueued per host check (a converged round costs a launch)
-  constexpr uint32_t kRoundsPerCheck = 4;
-  for (uint32_t round = 0;; round += kRoundsPerCheck) {
-    if (round > j.nsub + kRoundsPerCheck) return -1;   // cannot happen: every round fixes at least one more subsequence
-    for (uint32_t r = 0; r < kRoundsPerCheck; r += 2) {
-      if (r == kRoundsPerCheck - 2) JD_TRY(hipMemsetAsync(flags, 0, 4, s));   // only the last pair of the batch decides
+  // rounds until a round changes nothing.  A host check costs a stream round trip (~25 us), a round that has nothing left to do a
+  // launch (~4 us): rounds are enqueued in growing batches (4, 8, 16, 16, ...), only the last pair of a batch reports
+  uint32_t done_rounds = 0;
+  for (uint32_t batch = 4;; batch = batch < 16u ? batch * 2u : 16u) {
+    if (done_rounds > j.nsub + 32u) return -1;   // cannot happen: every round fixes at least one more subsequence
+    for (uint32_t r = 0; r < batch; r += 2) {
+      if (r == batch - 2) JD_TRY(hipMemsetAsync(flags, 0, 4, s));
       hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sa, sb, (const uint8_t*)da, db, nblocks, flags);
       hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sb, sa, (const uint8_t*)db, da, nblocks, flags);
     }
+    done_rounds += batch;
     uint32_t changed = 0;
     JD_TRY(hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, s));
     JD_TRY(hipStreamSynchronize(s));

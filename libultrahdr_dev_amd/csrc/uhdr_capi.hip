@@ -44,6 +44,7 @@ struct DeviceState {
   // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
   void* stage[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  hipStream_t aux = nullptr;  // second stream of uhdr_hip_jpegr_decode: the gain map is decompressed beside the primary image
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
 std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
@@ -478,6 +479,7 @@ int uhdr_hip_shutdown(void) {
     (void)hipDeviceSynchronize();
     for (auto& t : kv.second.idw) (void)hipFree(t.second);
     if (kv.second.lut) (void)hipFree(kv.second.lut);
+    if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
     for (int i = 0; i < 12; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
   }
@@ -652,6 +654,48 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
   return UHDR_HIP_NO_ERROR;
 }
 
+}  // extern "C"
+
+namespace {
+// Both JPEGs of a JPEG/R file decompressed at once into device planes: the primary image on `s`, the gain map on the device's
+// auxiliary stream, advancing in lock step (jpeg::decode_device_multi) so that their synchronisation rounds overlap.  Returns with
+// both streams idle.  0 ok, else UHDR_HIP_ERROR_DECODE_ERROR / UNKNOWN_ERROR.
+int decode_pair_device(DeviceState* st, const uint8_t* const jpg[2], const jpeg::DecInfo info[2], uint8_t* const out[2], hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_host_mu);   // workspace slot 7 is the single-image decoder's too
+  if (st->aux == nullptr) HIP_TRY(hipStreamCreateWithFlags(&st->aux, hipStreamNonBlocking));
+  const hipStream_t streams[2] = {s, st->aux};
+  const int slot[2] = {7, 11};
+  jpeg::DecLayout l[2];
+  uint8_t* ws[2];
+  jpeg::DecPlane planes[2][3];
+  memset(planes, 0, sizeof(planes));
+  auto mk = [](uint8_t* p, size_t pw, size_t ph) {
+    jpeg::DecPlane q;
+    q.p = p; q.w = (int)pw; q.h = (int)ph; q.stride = (int)pw;
+    q.aligned8 = (reinterpret_cast<uintptr_t>(p) % 8 == 0 && pw % 8 == 0) ? 1 : 0;
+    return q;
+  };
+  int rc;
+  for (int k = 0; k < 2; ++k) {
+    const size_t bytes = jpeg::dec_workspace_bytes(info[k], &l[k]);
+    if ((rc = stage_reserve(st, slot[k], bytes)) != 0) return rc;
+    ws[k] = static_cast<uint8_t*>(st->stage[slot[k]]);
+    HIP_TRY(hipMemcpyAsync(ws[k] + l[k].src, jpg[k] + info[k].scan_offset, info[k].scan_bytes, hipMemcpyHostToDevice, streams[k]));
+    const size_t w = (size_t)info[k].w, h = (size_t)info[k].h, luma = w * h, chroma = luma / 4;
+    planes[k][0] = mk(out[k], w, h);
+    if (!info[k].gray) { planes[k][1] = mk(out[k] + luma, w / 2, h / 2); planes[k][2] = mk(out[k] + luma + chroma, w / 2, h / 2); }
+  }
+  const jpeg::DecInfo* infos[2] = {&info[0], &info[1]};
+  jpeg::DecPlane (*pl[2])[3] = {&planes[0], &planes[1]};
+  hipError_t herr = hipSuccess;
+  const int drc = jpeg::decode_device_multi(2, infos, l, ws, pl, streams, &herr);
+  if (drc > 0) { set_err("uhdr_hip_jpegr_decode", herr); return UHDR_HIP_UNKNOWN_ERROR; }
+  return drc < 0 ? UHDR_HIP_ERROR_DECODE_ERROR : UHDR_HIP_NO_ERROR;
+}
+}  // namespace
+
+extern "C" {
+
 // JpegR::decodeJPEGR (jpegr.cpp:655-822), HDR outputs
 int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_format, float max_display_boost, void* dest_data,
                           size_t dest_capacity, uhdr_hip_image_t* dest, uhdr_hip_metadata_t* metadata, int apply_mode,
@@ -669,14 +713,15 @@ int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_forma
   const uint8_t* pj = file + img[0].begin;
   const uint8_t* gj = file + img[1].begin;
 
-  // sizes first: header probes of the two JPEGs
-  uhdr_hip_image_t ydesc, gdesc;
-  int rc = uhdr_hip_jpeg_decode(pj, img[0].len, nullptr, 0, &ydesc, UHDR_HIP_MEM_DEVICE, stream);
-  if (rc == UHDR_HIP_ERROR_UNSUPPORTED_FEATURE) return rc;
-  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE || ydesc.pixelFormat != UHDR_HIP_PIX_FMT_YUV420) return UHDR_HIP_ERROR_DECODE_ERROR;   // :690-694
-  rc = uhdr_hip_jpeg_decode(gj, img[1].len, nullptr, 0, &gdesc, UHDR_HIP_MEM_DEVICE, stream);
-  if (rc == UHDR_HIP_ERROR_UNSUPPORTED_FEATURE) return rc;
-  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return UHDR_HIP_ERROR_DECODE_ERROR;                    // :731-733
+  // the two headers, parsed once (jpeg_read_header of either decompressImage call, :690-694 / :731-733)
+  jpeg::DecInfo info[2];
+  for (int k = 0; k < 2; ++k) {
+    const int prc = jpeg::parse_header(k ? gj : pj, img[k].len, &info[k]);
+    if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+    if (prc != 0 || info[k].w > 8192 || info[k].h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;
+  }
+  if (info[0].gray) return UHDR_HIP_ERROR_DECODE_ERROR;   // the primary image must come back as three planes
+  int rc;
   // metadata from the gain map's XMP packet (:756-760)
   uhdr_hip_metadata_t md;
   const uint8_t* xmp = nullptr;
@@ -690,7 +735,7 @@ int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_forma
   static const char kIccSig[] = "ICC_PROFILE";
   const int gamut = jpegr::find_app_segment(pj, img[0].len, 0xE2, kIccSig, sizeof(kIccSig), &icc, &icc_len) ? jpegr::gamut_from_icc(icc, icc_len)
                                                                                                            : UHDR_HIP_CG_UNSPECIFIED;
-  const size_t w = ydesc.width, h = ydesc.height;
+  const size_t w = (size_t)info[0].w, h = (size_t)info[0].h, gw = (size_t)info[1].w, gh = (size_t)info[1].h;
   dest->width = w; dest->height = h; dest->colorGamut = gamut;
   const size_t out_bytes = w * h * apply_bpp(output_format);
   if (dest_data == nullptr || dest_capacity < out_bytes) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
@@ -700,14 +745,21 @@ int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_forma
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lk(g_jpegr_mu);
   const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
-  const size_t ybytes = w * h + 2 * (w * h / 4), gbytes = gdesc.width * gdesc.height * (gdesc.pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME ? 1 : 2);
+  const size_t ybytes = w * h + 2 * (w * h / 4), gbytes = gw * gh * (info[1].gray ? 1 : 2);
   if ((rc = stage_reserve(st, 8, ybytes + 64)) != 0) return rc;
   if ((rc = stage_reserve(st, 9, gbytes + 64)) != 0) return rc;
   if (host && (rc = stage_reserve(st, 10, out_bytes)) != 0) return rc;
-  if (uhdr_hip_jpeg_decode(pj, img[0].len, st->stage[8], ybytes, &ydesc, UHDR_HIP_MEM_DEVICE, stream) != UHDR_HIP_NO_ERROR)
-    return UHDR_HIP_ERROR_DECODE_ERROR;
-  if (uhdr_hip_jpeg_decode(gj, img[1].len, st->stage[9], gbytes, &gdesc, UHDR_HIP_MEM_DEVICE, stream) != UHDR_HIP_NO_ERROR)
-    return UHDR_HIP_ERROR_DECODE_ERROR;
+  {
+    const uint8_t* jpgs[2] = {pj, gj};
+    uint8_t* outs[2] = {static_cast<uint8_t*>(st->stage[8]), static_cast<uint8_t*>(st->stage[9])};
+    if ((rc = decode_pair_device(st, jpgs, info, outs, s)) != UHDR_HIP_NO_ERROR) return rc == UHDR_HIP_UNKNOWN_ERROR ? rc : UHDR_HIP_ERROR_DECODE_ERROR;
+  }
+  uhdr_hip_image_t ydesc, gdesc;
+  memset(&ydesc, 0, sizeof(ydesc));
+  memset(&gdesc, 0, sizeof(gdesc));
+  ydesc.data = st->stage[8]; ydesc.width = w; ydesc.height = h; ydesc.luma_stride = w;
+  ydesc.chroma_data = static_cast<uint8_t*>(st->stage[8]) + w * h; ydesc.chroma_stride = w / 2; ydesc.pixelFormat = UHDR_HIP_PIX_FMT_YUV420;
+  gdesc.data = st->stage[9]; gdesc.width = gw; gdesc.height = gh; gdesc.luma_stride = gw; gdesc.colorGamut = UHDR_HIP_CG_UNSPECIFIED;
   // :796-801: the decoded planes as a YUV420 image with the ICC gamut; the gain map is the first plane of its JPEG
   ydesc.colorGamut = gamut;
   uhdr_hip_image_t gimg = gdesc;

@@ -492,114 +492,180 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   return o;
 }
 
-// Runs the whole decoder on `s` (synchronises: the number of synchronisation rounds is data dependent).
-// src_dev: the entropy-coded segment already in device memory at ws + l.src.  Returns 0, -1 (corrupt) or a hipError_t > 0.
-int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr) {
-#define JD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *herr = _e; return 1; } } while (0)
-  const uint32_t nbytes = (uint32_t)info.scan_bytes;
-  uint8_t* src = ws + l.src;
-  uint8_t* raw = ws + l.raw;
-  uint32_t* kept = reinterpret_cast<uint32_t*>(ws + l.kept);
-  uint32_t* kept_off = reinterpret_cast<uint32_t*>(ws + l.kept_off);
-  uint32_t* flags = reinterpret_cast<uint32_t*>(ws + l.flags);
-  JD_TRY(hipMemsetAsync(flags, 0, 256, s));
-  JD_TRY(hipMemsetAsync(raw, 0, ((size_t)nbytes + 64 + 255) / 256 * 256, s));
-  JD_TRY(hipMemsetAsync(kept + l.nchunks, 0, 4, s));
-  const dim3 gu((l.nchunks + 255u) / 256u), b256(256);
-  const int rst = info.restart_interval != 0 ? 1 : 0;
-  hipLaunchKernelGGL(k_jd_unstuff_count, gu, b256, 0, s, src, nbytes, kept, rst);
-  size_t tmp = l.scan_tmp_bytes;
-  JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, kept, kept_off, (int)(l.nchunks + 1u), s));
-  hipLaunchKernelGGL(k_jd_unstuff_copy, gu, b256, 0, s, src, nbytes, kept_off, raw, rst);
-  const uint32_t raw_bytes = info.raw_bytes;   // the host counted the stuffed zeros and markers while it looked for the segment's end: no round trip
-  hipLaunchKernelGGL(k_jd_build_lut, dim3(4u * 65536u / 256u), b256, 0, s, info.tables, reinterpret_cast<uint16_t*>(ws + l.lut),
-                     reinterpret_cast<uint16_t*>(ws + l.adv));
-
+// One decode in flight: the decoder's kernels are enqueued in three phases so that two images (the primary image and the gain
+// map of a JPEG/R file) can advance in lock step on two streams -- their latency-bound synchronisation rounds then overlap.
+//   begin()    unstuffing, table building, the first pass
+//   rounds(n)  n more synchronisation rounds; poll() enqueues the read-back of "did the last pair change anything"
+//   finish()   block indices, final pass, DC scans, IDCT; the error flag is read back by poll_error()
+// Every method returns 0, -1 (corrupt stream) or 1 (HIP error in herr).  The caller synchronises the stream between poll and
+// the use of `changed` / `error`.
+struct DecRun {
+  const DecInfo* info = nullptr;
+  DecLayout l;
+  uint8_t* ws = nullptr;
+  hipStream_t s = nullptr;
+  hipError_t herr = hipSuccess;
   DecJob j;
-  memset(&j, 0, sizeof(j));
-  j.raw = reinterpret_cast<const uint32_t*>(raw);
-  j.lut = reinterpret_cast<const uint16_t*>(ws + l.lut);
-  j.adv = reinterpret_cast<const uint16_t*>(ws + l.adv);
-  j.total_bits = raw_bytes * 8u;
-  j.nsub = (j.total_bits + kSubBits - 1u) / kSubBits;
-  if (rst) {
-    // one table row per subsequence: the intervals found by the host scan, cut into 512-bit pieces
-    const size_t nint = info.interval_start.size();
-    std::vector<uint32_t> sb, se, sk;
-    for (size_t k = 0; k < nint; ++k) {
-      const uint32_t b0 = info.interval_start[k] * 8u, b1 = (k + 1 < nint ? info.interval_start[k + 1] : raw_bytes) * 8u;
-      if (b1 <= b0) return -1;   // an empty interval
-      for (uint32_t b = b0; b < b1; b += kSubBits) { sb.push_back(b); se.push_back(b + kSubBits < b1 ? b + kSubBits : b1); sk.push_back((uint32_t)k); }
+  DState* sa = nullptr;
+  DState* sb = nullptr;
+  uint8_t* da = nullptr;
+  uint8_t* db = nullptr;
+  uint32_t* nblocks = nullptr;
+  uint32_t* flags = nullptr;
+  dim3 gs;
+  int rst = 0;
+  uint32_t done_rounds = 0, changed = 1, error = 0;
+  bool converged = false;
+
+#define JD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { herr = _e; return 1; } } while (0)
+  int begin(const DecInfo& info_, const DecLayout& l_, uint8_t* ws_, DecPlane planes[3], hipStream_t s_) {
+    info = &info_; l = l_; ws = ws_; s = s_;
+    const uint32_t nbytes = (uint32_t)info->scan_bytes;
+    uint8_t* src = ws + l.src;
+    uint8_t* raw = ws + l.raw;
+    uint32_t* kept = reinterpret_cast<uint32_t*>(ws + l.kept);
+    uint32_t* kept_off = reinterpret_cast<uint32_t*>(ws + l.kept_off);
+    flags = reinterpret_cast<uint32_t*>(ws + l.flags);
+    JD_TRY(hipMemsetAsync(flags, 0, 256, s));
+    JD_TRY(hipMemsetAsync(raw, 0, ((size_t)nbytes + 64 + 255) / 256 * 256, s));
+    JD_TRY(hipMemsetAsync(kept + l.nchunks, 0, 4, s));
+    const dim3 gu((l.nchunks + 255u) / 256u), b256(256);
+    rst = info->restart_interval != 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_jd_unstuff_count, gu, b256, 0, s, src, nbytes, kept, rst);
+    size_t tmp = l.scan_tmp_bytes;
+    JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, kept, kept_off, (int)(l.nchunks + 1u), s));
+    hipLaunchKernelGGL(k_jd_unstuff_copy, gu, b256, 0, s, src, nbytes, kept_off, raw, rst);
+    const uint32_t raw_bytes = info->raw_bytes;   // the host counted the stuffed zeros and markers while it looked for the segment's end: no round trip
+    hipLaunchKernelGGL(k_jd_build_lut, dim3(4u * 65536u / 256u), b256, 0, s, info->tables, reinterpret_cast<uint16_t*>(ws + l.lut),
+                       reinterpret_cast<uint16_t*>(ws + l.adv));
+
+    memset(&j, 0, sizeof(j));
+    j.raw = reinterpret_cast<const uint32_t*>(raw);
+    j.lut = reinterpret_cast<const uint16_t*>(ws + l.lut);
+    j.adv = reinterpret_cast<const uint16_t*>(ws + l.adv);
+    j.total_bits = raw_bytes * 8u;
+    j.nsub = (j.total_bits + kSubBits - 1u) / kSubBits;
+    if (rst) {
+      // one table row per subsequence: the intervals found by the host scan, cut into 512-bit pieces
+      const size_t nint = info->interval_start.size();
+      std::vector<uint32_t> sb_, se_, sk_;
+      for (size_t k = 0; k < nint; ++k) {
+        const uint32_t b0 = info->interval_start[k] * 8u, b1 = (k + 1 < nint ? info->interval_start[k + 1] : raw_bytes) * 8u;
+        if (b1 <= b0) return -1;   // an empty interval
+        for (uint32_t b = b0; b < b1; b += kSubBits) { sb_.push_back(b); se_.push_back(b + kSubBits < b1 ? b + kSubBits : b1); sk_.push_back((uint32_t)k); }
+      }
+      j.nsub = (uint32_t)sb_.size();
+      if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
+      sk_.push_back(0xFFFFFFFFu);
+      JD_TRY(hipMemcpyAsync(ws + l.sub_start, sb_.data(), sb_.size() * 4, hipMemcpyHostToDevice, s));
+      JD_TRY(hipMemcpyAsync(ws + l.sub_end, se_.data(), se_.size() * 4, hipMemcpyHostToDevice, s));
+      JD_TRY(hipMemcpyAsync(ws + l.sub_key, sk_.data(), sk_.size() * 4, hipMemcpyHostToDevice, s));
+      JD_TRY(hipStreamSynchronize(s));   // the vectors go out of scope
+      j.sub_start = reinterpret_cast<const uint32_t*>(ws + l.sub_start);
+      j.sub_end = reinterpret_cast<const uint32_t*>(ws + l.sub_end);
+      j.sub_key = reinterpret_cast<const uint32_t*>(ws + l.sub_key);
+      j.restart_blocks = info->restart_interval * (info->gray ? 1u : 6u);
     }
-    j.nsub = (uint32_t)sb.size();
     if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
-    sk.push_back(0xFFFFFFFFu);
-    JD_TRY(hipMemcpyAsync(ws + l.sub_start, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, s));
-    JD_TRY(hipMemcpyAsync(ws + l.sub_end, se.data(), se.size() * 4, hipMemcpyHostToDevice, s));
-    JD_TRY(hipMemcpyAsync(ws + l.sub_key, sk.data(), sk.size() * 4, hipMemcpyHostToDevice, s));
-    JD_TRY(hipStreamSynchronize(s));   // the vectors go out of scope
-    j.sub_start = reinterpret_cast<const uint32_t*>(ws + l.sub_start);
-    j.sub_end = reinterpret_cast<const uint32_t*>(ws + l.sub_end);
-    j.sub_key = reinterpret_cast<const uint32_t*>(ws + l.sub_key);
-    j.restart_blocks = info.restart_interval * (info.gray ? 1u : 6u);
+    j.gray = info->gray;
+    j.nblk = l.nblk;
+    j.mcus_x = l.mcus_x;
+    j.dc_tbl[0] = 0; j.ac_tbl[0] = 1; j.dc_tbl[1] = 2; j.ac_tbl[1] = 3;
+    j.coef = reinterpret_cast<int16_t*>(ws + l.coef);
+    for (int c = 0; c < 3; ++c) { j.plane[c] = planes[c]; memcpy(j.quant[c], info->quant[c], sizeof(j.quant[c])); }
+    sa = reinterpret_cast<DState*>(ws + l.st_a);
+    sb = reinterpret_cast<DState*>(ws + l.st_b);
+    gs = dim3((j.nsub + 255u) / 256u);
+    da = ws + l.dirty_a;
+    db = ws + l.dirty_b;
+    nblocks = reinterpret_cast<uint32_t*>(ws + l.nblocks);
+    hipLaunchKernelGGL(k_jd_sync<0>, gs, b256, 0, s, j, (const DState*)nullptr, sa, (const uint8_t*)nullptr, da, nblocks, flags);
+    return 0;
   }
-  if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
-  j.gray = info.gray;
-  j.nblk = l.nblk;
-  j.mcus_x = l.mcus_x;
-  j.dc_tbl[0] = 0; j.ac_tbl[0] = 1; j.dc_tbl[1] = 2; j.ac_tbl[1] = 3;
-  j.coef = reinterpret_cast<int16_t*>(ws + l.coef);
-  for (int c = 0; c < 3; ++c) { j.plane[c] = planes[c]; memcpy(j.quant[c], info.quant[c], sizeof(j.quant[c])); }
-  DState* sa = reinterpret_cast<DState*>(ws + l.st_a);
-  DState* sb = reinterpret_cast<DState*>(ws + l.st_b);
-  const dim3 gs((j.nsub + 255u) / 256u);
-  uint8_t* da = ws + l.dirty_a;
-  uint8_t* db = ws + l.dirty_b;
-  uint32_t* nblocks = reinterpret_cast<uint32_t*>(ws + l.nblocks);
-  hipLaunchKernelGGL(k_jd_sync<0>, gs, b256, 0, s, j, (const DState*)nullptr, sa, (const uint8_t*)nullptr, da, nblocks, flags);
   // rounds until a round changes nothing.  A host check costs a stream round trip (~25 us), a round that has nothing left to do a
-  // launch (~4 us): rounds are enqueued in growing batches (4, 8, 16, 16, ...), only the last pair of a batch reports
-  uint32_t done_rounds = 0;
-  for (uint32_t batch = 4;; batch = batch < 16u ? batch * 2u : 16u) {
+  // launch (~4 us): the callers enqueue rounds in growing batches (4, 8, 16, 16, ...); only the last pair of a batch reports
+  int rounds(uint32_t batch) {
     if (done_rounds > j.nsub + 32u) return -1;   // cannot happen: every round fixes at least one more subsequence
+    const dim3 b256(256);
     for (uint32_t r = 0; r < batch; r += 2) {
       if (r == batch - 2) JD_TRY(hipMemsetAsync(flags, 0, 4, s));
       hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sa, sb, (const uint8_t*)da, db, nblocks, flags);
       hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sb, sa, (const uint8_t*)db, da, nblocks, flags);
     }
     done_rounds += batch;
-    uint32_t changed = 0;
-    JD_TRY(hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, s));
-    JD_TRY(hipStreamSynchronize(s));
-    if (!changed) break;
+    return 0;
   }
-  uint32_t* first_block = reinterpret_cast<uint32_t*>(ws + l.first_block);
-  tmp = l.scan_tmp_bytes;
-  if (rst) JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(ws + l.scan_tmp, tmp, j.sub_key, nblocks, first_block, (int)j.nsub, hipcub::Equality(), s));
-  else JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, nblocks, first_block, (int)j.nsub, s));
-  JD_TRY(hipMemsetAsync(j.coef, 0, (size_t)j.nblk * 128, s));
-  hipLaunchKernelGGL(k_jd_write, gs, b256, 0, s, j, (const DState*)sa, (const uint32_t*)first_block, flags + 1);
-  int* dc[3] = {reinterpret_cast<int*>(ws + l.dc[0]), reinterpret_cast<int*>(ws + l.dc[1]), reinterpret_cast<int*>(ws + l.dc[2])};
-  for (int c = 0; c < (info.gray ? 1 : 3); ++c) {
-    hipcub::CountingInputIterator<uint32_t> cnt(0u);
-    hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{j.coef, c, info.gray});
-    tmp = l.scan_tmp_bytes;
-    if (rst) {
-      hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{j.restart_blocks});
-      JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(ws + l.scan_tmp, tmp, keys, it, dc[c], (int)j.nblk, hipcub::Equality(), s));
-    } else {
-      JD_TRY(hipcub::DeviceScan::InclusiveSum(ws + l.scan_tmp, tmp, it, dc[c], (int)j.nblk, s));
+  int poll() { JD_TRY(hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, s)); return 0; }
+  int finish() {
+    const dim3 b256(256);
+    uint32_t* first_block = reinterpret_cast<uint32_t*>(ws + l.first_block);
+    size_t tmp = l.scan_tmp_bytes;
+    if (rst) JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(ws + l.scan_tmp, tmp, j.sub_key, nblocks, first_block, (int)j.nsub, hipcub::Equality(), s));
+    else JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, nblocks, first_block, (int)j.nsub, s));
+    JD_TRY(hipMemsetAsync(j.coef, 0, (size_t)j.nblk * 128, s));
+    hipLaunchKernelGGL(k_jd_write, gs, b256, 0, s, j, (const DState*)sa, (const uint32_t*)first_block, flags + 1);
+    int* dc[3] = {reinterpret_cast<int*>(ws + l.dc[0]), reinterpret_cast<int*>(ws + l.dc[1]), reinterpret_cast<int*>(ws + l.dc[2])};
+    for (int c = 0; c < (info->gray ? 1 : 3); ++c) {
+      hipcub::CountingInputIterator<uint32_t> cnt(0u);
+      hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{j.coef, c, info->gray});
+      tmp = l.scan_tmp_bytes;
+      if (rst) {
+        hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{j.restart_blocks});
+        JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(ws + l.scan_tmp, tmp, keys, it, dc[c], (int)j.nblk, hipcub::Equality(), s));
+      } else {
+        JD_TRY(hipcub::DeviceScan::InclusiveSum(ws + l.scan_tmp, tmp, it, dc[c], (int)j.nblk, s));
+      }
     }
+    const dim3 gb256((j.nblk + 255u) / 256u);
+    hipLaunchKernelGGL(k_jd_dc_apply, gb256, b256, 0, s, j, (const int*)dc[0], (const int*)dc[1], (const int*)dc[2]);
+    hipLaunchKernelGGL(k_jd_idct, dim3((j.nblk + 127u) / 128u), dim3(128), 0, s, j);
+    return 0;
   }
-  const dim3 gb256((j.nblk + 255u) / 256u);
-  hipLaunchKernelGGL(k_jd_dc_apply, gb256, b256, 0, s, j, (const int*)dc[0], (const int*)dc[1], (const int*)dc[2]);
-  hipLaunchKernelGGL(k_jd_idct, dim3((j.nblk + 127u) / 128u), dim3(128), 0, s, j);
-  uint32_t err = 0;
-  JD_TRY(hipMemcpyAsync(&err, flags + 1, 4, hipMemcpyDeviceToHost, s));
-  JD_TRY(hipStreamSynchronize(s));
-  JD_TRY(hipGetLastError());
-  return err ? -1 : 0;
+  int poll_error() { JD_TRY(hipMemcpyAsync(&error, flags + 1, 4, hipMemcpyDeviceToHost, s)); return 0; }
 #undef JD_TRY
+};
+
+// Runs the whole decoder for up to two images, image k on streams[k] (synchronises: the number of synchronisation rounds is data
+// dependent).  The entropy-coded segment of image k must already sit at ws[k] + l[k].src.  Returns 0, -1 (a corrupt stream) or 1
+// (HIP error in *herr).
+int decode_device_multi(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3],
+                        const hipStream_t streams[], hipError_t* herr) {
+  DecRun run[2];
+  if (n < 1 || n > 2) return -1;
+  auto fail = [&](int rc, int k) { if (rc > 0) *herr = run[k].herr; for (int q = 0; q < n; ++q) (void)hipStreamSynchronize(streams[q]); return rc; };
+  int rc;
+  for (int k = 0; k < n; ++k)
+    if ((rc = run[k].begin(*info[k], l[k], ws[k], *planes[k], streams[k])) != 0) return fail(rc, k);
+  for (uint32_t batch = 4;; batch = batch < 16u ? batch * 2u : 16u) {
+    bool any = false;
+    for (int k = 0; k < n; ++k)
+      if (!run[k].converged) { any = true; if ((rc = run[k].rounds(batch)) != 0) return fail(rc, k); }
+    if (!any) break;
+    // read-backs after everything is enqueued: a copy into pageable memory may block the host until its stream gets there
+    for (int k = 0; k < n; ++k)
+      if (!run[k].converged && (rc = run[k].poll()) != 0) return fail(rc, k);
+    for (int k = 0; k < n; ++k)
+      if (!run[k].converged) {
+        if (hipStreamSynchronize(streams[k]) != hipSuccess) { *herr = hipGetLastError(); return fail(1, k); }
+        run[k].converged = run[k].changed == 0u;
+        if (run[k].converged && (rc = run[k].finish()) != 0) return fail(rc, k);   // the epilogue of one runs under the rounds of the other
+      }
+  }
+  for (int k = 0; k < n; ++k)
+    if ((rc = run[k].poll_error()) != 0) return fail(rc, k);
+  int out = 0;
+  for (int k = 0; k < n; ++k) {
+    if (hipStreamSynchronize(streams[k]) != hipSuccess || hipGetLastError() != hipSuccess) { *herr = hipErrorUnknown; return fail(1, k); }
+    if (run[k].error) out = -1;
+  }
+  return out;
+}
+
+int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr) {
+  const DecInfo* infos[1] = {&info};
+  uint8_t* wss[1] = {ws};
+  DecPlane (*pl[1])[3] = {reinterpret_cast<DecPlane (*)[3]>(planes)};
+  return decode_device_multi(1, infos, &l, wss, pl, &s, herr);
 }
 
 }  // namespace jpeg

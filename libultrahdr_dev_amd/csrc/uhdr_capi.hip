@@ -779,15 +779,9 @@ int uhdr_hip_jpegr_append_gainmap(const void* primary_jpeg, size_t primary_size,
                                   const void* exif, size_t exif_size, const void* icc, size_t icc_size,
                                   const uhdr_hip_metadata_t* metadata, void* out, size_t out_capacity, size_t* out_size) {
   if (primary_jpeg == nullptr || gainmap_jpeg == nullptr || metadata == nullptr || out_size == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
-  std::vector<uint8_t> file;
-  const int rc = jpegr::append_gainmap(static_cast<const uint8_t*>(primary_jpeg), primary_size, static_cast<const uint8_t*>(gainmap_jpeg),
-                                       gainmap_size, static_cast<const uint8_t*>(exif), exif_size, static_cast<const uint8_t*>(icc), icc_size,
-                                       *metadata, file);
-  if (rc != UHDR_HIP_NO_ERROR) return rc;
-  *out_size = file.size();
-  if (out == nullptr || out_capacity < file.size()) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
-  memcpy(out, file.data(), file.size());
-  return UHDR_HIP_NO_ERROR;
+  return jpegr::append_gainmap_to(static_cast<const uint8_t*>(primary_jpeg), primary_size, static_cast<const uint8_t*>(gainmap_jpeg), gainmap_size,
+                                  static_cast<const uint8_t*>(exif), exif_size, static_cast<const uint8_t*>(icc), icc_size, *metadata,
+                                  static_cast<uint8_t*>(out), out_capacity, out_size);
 }
 
 int uhdr_hip_icc_profile(int transfer_function, int color_gamut, void* out, size_t out_capacity, size_t* out_size) {
@@ -844,9 +838,29 @@ struct EncodeCtx {
   hipStream_t s() const { return static_cast<hipStream_t>(stream); }
 };
 
+// Host bytes a compressed stream comes down into: page-locked (the copy runs at DMA speed instead of through the runtime's staging
+// buffer) and kept between calls by their thread_local owners -- a fresh multi-megabyte std::vector costs a memset and a page fault
+// per 4 KiB on every call, which was more than half of a 4K encodeJPEGR call.  Never freed: the process owns them until it ends.
+struct HostBytes {
+  uint8_t* p = nullptr;
+  size_t n = 0, cap = 0;
+  uint8_t* data() const { return p; }
+  size_t size() const { return n; }
+  void resize(size_t want) {
+    if (want > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr; cap = 0;
+      void* q = nullptr;
+      if (hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess) { p = static_cast<uint8_t*>(q); cap = want; }
+    }
+    n = p ? want : 0;
+  }
+};
+
 // JpegEncoderHelper::compressImage with the bytes landing in host memory whichever side the planes live on
-int jpeg_to_host(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, const std::vector<uint8_t>* icc, std::vector<uint8_t>& dst, size_t* n) {
+int jpeg_to_host(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, const std::vector<uint8_t>* icc, HostBytes& dst, size_t* n) {
   for (int attempt = 0; attempt < 2; ++attempt) {
+    if (dst.data() == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
     int r;
     if (c.host()) {
       r = uhdr_hip_jpeg_encode(&img, q, icc ? icc->data() : nullptr, icc ? icc->size() : 0, dst.data(), dst.size(), n, UHDR_HIP_MEM_HOST, c.stream);
@@ -866,7 +880,7 @@ int jpeg_to_host(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, const s
 }
 
 // compressGainMap (jpegr.cpp:806-821): one plane at kMapCompressQuality = 85
-int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, std::vector<uint8_t>& jpeg, size_t* n) {
+int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, HostBytes& jpeg, size_t* n) {
   uhdr_hip_image_t g = map;
   g.chroma_data = nullptr; g.chroma_stride = 0; g.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
   jpeg.resize(map.width * map.height + 65536);
@@ -875,7 +889,7 @@ int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, std::vector
 
 // generateGainMap followed by compressGainMap: the block every one of API-0..3 contains (e.g. jpegr.cpp:277-292)
 int make_gainmap_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& p010, int hdr_tf, int sdr_is_601,
-                      uhdr_hip_metadata_t* md, std::vector<uint8_t>& jpeg, size_t* n) {
+                      uhdr_hip_metadata_t* md, HostBytes& jpeg, size_t* n) {
   const size_t mw = yuv.width / 4, mh = yuv.height / 4;
   std::vector<uint8_t> host_map;
   uhdr_hip_image_t map = yuv;
@@ -888,30 +902,22 @@ int make_gainmap_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& yuv, const uhd
   return gainmap_to_jpeg(c, map, jpeg, n);
 }
 
-int deliver(const std::vector<uint8_t>& file, void* out, size_t out_capacity, size_t* out_size) {
-  *out_size = file.size();
-  if (out_capacity < file.size()) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;   // Write() running past maxLength, jpegr.cpp:46-61
-  memcpy(out, file.data(), file.size());
-  return UHDR_HIP_NO_ERROR;
-}
-
 // the tail API-0 and API-1 share (jpegr.cpp:210-247 / :294-380): ICC for the SDR gamut, BT.601 re-encode unless P3, JPEG at `quality`,
 // appendGainMap.  `enc` must be private to the call when it is not P3 (it is converted in place).
 int finish_from_planes(const EncodeCtx& c, uhdr_hip_image_t enc, int quality, const void* exif, size_t exif_size,
-                       const std::vector<uint8_t>& gm_jpeg, size_t gm_n, const uhdr_hip_metadata_t& md, void* out, size_t out_capacity,
+                       const HostBytes& gm_jpeg, size_t gm_n, const uhdr_hip_metadata_t& md, void* out, size_t out_capacity,
                        size_t* out_size) {
   std::vector<uint8_t> icc;
   if (!jpegr::icc_profile_srgb_transfer(enc.colorGamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
   int rc;
   if (enc.colorGamut != UHDR_HIP_CG_P3 && (rc = uhdr_hip_convert_yuv(&enc, enc.colorGamut, UHDR_HIP_CG_P3, c.mem_space, c.stream)) != UHDR_HIP_NO_ERROR)
     return rc;
-  std::vector<uint8_t> sdr_jpeg(enc.width * enc.height + 65536);
+  static thread_local HostBytes sdr_jpeg;
+  sdr_jpeg.resize(enc.width * enc.height + 65536);
   size_t sdr_n = 0;
   if (jpeg_to_host(c, enc, quality, &icc, sdr_jpeg, &sdr_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
-  std::vector<uint8_t> file;
-  rc = jpegr::append_gainmap(sdr_jpeg.data(), sdr_n, gm_jpeg.data(), gm_n, static_cast<const uint8_t*>(exif), exif_size, nullptr, 0, md, file);
-  if (rc != UHDR_HIP_NO_ERROR) return rc;
-  return deliver(file, out, out_capacity, out_size);
+  return jpegr::append_gainmap_to(sdr_jpeg.data(), sdr_n, gm_jpeg.data(), gm_n, static_cast<const uint8_t*>(exif), exif_size, nullptr, 0, md,
+                                  static_cast<uint8_t*>(out), out_capacity, out_size);
 }
 
 }  // namespace
@@ -950,7 +956,7 @@ int uhdr_hip_jpegr_encode_api0(const uhdr_hip_image_t* p010_in, int hdr_tf, int 
   if ((rc = uhdr_hip_tonemap(&p010, &yuv, mem_space, stream)) != UHDR_HIP_NO_ERROR) return rc;                    // :226
 
   uhdr_hip_metadata_t md;
-  std::vector<uint8_t> gm_jpeg;
+  static thread_local HostBytes gm_jpeg;
   size_t gm_n = 0;
   if ((rc = make_gainmap_jpeg(c, yuv, p010, hdr_tf, 0, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;     // :228-244
   return finish_from_planes(c, yuv, quality, exif, exif_size, gm_jpeg, gm_n, md, out, out_capacity, out_size);
@@ -973,7 +979,7 @@ int uhdr_hip_jpegr_encode_api1(const uhdr_hip_image_t* p010_in, const uhdr_hip_i
   const size_t w = yuv.width, h = yuv.height;
 
   uhdr_hip_metadata_t md;
-  std::vector<uint8_t> gm_jpeg;
+  static thread_local HostBytes gm_jpeg;
   size_t gm_n = 0;
   if ((rc = make_gainmap_jpeg(c, yuv, p010, hdr_tf, 0, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;     // :277-292
 
@@ -1022,11 +1028,8 @@ int uhdr_hip_jpegr_encode_api4(const void* sdr_jpeg, size_t sdr_jpeg_size, int s
     jpegr::icc_profile_srgb_transfer(sdr_jpeg_gamut, icc);
   }
   if (metadata == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                         // :955-958
-  std::vector<uint8_t> file;
-  const int rc = jpegr::append_gainmap(pj, sdr_jpeg_size, static_cast<const uint8_t*>(gainmap_jpeg), gainmap_jpeg_size, nullptr, 0,
-                                       icc.empty() ? nullptr : icc.data(), icc.size(), *metadata, file);
-  if (rc != UHDR_HIP_NO_ERROR) return rc;
-  return deliver(file, out, out_capacity, out_size);
+  return jpegr::append_gainmap_to(pj, sdr_jpeg_size, static_cast<const uint8_t*>(gainmap_jpeg), gainmap_jpeg_size, nullptr, 0,
+                                  icc.empty() ? nullptr : icc.data(), icc.size(), *metadata, static_cast<uint8_t*>(out), out_capacity, out_size);
 }
 
 // JpegR::encodeJPEGR API-2 (jpegr.cpp:384-437)
@@ -1042,7 +1045,7 @@ int uhdr_hip_jpegr_encode_api2(const uhdr_hip_image_t* p010_in, const uhdr_hip_i
   EncodeCtx c{nullptr, stream, mem_space};
   if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
   uhdr_hip_metadata_t md;
-  std::vector<uint8_t> gm_jpeg;
+  static thread_local HostBytes gm_jpeg;
   size_t gm_n = 0;
   {
     std::lock_guard<std::mutex> lk(g_jpegr_mu);
@@ -1070,7 +1073,7 @@ int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_in, const void* sdr_
   if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
   const size_t w = ydesc.width, h = ydesc.height, ybytes = w * h + 2 * (w * h / 4);
   uhdr_hip_metadata_t md;
-  std::vector<uint8_t> gm_jpeg;
+  static thread_local HostBytes gm_jpeg;
   size_t gm_n = 0;
   {
     std::lock_guard<std::mutex> lk(g_jpegr_mu);
@@ -1111,17 +1114,17 @@ int uhdr_hip_jpegr_encode_apix(const uhdr_hip_image_t* yuv_in, const uhdr_hip_im
   int rc;
   if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
   std::lock_guard<std::mutex> lk(g_jpegr_mu);
-  std::vector<uint8_t> gm_jpeg, icc;
+  static thread_local HostBytes gm_jpeg;
+  std::vector<uint8_t> icc;
   size_t gm_n = 0;
   if ((rc = gainmap_to_jpeg(c, *gainmap, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;                        // :590-597
   if (!jpegr::icc_profile_srgb_transfer(yuv.colorGamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;           // :599-600
-  std::vector<uint8_t> sdr_jpeg(yuv.width * yuv.height + 65536);
+  static thread_local HostBytes sdr_jpeg;
+  sdr_jpeg.resize(yuv.width * yuv.height + 65536);
   size_t sdr_n = 0;
   if (jpeg_to_host(c, yuv, quality, &icc, sdr_jpeg, &sdr_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;   // :602-611
-  std::vector<uint8_t> file;
-  rc = jpegr::append_gainmap(sdr_jpeg.data(), sdr_n, gm_jpeg.data(), gm_n, static_cast<const uint8_t*>(exif), exif_size, nullptr, 0, *metadata, file);
-  if (rc != UHDR_HIP_NO_ERROR) return rc;
-  return deliver(file, out, out_capacity, out_size);
+  return jpegr::append_gainmap_to(sdr_jpeg.data(), sdr_n, gm_jpeg.data(), gm_n, static_cast<const uint8_t*>(exif), exif_size, nullptr, 0, *metadata,
+                                  static_cast<uint8_t*>(out), out_capacity, out_size);
 }
 
 // JpegR::getJPEGRInfo (jpegr.cpp:633-653)

@@ -422,9 +422,11 @@ bool has_valid_header(const uint8_t* jpg, size_t n) {
   return extract_exif(jpg, n, &pos, &e, &el);
 }
 
-// appendGainMap (jpegr.cpp:951-1130): 0 ok, else the reference's status
-int append_gainmap(const uint8_t* primary_in, size_t n1, const uint8_t* gainmap, size_t n2, const uint8_t* exif, size_t exif_len,
-                   const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata_t& md, std::vector<uint8_t>& out) {
+// appendGainMap (jpegr.cpp:951-1130): 0 ok, else the reference's status.  The file is written straight into the caller's buffer
+// (the two compressed streams are megabytes: one copy each, no intermediate container); *size is set whenever the size is known,
+// ERROR_INSUFFICIENT_RESOURCE when cap is smaller (Write() running past maxLength, jpegr.cpp:46-61).
+int append_gainmap_to(const uint8_t* primary_in, size_t n1, const uint8_t* gainmap, size_t n2, const uint8_t* exif, size_t exif_len,
+                      const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata_t& md, uint8_t* dst, size_t cap, size_t* size) {
   if (strncmp(md.version, "1.0", sizeof(md.version)) != 0) return UHDR_HIP_ERROR_BAD_METADATA;                  // :961-964
   if (md.maxContentBoost < md.minContentBoost) return UHDR_HIP_ERROR_BAD_METADATA;
   if (md.hdrCapacityMax < md.hdrCapacityMin || md.hdrCapacityMin < 1.0f) return UHDR_HIP_ERROR_BAD_METADATA;
@@ -443,39 +445,61 @@ int append_gainmap(const uint8_t* primary_in, size_t n1, const uint8_t* gainmap,
   const uint8_t* in_exif;
   size_t in_exif_len;
   if (!extract_exif(primary_in, n1, &exif_pos, &in_exif, &in_exif_len)) return UHDR_HIP_ERROR_DECODE_ERROR;
-  std::vector<uint8_t> stripped;
-  const uint8_t* primary = primary_in;
+  // the primary image without its SOI, and without the EXIF segment if it has one (copyJpegWithoutExif :63-73): one or two pieces
+  const uint8_t* piece[2] = {primary_in + 2, nullptr};
+  size_t piece_len[2] = {n1 - 2, 0};
   if (exif_pos >= 0) {
     if (exif != nullptr) return UHDR_HIP_ERROR_MULTIPLE_EXIFS_RECEIVED;
     if ((size_t)exif_pos + in_exif_len > n1 || exif_pos < 4) return UHDR_HIP_ERROR_DECODE_ERROR;   // the reference would read out of bounds
-    stripped.assign(primary_in, primary_in + exif_pos - 4);                                          // copyJpegWithoutExif :63-73
-    stripped.insert(stripped.end(), primary_in + exif_pos + in_exif_len, primary_in + n1);
-    primary = stripped.data(); n1 = stripped.size();
+    if (exif_pos - 4 < 2) return UHDR_HIP_ERROR_DECODE_ERROR;
+    piece_len[0] = (size_t)exif_pos - 4 - 2;
+    piece[1] = primary_in + exif_pos + in_exif_len; piece_len[1] = n1 - (size_t)exif_pos - in_exif_len;
+    n1 = 2 + piece_len[0] + piece_len[1];
     exif = in_exif; exif_len = in_exif_len;
   }
-  auto segment = [&](unsigned marker, size_t payload) { out.push_back(0xFF); out.push_back((uint8_t)marker); be16(out, (unsigned)(payload + 2)); };
-  out.clear();
-  out.push_back(0xFF); out.push_back(0xD8);
-  if (exif != nullptr) { segment(0xE1, exif_len); out.insert(out.end(), exif, exif + exif_len); }
-  segment(0xE1, (size_t)xp_len - 2);
-  out.insert(out.end(), kNs, kNs + sizeof(kNs));
-  out.insert(out.end(), xp.begin(), xp.end());
-  if (icc != nullptr && icc_len > 0) { segment(0xE2, icc_len); out.insert(out.end(), icc, icc + icc_len); }
+  std::vector<uint8_t> head, mid;
+  auto segment = [](std::vector<uint8_t>& o, unsigned marker, size_t payload) { o.push_back(0xFF); o.push_back((uint8_t)marker); be16(o, (unsigned)(payload + 2)); };
+  head.reserve(exif_len + icc_len + xp.size() + 256);
+  head.push_back(0xFF); head.push_back(0xD8);
+  if (exif != nullptr) { segment(head, 0xE1, exif_len); head.insert(head.end(), exif, exif + exif_len); }
+  segment(head, 0xE1, (size_t)xp_len - 2);
+  head.insert(head.end(), kNs, kNs + sizeof(kNs));
+  head.insert(head.end(), xp.begin(), xp.end());
+  if (icc != nullptr && icc_len > 0) { segment(head, 0xE2, icc_len); head.insert(head.end(), icc, icc + icc_len); }
   {
-    const int pos = (int)out.size(), length = 2 + 86;
+    const int pos = (int)head.size(), length = 2 + 86;
     const int primary_size = pos + length + (int)n1;
     std::vector<uint8_t> mpf;
     mpf_segment(primary_size, 0, secondary_size, primary_size - pos - 8, mpf);
-    segment(0xE2, 86);
-    out.insert(out.end(), mpf.begin(), mpf.end());
+    segment(head, 0xE2, 86);
+    head.insert(head.end(), mpf.begin(), mpf.end());
   }
-  out.insert(out.end(), primary + 2, primary + n1);
-  out.push_back(0xFF); out.push_back(0xD8);
-  segment(0xE1, (size_t)xs_len - 2);
-  out.insert(out.end(), kNs, kNs + sizeof(kNs));
-  out.insert(out.end(), xs.begin(), xs.end());
-  out.insert(out.end(), gainmap + 2, gainmap + n2);
+  mid.push_back(0xFF); mid.push_back(0xD8);
+  segment(mid, 0xE1, (size_t)xs_len - 2);
+  mid.insert(mid.end(), kNs, kNs + sizeof(kNs));
+  mid.insert(mid.end(), xs.begin(), xs.end());
+
+  const size_t total = head.size() + piece_len[0] + piece_len[1] + mid.size() + (n2 - 2);
+  *size = total;
+  if (dst == nullptr || cap < total) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  uint8_t* w = dst;
+  memcpy(w, head.data(), head.size()); w += head.size();
+  memcpy(w, piece[0], piece_len[0]); w += piece_len[0];
+  if (piece_len[1]) { memcpy(w, piece[1], piece_len[1]); w += piece_len[1]; }
+  memcpy(w, mid.data(), mid.size()); w += mid.size();
+  memcpy(w, gainmap + 2, n2 - 2);
   return UHDR_HIP_NO_ERROR;
+}
+
+// the same into a byte vector (tests, fuzzing)
+int append_gainmap(const uint8_t* primary, size_t n1, const uint8_t* gainmap, size_t n2, const uint8_t* exif, size_t exif_len,
+                   const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata_t& md, std::vector<uint8_t>& out) {
+  size_t total = 0;
+  out.clear();
+  int rc = append_gainmap_to(primary, n1, gainmap, n2, exif, exif_len, icc, icc_len, md, nullptr, 0, &total);
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return rc;
+  out.resize(total);
+  return append_gainmap_to(primary, n1, gainmap, n2, exif, exif_len, icc, icc_len, md, out.data(), out.size(), &total);
 }
 
 }  // namespace jpegr

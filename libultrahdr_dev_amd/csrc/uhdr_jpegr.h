@@ -26,6 +26,9 @@ int append_gainmap(const uint8_t* primary, size_t n1, const uint8_t* gainmap, si
                    const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata& md, std::vector<uint8_t>& out);
 void first_packets(const uint8_t* jpg, size_t n, size_t* xmp_off, size_t* xmp_len, size_t* exif_off, size_t* exif_len, size_t* icc_off,
                    size_t* icc_len);
+// ... written straight into dst[0, cap); *size receives the file size (ERROR_INSUFFICIENT_RESOURCE when cap is smaller)
+int append_gainmap_to(const uint8_t* primary, size_t n1, const uint8_t* gainmap, size_t n2, const uint8_t* exif, size_t exif_len,
+                      const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata& md, uint8_t* dst, size_t cap, size_t* size);
 bool dimensions(const uint8_t* jpg, size_t n, int* w, int* h);
 bool has_valid_header(const uint8_t* jpg, size_t n);   // JpegDecoderHelper::getCompressedImageParameters succeeding
 }  // namespace jpegr

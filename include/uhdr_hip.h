@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define UHDR_HIP_ABI_VERSION 2
+#define UHDR_HIP_ABI_VERSION 3
 
 /* ultrahdr_color_gamut, ultrahdr.h:36-42 */
 #define UHDR_HIP_CG_UNSPECIFIED (-1)

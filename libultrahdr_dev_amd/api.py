@@ -26,7 +26,7 @@ ERROR_NO_IMAGES_FOUND, ERROR_MULTIPLE_EXIFS_RECEIVED = -20006, -20007
 MEM_HOST, MEM_DEVICE = 0, 1
 APPLY_FAST, APPLY_EXACT, APPLY_LUT = 0, 1, 2
 GENERATE_EXACT, GENERATE_LUT, GENERATE_UNFILTERED = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLT_MAX = 3.4028234663852886e38
 
 

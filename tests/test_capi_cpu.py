@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(api):
     for n in names:
         assert hasattr(lib, n), "libuhdr_hip.so does not export %s" % n
         assert n in api.SIGNATURES, "python binding lacks %s" % n
-    assert lib.uhdr_hip_abi_version() == 2
+    assert lib.uhdr_hip_abi_version() == api.ABI_VERSION == 3
     out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH]).decode()
     exported = set(re.findall(r" T (uhdr_hip_\w+)", out))
     assert exported == set(names), exported ^ set(names)
@@ -157,3 +157,14 @@ def test_synthetic_frames_match_the_survey_lcg(orc):
         p, y = synth.lcg_frame(w, h, seed, device="cpu")
         op, oy = orc.lcg_frame(w, h, seed)
         assert np.array_equal(p.numpy().view(np.uint16), op) and np.array_equal(y.numpy(), oy)
+
+
+def test_graft_entry_build_runs():
+    """the driver's "does it build" check: __graft_entry__.build() compiles the library, the shim and the checkers and loads the library"""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    g = importlib.import_module("__graft_entry__")
+    g.build()

@@ -252,6 +252,15 @@ int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_forma
                           size_t dest_capacity, uhdr_hip_image_t* dest, uhdr_hip_metadata_t* metadata, int apply_mode,
                           int mem_space, void* stream);
 
+/* The same for n files in one call (no reference counterpart: the reference decodes one file per call).  A JPEG decode on the
+ * device is latency-bound, so the 2 n JPEGs of the call advance in lock step on a pool of streams and n files take little longer
+ * than one.  Arrays are indexed by file; dest_data[i] (memory space mem_space) needs dest_capacity[i] bytes; status (optional)
+ * receives each file's status, the return value is the first one that is not NO_ERROR; a file that fails does not disturb the
+ * others.  dest_data[i] == NULL asks for file i's size only (ERROR_INSUFFICIENT_RESOURCE, dests[i] filled). */
+int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* jpegr_size, int output_format, float max_display_boost,
+                                void* const* dest_data, const size_t* dest_capacity, uhdr_hip_image_t* dests,
+                                uhdr_hip_metadata_t* metadata, int* status, int apply_mode, int mem_space, void* stream);
+
 /* JpegR::appendGainMap (lib/src/jpegr.cpp:951-1130): primary JPEG + gain-map JPEG + metadata -> JPEG/R container (XMP packets of
  * jpegrutils.cpp:547-611, MPF segment of multipictureformat.cpp:30-92).  exif / icc: payloads of an APP1 / APP2 segment to add, or
  * NULL; an EXIF segment found inside primary_jpeg moves in front of the XMP segment (and ERROR_MULTIPLE_EXIFS_RECEIVED if exif is

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/uhdr_hip.h"
@@ -44,7 +45,10 @@ struct DeviceState {
   // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
   void* stage[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  hipStream_t aux = nullptr;  // second stream of uhdr_hip_jpegr_decode: the gain map is decompressed beside the primary image
+  // uhdr_hip_jpegr_decode[_batch]: a pool of streams the JPEGs of a call are decompressed on side by side, and their buffers
+  std::vector<hipStream_t> streams;
+  std::vector<void*> pool;
+  std::vector<size_t> pool_bytes;
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
 std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
@@ -479,7 +483,8 @@ int uhdr_hip_shutdown(void) {
     (void)hipDeviceSynchronize();
     for (auto& t : kv.second.idw) (void)hipFree(t.second);
     if (kv.second.lut) (void)hipFree(kv.second.lut);
-    if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
+    for (hipStream_t q : kv.second.streams) (void)hipStreamDestroy(q);
+    for (void* q : kv.second.pool) if (q) (void)hipFree(q);
     for (int i = 0; i < 12; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
   }
@@ -657,122 +662,213 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
 }  // extern "C"
 
 namespace {
-// Both JPEGs of a JPEG/R file decompressed at once into device planes: the primary image on `s`, the gain map on the device's
-// auxiliary stream, advancing in lock step (jpeg::decode_device_multi) so that their synchronisation rounds overlap.  Returns with
-// both streams idle.  0 ok, else UHDR_HIP_ERROR_DECODE_ERROR / UNKNOWN_ERROR.
-int decode_pair_device(DeviceState* st, const uint8_t* const jpg[2], const jpeg::DecInfo info[2], uint8_t* const out[2], hipStream_t s) {
-  std::lock_guard<std::mutex> lk(g_host_mu);   // workspace slot 7 is the single-image decoder's too
-  if (st->aux == nullptr) HIP_TRY(hipStreamCreateWithFlags(&st->aux, hipStreamNonBlocking));
-  const hipStream_t streams[2] = {s, st->aux};
-  const int slot[2] = {7, 11};
-  jpeg::DecLayout l[2];
-  uint8_t* ws[2];
-  jpeg::DecPlane planes[2][3];
-  memset(planes, 0, sizeof(planes));
-  auto mk = [](uint8_t* p, size_t pw, size_t ph) {
-    jpeg::DecPlane q;
-    q.p = p; q.w = (int)pw; q.h = (int)ph; q.stride = (int)pw;
-    q.aligned8 = (reinterpret_cast<uintptr_t>(p) % 8 == 0 && pw % 8 == 0) ? 1 : 0;
-    return q;
-  };
-  int rc;
-  for (int k = 0; k < 2; ++k) {
-    const size_t bytes = jpeg::dec_workspace_bytes(info[k], &l[k]);
-    if ((rc = stage_reserve(st, slot[k], bytes)) != 0) return rc;
-    ws[k] = static_cast<uint8_t*>(st->stage[slot[k]]);
-    HIP_TRY(hipMemcpyAsync(ws[k] + l[k].src, jpg[k] + info[k].scan_offset, info[k].scan_bytes, hipMemcpyHostToDevice, streams[k]));
-    const size_t w = (size_t)info[k].w, h = (size_t)info[k].h, luma = w * h, chroma = luma / 4;
-    planes[k][0] = mk(out[k], w, h);
-    if (!info[k].gray) { planes[k][1] = mk(out[k] + luma, w / 2, h / 2); planes[k][2] = mk(out[k] + luma + chroma, w / 2, h / 2); }
-  }
-  const jpeg::DecInfo* infos[2] = {&info[0], &info[1]};
-  jpeg::DecPlane (*pl[2])[3] = {&planes[0], &planes[1]};
-  hipError_t herr = hipSuccess;
-  const int drc = jpeg::decode_device_multi(2, infos, l, ws, pl, streams, &herr);
-  if (drc > 0) { set_err("uhdr_hip_jpegr_decode", herr); return UHDR_HIP_UNKNOWN_ERROR; }
-  return drc < 0 ? UHDR_HIP_ERROR_DECODE_ERROR : UHDR_HIP_NO_ERROR;
-}
-}  // namespace
-
-extern "C" {
-
-// JpegR::decodeJPEGR (jpegr.cpp:655-822), HDR outputs
-int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_format, float max_display_boost, void* dest_data,
-                          size_t dest_capacity, uhdr_hip_image_t* dest, uhdr_hip_metadata_t* metadata, int apply_mode,
-                          int mem_space, void* stream) {
-  if (jpegr == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                   // :658-661
-  if (dest == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                    // :662-665
-  if (max_display_boost < 1.0f) return UHDR_HIP_ERROR_INVALID_DISPLAY_BOOST;                             // :666-669
-  if (output_format < UHDR_HIP_OUTPUT_SDR || output_format > UHDR_HIP_OUTPUT_HDR_LINEAR_RGB_10BIT) return UHDR_HIP_ERROR_INVALID_OUTPUT_FORMAT;
+// what the host learns from one JPEG/R file before anything is launched: the checks and the parsing of decodeJPEGR up to its
+// first decompressImage call (jpegr.cpp:655-699) plus what it reads from the decoders afterwards (XMP :756-760, ICC :796-801)
+struct JpegrFile {
+  const uint8_t* jpg[2] = {nullptr, nullptr};   // primary image, gain map
+  size_t len[2] = {0, 0};
+  jpeg::DecInfo info[2];
+  uhdr_hip_metadata_t md;
+  int gamut = UHDR_HIP_CG_UNSPECIFIED;
+};
+int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, JpegrFile* f) {
   const uint8_t* file = static_cast<const uint8_t*>(jpegr);
   jpegr::Range img[2];
   const int found = jpegr::find_images(file, jpegr_size, img);                                          // :823-876
   if (found == 0) return UHDR_HIP_ERROR_NO_IMAGES_FOUND;
   if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
   if (output_format == UHDR_HIP_OUTPUT_SDR) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
-  const uint8_t* pj = file + img[0].begin;
-  const uint8_t* gj = file + img[1].begin;
-
-  // the two headers, parsed once (jpeg_read_header of either decompressImage call, :690-694 / :731-733)
-  jpeg::DecInfo info[2];
-  for (int k = 0; k < 2; ++k) {
-    const int prc = jpeg::parse_header(k ? gj : pj, img[k].len, &info[k]);
+  for (int k = 0; k < 2; ++k) {   // the two headers, parsed once (jpeg_read_header of either decompressImage call, :690-694 / :731-733)
+    f->jpg[k] = file + img[k].begin; f->len[k] = img[k].len;
+    const int prc = jpeg::parse_header(f->jpg[k], f->len[k], &f->info[k]);
     if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
-    if (prc != 0 || info[k].w > 8192 || info[k].h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;
+    if (prc != 0 || f->info[k].w > 8192 || f->info[k].h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;
   }
-  if (info[0].gray) return UHDR_HIP_ERROR_DECODE_ERROR;   // the primary image must come back as three planes
-  int rc;
+  if (f->info[0].gray) return UHDR_HIP_ERROR_DECODE_ERROR;   // the primary image must come back as three planes
   // metadata from the gain map's XMP packet (:756-760)
-  uhdr_hip_metadata_t md;
   const uint8_t* xmp = nullptr;
   size_t xmp_len = 0;
   static const char kXmpNs[] = "http://ns.adobe.com/xap/1.0/";
-  if (!jpegr::find_app_segment(gj, img[1].len, 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) || !jpegr::metadata_from_xmp(xmp, xmp_len, &md))
+  if (!jpegr::find_app_segment(f->jpg[1], f->len[1], 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) || !jpegr::metadata_from_xmp(xmp, xmp_len, &f->md))
     return UHDR_HIP_ERROR_METADATA_ERROR;
-  if (metadata != nullptr) *metadata = md;
   const uint8_t* icc = nullptr;
   size_t icc_len = 0;
   static const char kIccSig[] = "ICC_PROFILE";
-  const int gamut = jpegr::find_app_segment(pj, img[0].len, 0xE2, kIccSig, sizeof(kIccSig), &icc, &icc_len) ? jpegr::gamut_from_icc(icc, icc_len)
-                                                                                                           : UHDR_HIP_CG_UNSPECIFIED;
-  const size_t w = (size_t)info[0].w, h = (size_t)info[0].h, gw = (size_t)info[1].w, gh = (size_t)info[1].h;
-  dest->width = w; dest->height = h; dest->colorGamut = gamut;
-  const size_t out_bytes = w * h * apply_bpp(output_format);
-  if (dest_data == nullptr || dest_capacity < out_bytes) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  f->gamut = jpegr::find_app_segment(f->jpg[0], f->len[0], 0xE2, kIccSig, sizeof(kIccSig), &icc, &icc_len) ? jpegr::gamut_from_icc(icc, icc_len)
+                                                                                                             : UHDR_HIP_CG_UNSPECIFIED;
+  return UHDR_HIP_NO_ERROR;
+}
+
+// grow-only device buffers / streams of the JPEG/R decode entry points (guarded by g_jpegr_mu)
+int pool_reserve(DeviceState* st, size_t idx, size_t bytes) {
+  if (st->pool.size() <= idx) { st->pool.resize(idx + 1, nullptr); st->pool_bytes.resize(idx + 1, 0); }
+  if (bytes == 0) bytes = 256;
+  if (st->pool_bytes[idx] >= bytes) return UHDR_HIP_NO_ERROR;
+  if (st->pool[idx]) HIP_TRY(hipFree(st->pool[idx]));
+  st->pool[idx] = nullptr; st->pool_bytes[idx] = 0;
+  HIP_TRY(hipMalloc(&st->pool[idx], bytes));
+  st->pool_bytes[idx] = bytes;
+  return UHDR_HIP_NO_ERROR;
+}
+constexpr size_t kDecodeStreams = 8;
+}  // namespace
+
+extern "C" {
+
+// JpegR::decodeJPEGR (jpegr.cpp:655-822), HDR outputs, for n files at once.  A JPEG decode on the device is latency-bound (tens of
+// synchronisation rounds of one lane's work each, uhdr_jpeg_dec.hip), so the 2 n images advance in lock step on a pool of streams
+// and their rounds overlap: n files take little longer than one.
+int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* jpegr_size, int output_format, float max_display_boost,
+                                void* const* dest_data, const size_t* dest_capacity, uhdr_hip_image_t* dests, uhdr_hip_metadata_t* metadata,
+                                int* status, int apply_mode, int mem_space, void* stream) {
+  if (n < 0 || (n > 0 && (jpegr == nullptr || jpegr_size == nullptr || dests == nullptr))) return UHDR_HIP_ERROR_BAD_PTR;
+  if (max_display_boost < 1.0f) return UHDR_HIP_ERROR_INVALID_DISPLAY_BOOST;                             // :666-669
+  if (output_format < UHDR_HIP_OUTPUT_SDR || output_format > UHDR_HIP_OUTPUT_HDR_LINEAR_RGB_10BIT) return UHDR_HIP_ERROR_INVALID_OUTPUT_FORMAT;
+  std::vector<JpegrFile> files((size_t)n);
+  std::vector<int> st_((size_t)n, UHDR_HIP_NO_ERROR);
+  std::vector<size_t> out_bytes((size_t)n, 0);
+  int live = 0;
+  for (int i = 0; i < n; ++i) {
+    if (jpegr[i] == nullptr) { st_[i] = UHDR_HIP_ERROR_BAD_PTR; continue; }
+    if ((st_[i] = parse_jpegr_file(jpegr[i], jpegr_size[i], output_format, &files[i])) != UHDR_HIP_NO_ERROR) continue;
+    if (metadata != nullptr) metadata[i] = files[i].md;
+    dests[i].width = (size_t)files[i].info[0].w; dests[i].height = (size_t)files[i].info[0].h; dests[i].colorGamut = files[i].gamut;
+    out_bytes[i] = dests[i].width * dests[i].height * apply_bpp(output_format);
+    if (dest_data == nullptr || dest_capacity == nullptr || dest_data[i] == nullptr || dest_capacity[i] < out_bytes[i]) { st_[i] = UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE; continue; }
+    ++live;
+  }
+  auto result = [&]() {
+    int first = UHDR_HIP_NO_ERROR;
+    for (int i = 0; i < n; ++i) { if (status) status[i] = st_[i]; if (first == UHDR_HIP_NO_ERROR) first = st_[i]; }
+    return first;
+  };
+  if (live == 0) return result();
 
   DeviceState* st = nullptr;
+  int rc;
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lk(g_jpegr_mu);
   const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
-  const size_t ybytes = w * h + 2 * (w * h / 4), gbytes = gw * gh * (info[1].gray ? 1 : 2);
-  if ((rc = stage_reserve(st, 8, ybytes + 64)) != 0) return rc;
-  if ((rc = stage_reserve(st, 9, gbytes + 64)) != 0) return rc;
-  if (host && (rc = stage_reserve(st, 10, out_bytes)) != 0) return rc;
-  {
-    const uint8_t* jpgs[2] = {pj, gj};
-    uint8_t* outs[2] = {static_cast<uint8_t*>(st->stage[8]), static_cast<uint8_t*>(st->stage[9])};
-    if ((rc = decode_pair_device(st, jpgs, info, outs, s)) != UHDR_HIP_NO_ERROR) return rc == UHDR_HIP_UNKNOWN_ERROR ? rc : UHDR_HIP_ERROR_DECODE_ERROR;
+  while (st->streams.size() < kDecodeStreams) {
+    hipStream_t q = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    st->streams.push_back(q);
   }
-  uhdr_hip_image_t ydesc, gdesc;
-  memset(&ydesc, 0, sizeof(ydesc));
-  memset(&gdesc, 0, sizeof(gdesc));
-  ydesc.data = st->stage[8]; ydesc.width = w; ydesc.height = h; ydesc.luma_stride = w;
-  ydesc.chroma_data = static_cast<uint8_t*>(st->stage[8]) + w * h; ydesc.chroma_stride = w / 2; ydesc.pixelFormat = UHDR_HIP_PIX_FMT_YUV420;
-  gdesc.data = st->stage[9]; gdesc.width = gw; gdesc.height = gh; gdesc.luma_stride = gw; gdesc.colorGamut = UHDR_HIP_CG_UNSPECIFIED;
+  // per file: two decoder workspaces, two sets of planes, (host callers) the rendition before it goes down
+  std::vector<const jpeg::DecInfo*> infos;
+  std::vector<jpeg::DecLayout> layouts;
+  std::vector<uint8_t*> wss;
+  std::vector<jpeg::DecPlane> planes;       // 3 per image
+  std::vector<hipStream_t> streams;
+  std::vector<int> owner;
+  std::vector<const uint8_t*> srcs;         // the entropy-coded segment of each image in the caller's file
+  infos.reserve(2 * live); layouts.reserve(2 * live); wss.reserve(2 * live); planes.reserve(6 * live);
+  auto mk = [](uint8_t* p, size_t pw, size_t ph) {
+    jpeg::DecPlane q;
+    q.p = p; q.w = (int)pw; q.h = (int)ph; q.stride = (int)pw;
+    q.aligned8 = (reinterpret_cast<uintptr_t>(p) % 8 == 0 && pw % 8 == 0) ? 1 : 0;
+    return q;
+  };
+  for (int i = 0; i < n; ++i) {
+    if (st_[i] != UHDR_HIP_NO_ERROR) continue;
+    const JpegrFile& f = files[i];
+    for (int k = 0; k < 2; ++k) {
+      const size_t w = (size_t)f.info[k].w, h = (size_t)f.info[k].h, luma = w * h, chroma = luma / 4;
+      jpeg::DecLayout l;
+      const size_t bytes = jpeg::dec_workspace_bytes(f.info[k], &l);
+      if ((rc = pool_reserve(st, 5 * (size_t)i + k, bytes)) != 0) return rc;
+      if ((rc = pool_reserve(st, 5 * (size_t)i + 2 + k, (f.info[k].gray ? luma : luma + 2 * chroma) + 64)) != 0) return rc;
+      uint8_t* ws = static_cast<uint8_t*>(st->pool[5 * (size_t)i + k]);
+      uint8_t* out = static_cast<uint8_t*>(st->pool[5 * (size_t)i + 2 + k]);
+      const hipStream_t q = st->streams[infos.size() % kDecodeStreams];
+      infos.push_back(&f.info[k]); layouts.push_back(l); wss.push_back(ws); streams.push_back(q); owner.push_back(i);
+      srcs.push_back(f.jpg[k] + f.info[k].scan_offset);
+      planes.push_back(mk(out, w, h));
+      planes.push_back(f.info[k].gray ? jpeg::DecPlane{} : mk(out + luma, w / 2, h / 2));
+      planes.push_back(f.info[k].gray ? jpeg::DecPlane{} : mk(out + luma + chroma, w / 2, h / 2));
+    }
+    if (host && (rc = pool_reserve(st, 5 * (size_t)i + 4, out_bytes[i])) != 0) return rc;
+  }
+  const int nimg = (int)infos.size();
+  std::vector<jpeg::DecPlane (*)[3]> pl((size_t)nimg);
+  for (int k = 0; k < nimg; ++k) pl[k] = reinterpret_cast<jpeg::DecPlane (*)[3]>(&planes[3 * (size_t)k]);
+  std::vector<int> image_rc((size_t)nimg, 0);
+  hipError_t herr = hipSuccess;
+  int drc = 0;
+  // A decode is ~70 kernel launches and the host needs ~5 us for each: one host thread cannot keep more than two images' streams
+  // busy.  The files of a batch are therefore driven by up to kDecodeStreams / 2 host threads, two images (one file) in lock step each.
+  const int nthreads = std::min<int>(nimg / 2, (int)kDecodeStreams / 2);
+  if (nthreads <= 1) {
+    for (int g = 0; g < nimg; ++g)
+      HIP_TRY(hipMemcpyAsync(wss[g] + layouts[g].src, srcs[g], infos[g]->scan_bytes, hipMemcpyHostToDevice, streams[g]));
+    drc = jpeg::decode_device_multi(nimg, infos.data(), layouts.data(), wss.data(), pl.data(), streams.data(), &herr, image_rc.data());
+  } else {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::vector<std::thread> workers;
+    std::vector<int> trc((size_t)nthreads, 0);
+    std::vector<hipError_t> terr((size_t)nthreads, hipSuccess);
+    for (int t = 0; t < nthreads; ++t)
+      workers.emplace_back([&, t]() {
+        if (hipSetDevice(dev) != hipSuccess) { trc[t] = 1; terr[t] = hipErrorInvalidDevice; return; }
+        // thread t takes files t, t + nthreads, ... (images 2f, 2f + 1), always on its own two streams
+        std::vector<const jpeg::DecInfo*> ti; std::vector<jpeg::DecLayout> tl; std::vector<uint8_t*> tw; std::vector<jpeg::DecPlane (*)[3]> tp;
+        std::vector<hipStream_t> ts; std::vector<int> idx;
+        for (int f = t; 2 * f + 1 < nimg; f += nthreads)
+          for (int k = 0; k < 2; ++k) {
+            const int g = 2 * f + k;
+            ti.push_back(infos[g]); tl.push_back(layouts[g]); tw.push_back(wss[g]); tp.push_back(pl[g]); ts.push_back(st->streams[2 * (size_t)t + k]); idx.push_back(g);
+          }
+        // uploads (pageable host memory: each copy occupies the calling thread) happen here, side by side with the other threads'
+        for (size_t q = 0; q < idx.size(); ++q)
+          if (hipMemcpyAsync(tw[q] + tl[q].src, srcs[idx[q]], ti[q]->scan_bytes, hipMemcpyHostToDevice, ts[q]) != hipSuccess) { trc[t] = 1; terr[t] = hipGetLastError(); return; }
+        std::vector<int> lrc(idx.size(), 0);
+        trc[t] = jpeg::decode_device_multi((int)idx.size(), ti.data(), tl.data(), tw.data(), tp.data(), ts.data(), &terr[t], lrc.data());
+        for (size_t q = 0; q < idx.size(); ++q) image_rc[idx[q]] = lrc[q];
+      });
+    for (auto& w : workers) w.join();
+    for (int t = 0; t < nthreads; ++t) {
+      if (trc[t] > 0) { drc = 1; herr = terr[t]; }
+      else if (trc[t] < 0 && drc == 0) drc = -1;
+    }
+  }
+  if (drc > 0) { set_err("uhdr_hip_jpegr_decode", herr); return UHDR_HIP_UNKNOWN_ERROR; }
+  for (int k = 0; k < nimg; ++k)
+    if (image_rc[k] != 0) st_[owner[k]] = UHDR_HIP_ERROR_DECODE_ERROR;
+
   // :796-801: the decoded planes as a YUV420 image with the ICC gamut; the gain map is the first plane of its JPEG
-  ydesc.colorGamut = gamut;
-  uhdr_hip_image_t gimg = gdesc;
-  gimg.chroma_data = nullptr; gimg.chroma_stride = 0; gimg.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
-  uhdr_hip_image_t ddev = *dest;
-  ddev.data = host ? st->stage[10] : dest_data;
-  rc = uhdr_hip_apply_gainmap(&ydesc, &gimg, &md, output_format, max_display_boost, &ddev, apply_mode, UHDR_HIP_MEM_DEVICE, stream);
-  if (rc != UHDR_HIP_NO_ERROR) return rc;
-  dest->data = dest_data;
-  dest->width = ddev.width; dest->height = ddev.height;
-  if (host) HIP_TRY(hipMemcpyAsync(dest_data, ddev.data, out_bytes, hipMemcpyDeviceToHost, s));
+  for (int i = 0; i < n; ++i) {
+    if (st_[i] != UHDR_HIP_NO_ERROR) continue;
+    const JpegrFile& f = files[i];
+    const size_t w = (size_t)f.info[0].w, h = (size_t)f.info[0].h, gw = (size_t)f.info[1].w, gh = (size_t)f.info[1].h;
+    uhdr_hip_image_t ydesc, gimg;
+    memset(&ydesc, 0, sizeof(ydesc));
+    memset(&gimg, 0, sizeof(gimg));
+    uint8_t* yp = static_cast<uint8_t*>(st->pool[5 * (size_t)i + 2]);
+    ydesc.data = yp; ydesc.width = w; ydesc.height = h; ydesc.luma_stride = w; ydesc.colorGamut = f.gamut;
+    ydesc.chroma_data = yp + w * h; ydesc.chroma_stride = w / 2; ydesc.pixelFormat = UHDR_HIP_PIX_FMT_YUV420;
+    gimg.data = st->pool[5 * (size_t)i + 3]; gimg.width = gw; gimg.height = gh; gimg.luma_stride = gw; gimg.colorGamut = UHDR_HIP_CG_UNSPECIFIED;
+    gimg.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
+    uhdr_hip_image_t ddev = dests[i];
+    ddev.data = host ? st->pool[5 * (size_t)i + 4] : dest_data[i];
+    st_[i] = uhdr_hip_apply_gainmap(&ydesc, &gimg, &f.md, output_format, max_display_boost, &ddev, apply_mode, UHDR_HIP_MEM_DEVICE, stream);
+    if (st_[i] != UHDR_HIP_NO_ERROR) continue;
+    dests[i].data = dest_data[i];
+    dests[i].width = ddev.width; dests[i].height = ddev.height;
+    if (host) HIP_TRY(hipMemcpyAsync(dest_data[i], ddev.data, out_bytes[i], hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(hipStreamSynchronize(s));
-  return UHDR_HIP_NO_ERROR;
+  return result();
+}
+
+int uhdr_hip_jpegr_decode(const void* jpegr, size_t jpegr_size, int output_format, float max_display_boost, void* dest_data,
+                          size_t dest_capacity, uhdr_hip_image_t* dest, uhdr_hip_metadata_t* metadata, int apply_mode,
+                          int mem_space, void* stream) {
+  if (jpegr == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                   // :658-661
+  if (dest == nullptr) return UHDR_HIP_ERROR_BAD_PTR;                                                    // :662-665
+  return uhdr_hip_jpegr_decode_batch(1, &jpegr, &jpegr_size, output_format, max_display_boost, &dest_data, &dest_capacity, dest, metadata, nullptr,
+                                     apply_mode, mem_space, stream);
 }
 
 int uhdr_hip_jpegr_append_gainmap(const void* primary_jpeg, size_t primary_size, const void* gainmap_jpeg, size_t gainmap_size,

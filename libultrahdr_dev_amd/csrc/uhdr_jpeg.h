@@ -98,9 +98,10 @@ int parse_header(const uint8_t* jpg, size_t n, DecInfo* info);
 size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l);
 // the entropy-coded segment must already sit at ws + l.src; 0 ok, -1 corrupt stream, 1 HIP error (*herr)
 int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr);
-// the same for n = 1 or 2 images advancing in lock step, image k with its own workspace on streams[k] (their synchronisation rounds overlap)
+// the same for n images advancing in lock step, image k with its own workspace on streams[k] (their latency-bound synchronisation
+// rounds overlap); image_rc (optional): 0 / -1 per image
 int decode_device_multi(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3],
-                        const hipStream_t streams[], hipError_t* herr);
+                        const hipStream_t streams[], hipError_t* herr, int* image_rc);
 
 }  // namespace jpeg
 }  // namespace uhdr

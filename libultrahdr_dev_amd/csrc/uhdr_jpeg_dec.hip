@@ -625,38 +625,49 @@ struct DecRun {
 #undef JD_TRY
 };
 
-// Runs the whole decoder for up to two images, image k on streams[k] (synchronises: the number of synchronisation rounds is data
-// dependent).  The entropy-coded segment of image k must already sit at ws[k] + l[k].src.  Returns 0, -1 (a corrupt stream) or 1
-// (HIP error in *herr).
+// Runs the whole decoder for n images advancing in lock step, image k with its own workspace on streams[k] (streams may repeat:
+// images on one stream run one after the other, images on different streams side by side).  Synchronises: the number of
+// synchronisation rounds is data dependent.  The entropy-coded segment of image k must already sit at ws[k] + l[k].src.
+// image_rc[k] (optional) receives 0 or -1 (corrupt stream) per image; returns 0, -1 (some image corrupt) or 1 (HIP error in *herr).
 int decode_device_multi(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3],
-                        const hipStream_t streams[], hipError_t* herr) {
-  DecRun run[2];
-  if (n < 1 || n > 2) return -1;
-  auto fail = [&](int rc, int k) { if (rc > 0) *herr = run[k].herr; for (int q = 0; q < n; ++q) (void)hipStreamSynchronize(streams[q]); return rc; };
+                        const hipStream_t streams[], hipError_t* herr, int* image_rc) {
+  if (n < 1) return -1;
+  std::vector<DecRun> run((size_t)n);
+  std::vector<int> bad((size_t)n, 0);
+  auto fail = [&](int k) { *herr = run[k].herr; for (int q = 0; q < n; ++q) (void)hipStreamSynchronize(streams[q]); return 1; };
   int rc;
-  for (int k = 0; k < n; ++k)
-    if ((rc = run[k].begin(*info[k], l[k], ws[k], *planes[k], streams[k])) != 0) return fail(rc, k);
+  for (int k = 0; k < n; ++k) {
+    rc = run[k].begin(*info[k], l[k], ws[k], *planes[k], streams[k]);
+    if (rc > 0) return fail(k);
+    if (rc < 0) { bad[k] = 1; run[k].converged = true; }
+  }
   for (uint32_t batch = 4;; batch = batch < 16u ? batch * 2u : 16u) {
     bool any = false;
     for (int k = 0; k < n; ++k)
-      if (!run[k].converged) { any = true; if ((rc = run[k].rounds(batch)) != 0) return fail(rc, k); }
+      if (!run[k].converged) {
+        any = true;
+        rc = run[k].rounds(batch);
+        if (rc > 0) return fail(k);
+        if (rc < 0) { bad[k] = 1; run[k].converged = true; }
+      }
     if (!any) break;
     // read-backs after everything is enqueued: a copy into pageable memory may block the host until its stream gets there
     for (int k = 0; k < n; ++k)
-      if (!run[k].converged && (rc = run[k].poll()) != 0) return fail(rc, k);
+      if (!run[k].converged && run[k].poll() != 0) return fail(k);
     for (int k = 0; k < n; ++k)
       if (!run[k].converged) {
-        if (hipStreamSynchronize(streams[k]) != hipSuccess) { *herr = hipGetLastError(); return fail(1, k); }
+        if (hipStreamSynchronize(streams[k]) != hipSuccess) { run[k].herr = hipGetLastError(); return fail(k); }
         run[k].converged = run[k].changed == 0u;
-        if (run[k].converged && (rc = run[k].finish()) != 0) return fail(rc, k);   // the epilogue of one runs under the rounds of the other
+        if (run[k].converged && run[k].finish() != 0) return fail(k);   // the epilogue of one runs under the rounds of the others
       }
   }
   for (int k = 0; k < n; ++k)
-    if ((rc = run[k].poll_error()) != 0) return fail(rc, k);
+    if (!bad[k] && run[k].poll_error() != 0) return fail(k);
   int out = 0;
   for (int k = 0; k < n; ++k) {
-    if (hipStreamSynchronize(streams[k]) != hipSuccess || hipGetLastError() != hipSuccess) { *herr = hipErrorUnknown; return fail(1, k); }
-    if (run[k].error) out = -1;
+    if (hipStreamSynchronize(streams[k]) != hipSuccess || hipGetLastError() != hipSuccess) { run[k].herr = hipErrorUnknown; return fail(k); }
+    if (bad[k] || run[k].error) { bad[k] = 1; out = -1; }
+    if (image_rc) image_rc[k] = bad[k] ? -1 : 0;
   }
   return out;
 }
@@ -665,7 +676,7 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
   const DecInfo* infos[1] = {&info};
   uint8_t* wss[1] = {ws};
   DecPlane (*pl[1])[3] = {reinterpret_cast<DecPlane (*)[3]>(planes)};
-  return decode_device_multi(1, infos, &l, wss, pl, &s, herr);
+  return decode_device_multi(1, infos, &l, wss, pl, &s, herr, nullptr);
 }
 
 }  // namespace jpeg

@@ -663,3 +663,54 @@ def test_invalid_argument_matrices_need_no_gpu():
     assert dec(fmt=api.OUTPUT_SDR) == api.ERROR_UNSUPPORTED_FEATURE
     assert dec() == api.ERROR_INSUFFICIENT_RESOURCE and (dest.width, dest.height, dest.colorGamut) == (1280, 720, api.CG_BT709)   # the size query
     assert abs(dmd.maxContentBoost - 10.0) < 1e-4 and dmd.version == b"1.0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [True, False])
+def test_gpu_decode_batch_equals_single_decodes(hip, orc, device):
+    """uhdr_hip_jpegr_decode_batch: files of different sizes, gamuts and qualities (plus a truncated one, an SDR-only JPEG and a size
+    query in the middle) decoded in one call == the CPU restatement per file; the bad ones fail alone"""
+    from oracle import jpegr_oracle as J
+    from tests.gpu_util import dev_empty, stream_ptr, to_host
+    from tests.test_gpu_parity import smooth_frame
+    lib = hip.load()
+    files, want = [], []
+    for (w, h), sg, tf, q in (((640, 480), 0, 1, 95), ((200, 120), 1, 2, 80), ((72, 40), 2, 0, 100), ((1280, 720), 0, 1, 90), ((64, 64), 0, 2, 50)):
+        p010, yuv = smooth_frame(w, h, w + q)
+        files.append(J.encode_api1(p010, yuv, w, h, sg, hip.CG_BT2100, tf, q))
+    files.append(open(SAMPLE, "rb").read())
+    good = len(files)
+    files.insert(2, files[0][:len(files[0]) * 3 // 5])          # truncated: the gain map is gone
+    files.insert(4, J.find_images(files[0]) and files[0][:J.find_images(files[0])[0][1]])   # the primary image alone
+    n = len(files)
+    bufs = [np.frombuffer(f, np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    sizes = (C.c_size_t * n)(*[b.size for b in bufs])
+    dests = (hip.Image * n)()
+    mds = (hip.Metadata * n)()
+    status = (C.c_int * n)()
+    # 1st call: sizes only
+    rc = lib.uhdr_hip_jpegr_decode_batch(n, ptrs, sizes, hip.OUTPUT_HDR_PQ, FLT_MAX, None, None, dests, mds, status, hip.APPLY_EXACT,
+                                         hip.MEM_DEVICE if device else hip.MEM_HOST, None)
+    assert rc != 0
+    st = list(status)
+    assert st[2] in (hip.ERROR_GAIN_MAP_IMAGE_NOT_FOUND, hip.ERROR_NO_IMAGES_FOUND, hip.ERROR_DECODE_ERROR) and st[4] == hip.ERROR_GAIN_MAP_IMAGE_NOT_FOUND
+    assert all(s == hip.ERROR_INSUFFICIENT_RESOURCE for i, s in enumerate(st) if i not in (2, 4))
+    need = [dests[i].width * dests[i].height * 4 if st[i] == hip.ERROR_INSUFFICIENT_RESOURCE else 0 for i in range(n)]
+    need[5] = 0                                                 # ... and leave one of the good files as a size query
+    outs = [(dev_empty(m, 0xCD) if device else np.full(max(m, 1), 0xCD, np.uint8)) if m else None for m in need]
+    optr = (C.c_void_p * n)(*[(o.data_ptr() if device else o.ctypes.data) if o is not None else None for o in outs])
+    ocap = (C.c_size_t * n)(*need)
+    rc = lib.uhdr_hip_jpegr_decode_batch(n, ptrs, sizes, hip.OUTPUT_HDR_PQ, FLT_MAX, optr, ocap, dests, mds, status, hip.APPLY_EXACT,
+                                         hip.MEM_DEVICE if device else hip.MEM_HOST, stream_ptr() if device else None)
+    st = list(status)
+    assert rc == st[2] != 0 and st[4] == hip.ERROR_GAIN_MAP_IMAGE_NOT_FOUND and st[5] == hip.ERROR_INSUFFICIENT_RESOURCE
+    for i in range(n):
+        if i in (2, 4, 5):
+            continue
+        assert st[i] == 0, (i, st[i])
+        ost, ref, ow, oh, gamut, md = J.decode(files[i], orc.OUT_HDR_PQ, FLT_MAX)
+        got = to_host(outs[i], need[i]) if device else outs[i][:need[i]]
+        assert ost == 0 and (dests[i].width, dests[i].height, dests[i].colorGamut) == (ow, oh, gamut) and np.array_equal(got, ref), i
+        assert mds[i].maxContentBoost == np.float32(md["max"])
+    assert good == 6

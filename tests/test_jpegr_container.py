@@ -714,3 +714,36 @@ def test_gpu_decode_batch_equals_single_decodes(hip, orc, device):
         assert ost == 0 and (dests[i].width, dests[i].height, dests[i].colorGamut) == (ow, oh, gamut) and np.array_equal(got, ref), i
         assert mds[i].maxContentBoost == np.float32(md["max"])
     assert good == 6
+
+
+@pytest.mark.gpu
+def test_gpu_decodes_a_file_whose_primary_image_has_restart_intervals(hip, orc, tmp_path):
+    """API-4 around an SDR JPEG written by libjpeg-turbo (Pillow) with DRI / RSTn markers and optimised tables -- what a camera or an
+    editor hands over -- and API-3 deriving the gain map from it: both decode to the restatement's rendition"""
+    import io
+    try:
+        from PIL import Image
+    except ImportError:
+        pytest.skip("no Pillow here")
+    from oracle import jpegr_oracle as J
+    from tests.test_gpu_parity import smooth_frame
+    lib = hip.load()
+    w, h = 640, 480
+    p010, yuv = smooth_frame(w, h, 31)
+    Y = yuv[:w * h].reshape(h, w)
+    U = yuv[w * h:w * h * 5 // 4].reshape(h // 2, w // 2)
+    V = yuv[w * h * 5 // 4:].reshape(h // 2, w // 2)
+    ycc = np.stack([Y, np.repeat(np.repeat(U, 2, 0), 2, 1), np.repeat(np.repeat(V, 2, 0), 2, 1)], -1)
+    b = io.BytesIO()
+    Image.fromarray(ycc, mode="YCbCr").save(b, "JPEG", quality=92, subsampling=2, restart_marker_rows=1, optimize=True)
+    sdr_jpeg = b.getvalue()
+    assert b"\xff\xdd" in sdr_jpeg[:1500] and b"\xff\xd0" in sdr_jpeg
+    want = J.encode_api3(p010, w, h, hip.CG_BT2100, sdr_jpeg, hip.CG_BT709, hip.TF_HLG)
+    assert isinstance(want, bytes)
+    e = _Enc(hip, True)
+    rc, got = e.run("api3", e.p010(p010, w, h, hip.CG_BT2100), sdr_jpeg, hip.CG_BT709, hip.TF_HLG)
+    assert rc == 0 and got == want
+    st, ref, ow, oh, gamut, md = J.decode(got, orc.OUT_HDR_HLG, FLT_MAX)
+    for device in (True, False):
+        rc, dec, dest, _ = _gpu_decode(lib, hip, got, hip.OUTPUT_HDR_HLG, FLT_MAX, hip.APPLY_EXACT, device)
+        assert rc == st == 0 and (dest.width, dest.height, dest.colorGamut) == (w, h, hip.CG_BT709) and np.array_equal(dec, ref)

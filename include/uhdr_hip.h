@@ -241,7 +241,10 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
  * and colorGamut; *metadata (optional) the parsed metadata.  Status values are the reference's: BAD_PTR,
  * INVALID_DISPLAY_BOOST (max_display_boost < 1), INVALID_OUTPUT_FORMAT, NO_IMAGES_FOUND, GAIN_MAP_IMAGE_NOT_FOUND, DECODE_ERROR,
  * METADATA_ERROR, then applyGainMap's own; plus ERROR_INSUFFICIENT_RESOURCE when dest_capacity is too small (*dest is filled)
- * and ERROR_UNSUPPORTED_FEATURE for ULTRAHDR_OUTPUT_SDR (libjpeg's RGB conversion is not built) and for progressive JPEGs. */
+ * and ERROR_UNSUPPORTED_FEATURE for progressive JPEGs.  UHDR_HIP_OUTPUT_SDR (:768-786) returns the primary image alone as
+ * RGBA8888 (4 bytes per pixel, alpha 0xFF) with the arithmetic libjpeg-turbo applies for DECODE_TO_RGBA (fancy 4:2:0 upsampling and
+ * its fixed-point YCbCr -> RGB tables; jpegdecoderhelper.cpp:251-281); the gain map is then not decompressed and its XMP packet is
+ * only read when `metadata` is not NULL, as in the reference. */
 #define UHDR_HIP_ERROR_INVALID_DISPLAY_BOOST (-10008)
 #define UHDR_HIP_ERROR_INVALID_OUTPUT_FORMAT (-10009)
 #define UHDR_HIP_ERROR_DECODE_ERROR (-20002)

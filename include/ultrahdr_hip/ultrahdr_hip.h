@@ -165,7 +165,7 @@ class JpegDecoderHelperHip {
 // ---- the JPEG/R codec: the public members of ultrahdr::JpegR (lib/include/ultrahdr/jpegr.h:59-265), same names, argument meaning,
 // defaults and status values; structs as in ultrahdr.h:186-207 and jpegr.h:37-57.  Host buffers in and out; toneMap, gain-map
 // generation / application and both JPEG codecs run on HIP device 0 (uhdr_hip_jpegr_*), the container is parsed / assembled on
-// the host.  Not covered: decodeJPEGR(ULTRAHDR_OUTPUT_SDR) (libjpeg's own RGBA conversion) -> ERROR_ULTRAHDR_UNSUPPORTED_FEATURE.
+// the host.  decodeJPEGR(ULTRAHDR_OUTPUT_SDR) returns the primary image as RGBA8888 with libjpeg-turbo's DECODE_TO_RGBA arithmetic.
 struct ultrahdr_compressed_struct {
   void* data;
   int length;

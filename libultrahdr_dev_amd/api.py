@@ -174,8 +174,9 @@ def out_image(ptr):
 
 
 def output_bytes(fmt, w, h):
+    """applyGainMap's output size; OUTPUT_SDR: the RGBA8888 rendition decodeJPEGR returns (applyGainMap itself writes nothing for it)"""
     return {OUTPUT_HDR_LINEAR: 8, OUTPUT_HDR_PQ: 4, OUTPUT_HDR_HLG: 4,
-            OUTPUT_HDR_LINEAR_RGB_10BIT: 6}.get(fmt, 0) * w * h
+            OUTPUT_HDR_LINEAR_RGB_10BIT: 6, OUTPUT_SDR: 4}.get(fmt, 0) * w * h
 
 
 def image_array(images):

@@ -671,26 +671,29 @@ struct JpegrFile {
   uhdr_hip_metadata_t md;
   int gamut = UHDR_HIP_CG_UNSPECIFIED;
 };
-int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, JpegrFile* f) {
+int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bool want_metadata, JpegrFile* f) {
   const uint8_t* file = static_cast<const uint8_t*>(jpegr);
   jpegr::Range img[2];
   const int found = jpegr::find_images(file, jpegr_size, img);                                          // :823-876
   if (found == 0) return UHDR_HIP_ERROR_NO_IMAGES_FOUND;
   if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
-  if (output_format == UHDR_HIP_OUTPUT_SDR) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
-  for (int k = 0; k < 2; ++k) {   // the two headers, parsed once (jpeg_read_header of either decompressImage call, :690-694 / :731-733)
+  const bool sdr = output_format == UHDR_HIP_OUTPUT_SDR;   // the gain map is neither decompressed nor (unless asked for) read (:728, :754)
+  for (int k = 0; k < (sdr ? 1 : 2); ++k) {   // the headers, parsed once (jpeg_read_header of either decompressImage call, :690-694 / :731-733)
     f->jpg[k] = file + img[k].begin; f->len[k] = img[k].len;
     const int prc = jpeg::parse_header(f->jpg[k], f->len[k], &f->info[k]);
     if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
     if (prc != 0 || f->info[k].w > 8192 || f->info[k].h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;
   }
   if (f->info[0].gray) return UHDR_HIP_ERROR_DECODE_ERROR;   // the primary image must come back as three planes
-  // metadata from the gain map's XMP packet (:756-760)
-  const uint8_t* xmp = nullptr;
-  size_t xmp_len = 0;
-  static const char kXmpNs[] = "http://ns.adobe.com/xap/1.0/";
-  if (!jpegr::find_app_segment(f->jpg[1], f->len[1], 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) || !jpegr::metadata_from_xmp(xmp, xmp_len, &f->md))
-    return UHDR_HIP_ERROR_METADATA_ERROR;
+  // metadata from the gain map's XMP packet (:754-760)
+  f->jpg[1] = file + img[1].begin; f->len[1] = img[1].len;
+  if (!sdr || want_metadata) {
+    const uint8_t* xmp = nullptr;
+    size_t xmp_len = 0;
+    static const char kXmpNs[] = "http://ns.adobe.com/xap/1.0/";
+    if (!jpegr::find_app_segment(f->jpg[1], f->len[1], 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) || !jpegr::metadata_from_xmp(xmp, xmp_len, &f->md))
+      return UHDR_HIP_ERROR_METADATA_ERROR;
+  }
   const uint8_t* icc = nullptr;
   size_t icc_len = 0;
   static const char kIccSig[] = "ICC_PROFILE";
@@ -730,7 +733,7 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   int live = 0;
   for (int i = 0; i < n; ++i) {
     if (jpegr[i] == nullptr) { st_[i] = UHDR_HIP_ERROR_BAD_PTR; continue; }
-    if ((st_[i] = parse_jpegr_file(jpegr[i], jpegr_size[i], output_format, &files[i])) != UHDR_HIP_NO_ERROR) continue;
+    if ((st_[i] = parse_jpegr_file(jpegr[i], jpegr_size[i], output_format, metadata != nullptr, &files[i])) != UHDR_HIP_NO_ERROR) continue;
     if (metadata != nullptr) metadata[i] = files[i].md;
     dests[i].width = (size_t)files[i].info[0].w; dests[i].height = (size_t)files[i].info[0].h; dests[i].colorGamut = files[i].gamut;
     out_bytes[i] = dests[i].width * dests[i].height * apply_bpp(output_format);
@@ -763,6 +766,8 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   std::vector<hipStream_t> streams;
   std::vector<int> owner;
   std::vector<const uint8_t*> srcs;         // the entropy-coded segment of each image in the caller's file
+  const bool sdr = output_format == UHDR_HIP_OUTPUT_SDR;
+  const int per_file = sdr ? 1 : 2;          // the SDR rendition is the primary image alone (:768-786)
   infos.reserve(2 * live); layouts.reserve(2 * live); wss.reserve(2 * live); planes.reserve(6 * live);
   auto mk = [](uint8_t* p, size_t pw, size_t ph) {
     jpeg::DecPlane q;
@@ -773,7 +778,7 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   for (int i = 0; i < n; ++i) {
     if (st_[i] != UHDR_HIP_NO_ERROR) continue;
     const JpegrFile& f = files[i];
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < per_file; ++k) {
       const size_t w = (size_t)f.info[k].w, h = (size_t)f.info[k].h, luma = w * h, chroma = luma / 4;
       jpeg::DecLayout l;
       const size_t bytes = jpeg::dec_workspace_bytes(f.info[k], &l);
@@ -798,7 +803,7 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   int drc = 0;
   // A decode is ~70 kernel launches and the host needs ~5 us for each: one host thread cannot keep more than two images' streams
   // busy.  The files of a batch are therefore driven by up to kDecodeStreams / 2 host threads, two images (one file) in lock step each.
-  const int nthreads = std::min<int>(nimg / 2, (int)kDecodeStreams / 2);
+  const int nthreads = sdr ? 1 : std::min<int>(nimg / 2, (int)kDecodeStreams / 2);
   if (nthreads <= 1) {
     for (int g = 0; g < nimg; ++g)
       HIP_TRY(hipMemcpyAsync(wss[g] + layouts[g].src, srcs[g], infos[g]->scan_bytes, hipMemcpyHostToDevice, streams[g]));
@@ -841,6 +846,16 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   for (int i = 0; i < n; ++i) {
     if (st_[i] != UHDR_HIP_NO_ERROR) continue;
     const JpegrFile& f = files[i];
+    if (sdr) {   // libjpeg-turbo's DECODE_TO_RGBA on the planes just decoded (k_ycc420_rgba)
+      const size_t w = (size_t)f.info[0].w, h = (size_t)f.info[0].h;
+      if ((w | h) & 1) { st_[i] = UHDR_HIP_ERROR_UNSUPPORTED_FEATURE; continue; }
+      const uint8_t* yp = static_cast<const uint8_t*>(st->pool[5 * (size_t)i + 2]);
+      uint8_t* out = static_cast<uint8_t*>(host ? st->pool[5 * (size_t)i + 4] : dest_data[i]);
+      HIP_TRY(launch_ycc420_to_rgba(yp, yp + w * h, yp + w * h + (w / 2) * (h / 2), (uint32_t)w, (uint32_t)h, (uint32_t)w, (uint32_t)(w / 2), out, s));
+      dests[i].data = dest_data[i];
+      if (host) HIP_TRY(hipMemcpyAsync(dest_data[i], out, out_bytes[i], hipMemcpyDeviceToHost, s));
+      continue;
+    }
     const size_t w = (size_t)f.info[0].w, h = (size_t)f.info[0].h, gw = (size_t)f.info[1].w, gh = (size_t)f.info[1].h;
     uhdr_hip_image_t ydesc, gimg;
     memset(&ydesc, 0, sizeof(ydesc));

@@ -133,6 +133,9 @@ hipError_t launch_build_luts(float* lut /* kLutTotal floats */, hipStream_t s);
 hipError_t launch_build_gain_lut(float* table, double log2_min, double log2_max, float boost_factor, hipStream_t s);
 hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s);
 hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s);
+// decoded 4:2:0 planes -> RGBA8888 with libjpeg-turbo's arithmetic (k_ycc420_rgba); w, h even, strides in bytes
+hipError_t launch_ycc420_to_rgba(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, uint32_t w, uint32_t h, uint32_t y_stride,
+                                 uint32_t c_stride, uint8_t* rgba, hipStream_t s);
 hipError_t upload_idw4(const float* tables /* 4*64 floats */);
 hipError_t launch_effect(const FxJobs& j, hipStream_t s);
 hipError_t launch_eval_transfer(int fn, const float* in, float* out, size_t n, const EvalConsts& ec, hipStream_t s);

@@ -1156,6 +1156,57 @@ hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, i
 }
 
 // =================================================================================================
+// The SDR rendition of decodeJPEGR (jpegr.cpp:768-786): what JpegDecoderHelper::decompressImage(..., DECODE_TO_RGBA) makes of the
+// primary image (jpegdecoderhelper.cpp:251-281), i.e. libjpeg-turbo's own path from the decoded 4:2:0 planes to RGBA:
+//   jdsample.c h2v2_fancy_upsample  triangle filter over the four nearest chroma samples, weights 9 3 3 1 / 16, rounding constant 8
+//                                    on even and 7 on odd columns, edges replicated; chroma planes at most 2 samples wide are
+//                                    replicated instead (jinit_upsampler)
+//   jdcolor.c ycc_rgb_convert        R = Y + ((91881 (Cr-128) + 32768) >> 16) etc., the tables of build_ycc_rgb_table evaluated in
+//                                    place, clamp to 0..255, alpha 0xFF
+// One thread per horizontal pixel pair (they share the centre chroma column).  Restated in oracle/jpeg_oracle.c and pinned there
+// against libjpeg-turbo itself (Pillow's).
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_ycc420_rgba(const uint8_t* __restrict__ yp, const uint8_t* __restrict__ cbp, const uint8_t* __restrict__ crp,
+                                                     uint32_t w, uint32_t h, uint32_t ys, uint32_t cs, uint8_t* __restrict__ rgba) {
+  const uint32_t cw = w >> 1, ch = h >> 1;
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x, r = blockIdx.y;
+  if (c >= cw) return;
+  const uint32_t i = r >> 1;
+  const uint32_t o = (r & 1u) ? min(i + 1u, ch - 1u) : (i ? i - 1u : 0u);
+  const uint32_t cl = c ? c - 1u : 0u, cr_ = min(c + 1u, cw - 1u);
+  int cb[2], cr[2];
+  if (cw > 2u) {
+    auto colsum = [&](const uint8_t* p, uint32_t col) { return 3 * (int)p[i * cs + col] + (int)p[o * cs + col]; };
+    const int b0 = colsum(cbp, c), r0 = colsum(crp, c);
+    cb[0] = (3 * b0 + colsum(cbp, cl) + 8) >> 4; cb[1] = (3 * b0 + colsum(cbp, cr_) + 7) >> 4;
+    cr[0] = (3 * r0 + colsum(crp, cl) + 8) >> 4; cr[1] = (3 * r0 + colsum(crp, cr_) + 7) >> 4;
+  } else {
+    cb[0] = cb[1] = cbp[i * cs + c];
+    cr[0] = cr[1] = crp[i * cs + c];
+  }
+  const uint8_t* yrow = yp + (size_t)r * ys + 2u * c;
+  const uint32_t y2 = (uint32_t)yrow[0] | ((uint32_t)yrow[1] << 8);
+  uint32_t px[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int y = (int)((y2 >> (8 * k)) & 0xffu), xb = cb[k] - 128, xr = cr[k] - 128;
+    int R = y + ((91881 * xr + 32768) >> 16);
+    int G = y + ((-22554 * xb + 32768 - 46802 * xr) >> 16);
+    int B = y + ((116130 * xb + 32768) >> 16);
+    R = min(max(R, 0), 255); G = min(max(G, 0), 255); B = min(max(B, 0), 255);
+    px[k] = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16) | 0xFF000000u;
+  }
+  *reinterpret_cast<uint2*>(rgba + ((size_t)r * w + 2u * c) * 4u) = make_uint2(px[0], px[1]);
+}
+
+hipError_t launch_ycc420_to_rgba(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, uint32_t w, uint32_t h, uint32_t y_stride,
+                                 uint32_t c_stride, uint8_t* rgba, hipStream_t s) {
+  if (w == 0 || h == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ycc420_rgba, dim3((w / 2u + 255u) / 256u, h), dim3(256), 0, s, y, cb, cr, w, h, y_stride, c_stride, rgba);
+  return hipGetLastError();
+}
+
+// =================================================================================================
 // toneMap (ultrahdr.cpp:517-558): Y8 = (Y16 >> 6 >> 2) & 0xff == bits 15..8 of the P010 word
 // =================================================================================================
 

@@ -370,7 +370,6 @@ status_t JpegRHip::decodeJPEGR(uhdr_compressed_ptr jpegr_image_ptr, uhdr_uncompr
   uhdr_hip_jpeg_info_t a, g;
   int rc = uhdr_hip_jpegr_info(file, n, &a, &g);
   if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
-  if (output_format == ULTRAHDR_OUTPUT_SDR) return ERROR_ULTRAHDR_UNSUPPORTED_FEATURE;
   if (exif != nullptr) {                                                                                   // :721-727
     if (exif->length < a.exif_size) return ERROR_ULTRAHDR_BUFFER_TOO_SMALL;
     std::memcpy(exif->data, static_cast<const uint8_t*>(file) + a.exif_offset, a.exif_size);
@@ -386,8 +385,9 @@ status_t JpegRHip::decodeJPEGR(uhdr_compressed_ptr jpegr_image_ptr, uhdr_uncompr
   uhdr_hip_image_t d = to_c(*dest);
   uhdr_hip_metadata_t md;
   const size_t bpp = output_format == ULTRAHDR_OUTPUT_HDR_LINEAR ? 8 : output_format == ULTRAHDR_OUTPUT_HDR_LINEAR_RGB_10BIT ? 6 : 4;
-  rc = uhdr_hip_jpegr_decode(file, n, (int)output_format, max_display_boost, dest->data, a.width * a.height * bpp, &d, &md, mApplyMode, UHDR_HIP_MEM_HOST,
-                             nullptr);
+  const bool want_md = metadata != nullptr || output_format != ULTRAHDR_OUTPUT_SDR;   // jpegr.cpp:754
+  rc = uhdr_hip_jpegr_decode(file, n, (int)output_format, max_display_boost, dest->data, a.width * a.height * bpp, &d, want_md ? &md : nullptr, mApplyMode,
+                             UHDR_HIP_MEM_HOST, nullptr);
   if (rc != UHDR_HIP_NO_ERROR) return static_cast<status_t>(rc);
   dest->width = d.width; dest->height = d.height;
   dest->colorGamut = static_cast<ultrahdr_color_gamut>(d.colorGamut);

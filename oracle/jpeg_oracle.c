@@ -570,3 +570,61 @@ long orc_jpeg_decode(const uint8_t* jpg, long n, uint8_t* out, long cap, int* pw
     pos += 2 + len;
   }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * libjpeg-turbo's path from decoded 4:2:0 planes to RGBA, as JpegDecoderHelper::decompressImage(..., DECODE_TO_RGBA)
+ * configures it (lib/src/jpegdecoderhelper.cpp:251-281: JCS_EXT_RGBA, default do_fancy_upsampling, JDCT_ISLOW) and
+ * decodeJPEGR(ULTRAHDR_OUTPUT_SDR) hands it out (lib/src/jpegr.cpp:768-786).  The arithmetic lives in the reference's pinned
+ * dependency (libjpeg-turbo 3.0.1, CMakeLists.txt:254-256), not under /root/reference; restated from the published algorithm:
+ *   jdsample.c h2v2_fancy_upsample: triangle filter, 9/16 3/16 3/16 1/16 of the four nearest chroma samples, rounding constants
+ *     8 and 7 alternating by column, edge samples replicated (jdmainct.c makes the rows above the first / below the last
+ *     duplicates of them); images whose chroma planes are at most 2 samples wide get h2v2_upsample (replication) instead
+ *     (jdsample.c jinit_upsampler);
+ *   jdcolor.c ycc_rgb_convert: R = Y + Cr_r[Cr], G = Y + ((Cb_g[Cb] + Cr_g[Cr]) >> 16), B = Y + Cb_b[Cb] with the 16-bit
+ *     fixed-point tables of build_ycc_rgb_table, clamped to 0..255; alpha 0xFF.
+ * Pinned against Pillow's bundled libjpeg-turbo on the JPEG corpus (tests/test_jpeg_oracle.py).  w, h even.
+ * ------------------------------------------------------------------------------------------------------------------- */
+int orc_ycc420_to_rgba(const uint8_t* yp, const uint8_t* cbp, const uint8_t* crp, int w, int h, uint8_t* rgba) {
+  if (!yp || !cbp || !crp || !rgba || w <= 0 || h <= 0 || (w & 1) || (h & 1)) return -1;
+  const int cw = w / 2, ch = h / 2;
+  int cr_r[256], cb_b[256];
+  long cr_g[256], cb_g[256];
+#define ORC_FIX(x) ((long)((x) * 65536.0 + 0.5))
+  for (int i = 0; i < 256; ++i) {
+    const long x = i - 128;
+    cr_r[i] = (int)((ORC_FIX(1.40200) * x + 32768) >> 16);
+    cb_b[i] = (int)((ORC_FIX(1.77200) * x + 32768) >> 16);
+    cr_g[i] = -ORC_FIX(0.71414) * x;
+    cb_g[i] = -ORC_FIX(0.34414) * x + 32768;
+  }
+#undef ORC_FIX
+  for (int r = 0; r < h; ++r) {
+    const int i = r >> 1;
+    int o = (r & 1) ? i + 1 : i - 1;
+    if (o < 0) o = 0;
+    if (o > ch - 1) o = ch - 1;
+    for (int x = 0; x < w; ++x) {
+      const int c = x >> 1;
+      int n = (x & 1) ? c + 1 : c - 1;
+      if (n < 0) n = 0;
+      if (n > cw - 1) n = cw - 1;
+      const int bias = (x & 1) ? 7 : 8;
+      int cb, cr;
+      if (cw > 2) {
+        cb = (3 * (3 * cbp[i * cw + c] + cbp[o * cw + c]) + (3 * cbp[i * cw + n] + cbp[o * cw + n]) + bias) >> 4;
+        cr = (3 * (3 * crp[i * cw + c] + crp[o * cw + c]) + (3 * crp[i * cw + n] + crp[o * cw + n]) + bias) >> 4;
+      } else {   /* jinit_upsampler: the fancy filter needs downsampled_width > 2, narrower images get plain replication */
+        cb = cbp[i * cw + c];
+        cr = crp[i * cw + c];
+      }
+      const int y = yp[r * w + x];
+      int R = y + cr_r[cr], G = y + (int)((cb_g[cb] + cr_g[cr]) >> 16), B = y + cb_b[cb];
+      R = R < 0 ? 0 : (R > 255 ? 255 : R);
+      G = G < 0 ? 0 : (G > 255 ? 255 : G);
+      B = B < 0 ? 0 : (B > 255 ? 255 : B);
+      uint8_t* px = rgba + ((size_t)r * w + x) * 4;
+      px[0] = (uint8_t)R; px[1] = (uint8_t)G; px[2] = (uint8_t)B; px[3] = 0xFF;
+    }
+  }
+  return 0;
+}

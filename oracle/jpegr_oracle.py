@@ -162,6 +162,10 @@ def decode(data, output_format, max_display_boost, threads=8):
     st, planes, w, h, gray = O.jpeg_decode("orc", pj)
     if st <= 0 or gray:
         return -20002, None, 0, 0, -1, None
+    if output_format == O.OUT_SDR:      # jpegr.cpp:768-786: the primary image through libjpeg-turbo's DECODE_TO_RGBA, nothing else
+        if (w | h) & 1:
+            return -30000, None, w, h, -1, None
+        return 0, O.ycc420_to_rgba(planes, w, h).reshape(-1), w, h, gamut_from_icc(app_segment(pj, 0xE2, ICC_ID)), None
     gst, gplanes, gw, gh, ggray = O.jpeg_decode("orc", gj)
     if gst <= 0:
         return -20002, None, 0, 0, -1, None

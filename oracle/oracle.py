@@ -201,6 +201,18 @@ def jpeg_decode(which, data):
     return int(n), (out[:n].copy() if n > 0 else None), w.value, h.value, g.value
 
 
+def ycc420_to_rgba(planes, w, h):
+    """decoded planes (Y, Cb, Cr as jpeg_decode returns them) -> (h, w, 4) uint8, libjpeg-turbo's DECODE_TO_RGBA arithmetic"""
+    lib = load()
+    lib.orc_ycc420_to_rgba.restype = C.c_int
+    lib.orc_ycc420_to_rgba.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    planes = np.ascontiguousarray(planes)
+    out = np.zeros((h, w, 4), np.uint8)
+    base = planes.ctypes.data
+    assert lib.orc_ycc420_to_rgba(base, base + w * h, base + w * h + (w // 2) * (h // 2), w, h, out.ctypes.data) == 0
+    return out
+
+
 def jpeg_coefficients(y, uv, w, h, quality, luma_stride=None, chroma_stride=None):
     lib = load()
     n = lib.orc_jpeg_block_count(w, h, 1 if uv is None else 0)

@@ -146,6 +146,8 @@ void orc_jpeg_fdct_quant(const uint8_t samples[64], const uint16_t quant[64], in
  * out = w*h luma, then (4:2:0) Cb and Cr of (w/2)*(h/2) at w*h and w*h + w*h/4.  Returns bytes written; -1 malformed,
  * -2 process / sampling outside the restatement, -3 cap too small (*w, *h, *gray are set). */
 long orc_jpeg_decode(const uint8_t* jpg, long n, uint8_t* out, long cap, int* w, int* h, int* gray);
+/* decoded 4:2:0 planes -> RGBA8888 the way libjpeg-turbo does it for DECODE_TO_RGBA (fancy upsampling + fixed-point colour conversion) */
+int orc_ycc420_to_rgba(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, int w, int h, uint8_t* rgba);
 void orc_jpeg_idct(const int16_t coef_natural[64], const uint16_t quant_natural[64], uint8_t samples[64]);
 
 /* fn: 0 srgbInvOetf 1 hlgInvOetf 2 pqInvOetf 3 encodeGain(y_sdr=1,y_hdr=x) 4 hlgOetf 5 pqOetf;

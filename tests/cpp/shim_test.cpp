@@ -176,7 +176,8 @@ int main(int argc, char** argv) {
     ultrahdr_exif_struct small_exif{exif_back.data(), 4};
     CHECK(codec.decodeJPEGR(&jpgr, &decoded, FLT_MAX, &small_exif) == ERROR_ULTRAHDR_BUFFER_TOO_SMALL);
     CHECK(codec.decodeJPEGR(&jpgr, &decoded, 0.5f) == ERROR_ULTRAHDR_INVALID_DISPLAY_BOOST);
-    CHECK(codec.decodeJPEGR(&jpgr, &decoded, FLT_MAX, nullptr, ULTRAHDR_OUTPUT_SDR) == ERROR_ULTRAHDR_UNSUPPORTED_FEATURE);
+    CHECK(codec.decodeJPEGR(&jpgr, &decoded, FLT_MAX, nullptr, ULTRAHDR_OUTPUT_SDR) == ULTRAHDR_NO_ERROR && decoded.width == w && decoded.height == h);
+    dump(out + "/api1_decoded_sdr.bin", dec_out.data(), w * h * 4);
     // API-2 / API-3 around the SDR JPEG made earlier (its ICC payload is not a profile -> gamut has to come from the struct... and is rejected)
     ultrahdr_compressed_struct sdr_jpg{enc_sdr.getCompressedImagePtr(), (int)enc_sdr.getCompressedImageSize(), (int)enc_sdr.getCompressedImageSize(),
                                        ULTRAHDR_COLORGAMUT_BT709};

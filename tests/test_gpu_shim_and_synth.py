@@ -83,6 +83,8 @@ def test_cpp_shim_on_reference_fixture(hip, orc, tmp_path):
     assert rd("api1.jpgr") == api1
     st, ref, ow, oh, gamut, md = J.decode(api1, orc.OUT_HDR_HLG, 3.4028234663852886e38)
     assert st == 0 and np.array_equal(np.fromfile(tmp_path / "api1_decoded_hlg.bin", np.uint8), ref)
+    st, sref, _, _, _, _ = J.decode(api1, orc.OUT_SDR, 3.4028234663852886e38)
+    assert st == 0 and np.array_equal(np.fromfile(tmp_path / "api1_decoded_sdr.bin", np.uint8), sref)
     gj = api1[J.find_images(api1)[1][0]:]
     assert np.array_equal(np.fromfile(tmp_path / "api1_decoded_map.bin", np.uint8), orc.jpeg_decode("orc", gj)[1])
     plain = orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, 95)

@@ -12,6 +12,7 @@ The reference's tests (tests/jpegencoderhelper_test.cpp) only check that encodin
 buffer; those properties are restated at the end.
 """
 import io
+import os
 import subprocess
 import sys
 
@@ -228,3 +229,34 @@ def test_decode_of_encode_is_close_to_the_input(orc):
     assert st == w * h * 3 // 2 and (dw, dh, gray) == (w, h, 0)
     assert np.abs(planes[:w * h].astype(int) - y.reshape(-1)).mean() < 2.0
     assert np.abs(planes[w * h:w * h * 5 // 4].astype(int) - u.reshape(-1)).mean() < 2.0
+
+
+def test_rgba_restatement_equals_libjpeg_turbo(orc, tmp_path):
+    """orc_ycc420_to_rgba (libjpeg-turbo's DECODE_TO_RGBA path: fancy h2v2 upsampling + fixed-point colour conversion, restated from
+    the published algorithm) against libjpeg-turbo itself, which Pillow bundles: every 4:2:0 file of the corpus plus small and narrow
+    sizes, and the primary image of the reference's own sample_jpegr.jpeg"""
+    try:
+        import io
+        from PIL import Image, features
+    except ImportError:
+        pytest.skip("no Pillow in this image")
+    if not features.check_feature("libjpeg_turbo"):
+        pytest.skip("Pillow without libjpeg-turbo")
+    corpus, extra = jpeg_corpus(orc, tmp_path)
+    rng = np.random.RandomState(4)
+    for (w, h) in ((2, 18), (4, 4), (4, 18), (6, 6), (8, 8), (16, 2), (10, 14), (66, 34), (640, 480)):
+        y = rng.randint(0, 256, w * h * 3 // 2).astype(np.uint8)
+        corpus.append(("rand_%dx%d" % (w, h), orc.jpeg_encode("orc", y[:w * h], y[w * h:], w, h, 30 + 6 * (w % 11))))
+    sample = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_jpegr.jpeg"), "rb").read()
+    corpus.append(("sample_jpegr primary", sample[:42326]))
+    checked = 0
+    for name, data in corpus + [(k, extra[k]) for k in ("opt", "rst", "rst_rows") if k in extra]:
+        st, planes, w, h, gray = orc.jpeg_decode("orc", data)
+        if gray or st <= 0 or (w & 1) or (h & 1):
+            continue
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        got = orc.ycc420_to_rgba(planes, w, h)
+        assert np.array_equal(got[..., :3], want), (name, int((got[..., :3] != want).sum()))
+        assert np.all(got[..., 3] == 255)
+        checked += 1
+    assert checked >= 40

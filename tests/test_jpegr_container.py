@@ -126,7 +126,16 @@ def test_gpu_decodes_files_assembled_from_the_device_encoder(hip, orc):
     assert _gpu_decode(lib, hip, pj + gj, hip.OUTPUT_HDR_HLG, FLT_MAX, 0, True)[0] == -20005                # METADATA_ERROR (no XMP)
     bad = assemble_jpegr(pj, gj, attrs[:3] + (("Gamma", "2.2"),) + attrs[4:])
     assert _gpu_decode(lib, hip, bad, hip.OUTPUT_HDR_HLG, FLT_MAX, 0, True)[0] == hip.ERROR_BAD_METADATA       # applyGainMap's own check
-    assert _gpu_decode(lib, hip, data, hip.OUTPUT_SDR, FLT_MAX, 0, True)[0] == hip.ERROR_UNSUPPORTED_FEATURE
+    # the SDR rendition works without a readable gain map or XMP packet (jpegr.cpp:728,754: neither is touched)
+    # ... unless the caller asks for the metadata (:754-760)
+    assert _gpu_decode(lib, hip, pj + gj, hip.OUTPUT_SDR, FLT_MAX, 0, True)[0] == -20005
+    plain = np.frombuffer(pj + gj, np.uint8)
+    sdest = hip.Image()
+    st, want_sdr, sw, sh, _, _ = J.decode(pj + gj, orc.OUT_SDR, FLT_MAX)
+    sdr = np.zeros(sw * sh * 4, np.uint8)
+    rc = lib.uhdr_hip_jpegr_decode(C.c_void_p(plain.ctypes.data), plain.size, hip.OUTPUT_SDR, FLT_MAX, C.c_void_p(sdr.ctypes.data), sdr.size, C.byref(sdest), None,
+                                   hip.APPLY_FAST, hip.MEM_HOST, None)
+    assert rc == st == 0 and (sdest.width, sdest.height) == (sw, sh) and np.array_equal(sdr, want_sdr)
     assert _gpu_decode(lib, hip, gj + pj, hip.OUTPUT_HDR_HLG, FLT_MAX, 0, True)[0] == -20002                # primary is not 4:2:0: DECODE_ERROR
 
 
@@ -660,7 +669,7 @@ def test_invalid_argument_matrices_need_no_gpu():
     assert dec(fmt=-1) == dec(fmt=5) == api.ERROR_INVALID_OUTPUT_FORMAT
     assert dec(buf=np.zeros(64, np.uint8)) == api.ERROR_NO_IMAGES_FOUND and dec(buf=pj) == api.ERROR_GAIN_MAP_IMAGE_NOT_FOUND
     assert dec(buf=np.concatenate([pj, gj])) == api.ERROR_METADATA_ERROR          # two JPEGs, no gain-map XMP
-    assert dec(fmt=api.OUTPUT_SDR) == api.ERROR_UNSUPPORTED_FEATURE
+    assert dec(fmt=api.OUTPUT_SDR) == api.ERROR_INSUFFICIENT_RESOURCE and (dest.width, dest.height) == (1280, 720)   # SDR rendition: RGBA8888, same size query
     assert dec() == api.ERROR_INSUFFICIENT_RESOURCE and (dest.width, dest.height, dest.colorGamut) == (1280, 720, api.CG_BT709)   # the size query
     assert abs(dmd.maxContentBoost - 10.0) < 1e-4 and dmd.version == b"1.0"
 
@@ -747,3 +756,32 @@ def test_gpu_decodes_a_file_whose_primary_image_has_restart_intervals(hip, orc, 
     for device in (True, False):
         rc, dec, dest, _ = _gpu_decode(lib, hip, got, hip.OUTPUT_HDR_HLG, FLT_MAX, hip.APPLY_EXACT, device)
         assert rc == st == 0 and (dest.width, dest.height, dest.colorGamut) == (w, h, hip.CG_BT709) and np.array_equal(dec, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [True, False])
+def test_gpu_sdr_rendition_is_libjpeg_turbos(hip, orc, device):
+    """decodeJPEGR(ULTRAHDR_OUTPUT_SDR): the primary image as RGBA8888 == the restatement of libjpeg-turbo's DECODE_TO_RGBA path, and --
+    where Pillow (which bundles libjpeg-turbo) is usable -- == what libjpeg-turbo itself makes of the reference's own sample file"""
+    from oracle import jpegr_oracle as J
+    from tests.test_gpu_parity import smooth_frame
+    lib = hip.load()
+    data = open(SAMPLE, "rb").read()
+    files = [data]
+    for (w, h), sg, tf, q in ENC_CASES + (((8, 8), 0, 1, 90), ((1280, 720), 1, 1, 97)):
+        p010, yuv = smooth_frame(w, h, w + 3)
+        files.append(J.encode_api1(p010, yuv, w, h, sg, hip.CG_BT2100, tf, q))
+    for k, blob in enumerate(files):
+        st, want, w, h, gamut, _ = J.decode(blob, orc.OUT_SDR, FLT_MAX)
+        rc, got, dest, _ = _gpu_decode(lib, hip, blob, hip.OUTPUT_SDR, FLT_MAX, hip.APPLY_FAST, device)
+        assert rc == st == 0 and (dest.width, dest.height, dest.colorGamut) == (w, h, gamut), k
+        assert np.array_equal(got, want), (k, int((got != want).sum()))
+        assert np.all(got.reshape(h, w, 4)[..., 3] == 0xFF)
+    try:
+        import io
+        from PIL import Image
+    except ImportError:
+        return
+    rc, got, dest, _ = _gpu_decode(lib, hip, data, hip.OUTPUT_SDR, FLT_MAX, hip.APPLY_FAST, device)
+    turbo = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+    assert np.array_equal(got.reshape(720, 1280, 4)[..., :3], turbo)

@@ -233,6 +233,13 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
                          int mem_space, void* stream);
 
+/* JpegDecoderHelper::decompressImage(..., DECODE_TO_RGBA) (lib/src/jpegdecoderhelper.cpp:251-281): a YCbCr 4:2:0 baseline JPEG ->
+ * width*height RGBA8888 pixels (alpha 0xFF) with libjpeg-turbo's arithmetic (fancy upsampling, fixed-point colour conversion; see
+ * uhdr_hip_jpegr_decode's UHDR_HIP_OUTPUT_SDR).  Same calling convention and status values as uhdr_hip_jpeg_decode; a single-plane
+ * JPEG is UNKNOWN_ERROR (the reference's call returns false). */
+int uhdr_hip_jpeg_decode_rgba(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc, int mem_space,
+                              void* stream);
+
 /* JpegR::decodeJPEGR (lib/src/jpegr.cpp:655-822) for the HDR output formats: a JPEG/R file (HOST memory: primary JPEG + gain
  * map JPEG, the gain map's APP1 carrying the hdrgm:* XMP attributes) -> the HDR rendition applyGainMap produces.  Container
  * scan (extractPrimaryImageAndGainMap, :823-876), XMP metadata (getMetadataFromXMP, jpegrutils.cpp:436-545) and the ICC gamut

@@ -146,10 +146,14 @@ class JpegEncoderHelperHip {
   std::vector<uint8_t> mResultBuffer;
 };
 
+// jpegdecoderhelper.h:34-38 (PARSE_ONLY is served by getCompressedImageParameters there and by JpegRHip::getJPEGRInfo here)
+enum decode_mode_t : int { DECODE_TO_RGBA = 1, DECODE_TO_YCBCR = 2 };
+
 class JpegDecoderHelperHip {
  public:
-  // DECODE_TO_YCBCR only (what applyGainMap's caller asks for, jpegr.cpp:780-801): 4:2:0 -> Y, Cb, Cr planes; grayscale -> Y
-  bool decompressImage(const void* image, int length);
+  // DECODE_TO_YCBCR (what applyGainMap's caller asks for, jpegr.cpp:780-801): 4:2:0 -> Y, Cb, Cr planes; grayscale -> Y.
+  // DECODE_TO_RGBA (the SDR rendition, jpegr.cpp:686-690): 4:2:0 -> RGBA8888 with libjpeg-turbo's arithmetic.
+  bool decompressImage(const void* image, int length, decode_mode_t decodeTo = DECODE_TO_YCBCR);
   void* getDecompressedImagePtr() { return mResultBuffer.data(); }
   size_t getDecompressedImageSize() { return mResultBuffer.size(); }
   size_t getDecompressedImageWidth() { return mWidth; }

@@ -91,6 +91,7 @@ SIGNATURES = {
     "uhdr_hip_jpegr_encode_api3": (C.c_int, [_IP, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
     "uhdr_hip_jpegr_encode_api4": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, _MP, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "uhdr_hip_jpegr_encode_apix": (C.c_int, [_IP, _IP, _MP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
+    "uhdr_hip_jpeg_decode_rgba": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_jpegr_decode_batch": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_float, C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_size_t), _IP, _MP, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_jpegr_metadata": (C.c_int, [C.c_void_p, C.c_size_t, _MP]),

@@ -718,6 +718,36 @@ constexpr size_t kDecodeStreams = 8;
 
 extern "C" {
 
+// JpegDecoderHelper::decompressImage(..., DECODE_TO_RGBA) (jpegdecoderhelper.cpp:251-281): a 4:2:0 JPEG -> RGBA8888
+int uhdr_hip_jpeg_decode_rgba(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc, int mem_space, void* stream) {
+  if (jpeg == nullptr || desc == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  uhdr_hip_image_t planes;
+  int rc = uhdr_hip_jpeg_decode(jpeg, jpeg_size, nullptr, 0, &planes, UHDR_HIP_MEM_DEVICE, stream);   // header probe
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return rc;
+  if (planes.pixelFormat != UHDR_HIP_PIX_FMT_YUV420) return UHDR_HIP_UNKNOWN_ERROR;                    // :258-270: YCbCr 4:2:0 only
+  const size_t w = planes.width, h = planes.height, need = w * h * 4;
+  memset(desc, 0, sizeof(*desc));
+  desc->data = out; desc->width = w; desc->height = h; desc->colorGamut = UHDR_HIP_CG_UNSPECIFIED; desc->luma_stride = w;
+  desc->pixelFormat = UHDR_HIP_PIX_FMT_UNSPECIFIED;
+  if (out == nullptr || out_capacity < need) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  if ((w | h) & 1) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  DeviceState* st = nullptr;
+  if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
+  const size_t ybytes = w * h + 2 * (w * h / 4);
+  if ((rc = stage_reserve(st, 8, ybytes + 64)) != 0) return rc;
+  if (host && (rc = stage_reserve(st, 10, need)) != 0) return rc;
+  if ((rc = uhdr_hip_jpeg_decode(jpeg, jpeg_size, st->stage[8], ybytes, &planes, UHDR_HIP_MEM_DEVICE, stream)) != UHDR_HIP_NO_ERROR) return rc;
+  const uint8_t* yp = static_cast<const uint8_t*>(st->stage[8]);
+  uint8_t* dst = static_cast<uint8_t*>(host ? st->stage[10] : out);
+  HIP_TRY(launch_ycc420_to_rgba(yp, yp + w * h, yp + w * h + (w / 2) * (h / 2), (uint32_t)w, (uint32_t)h, (uint32_t)w, (uint32_t)(w / 2), dst, s));
+  if (host) HIP_TRY(hipMemcpyAsync(out, dst, need, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return UHDR_HIP_NO_ERROR;
+}
+
 // JpegR::decodeJPEGR (jpegr.cpp:655-822), HDR outputs, for n files at once.  A JPEG decode on the device is latency-bound (tens of
 // synchronisation rounds of one lane's work each, uhdr_jpeg_dec.hip), so the 2 n images advance in lock step on a pool of streams
 // and their rounds overlap: n files take little longer than one.

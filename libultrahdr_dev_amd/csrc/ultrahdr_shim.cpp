@@ -231,11 +231,21 @@ bool JpegEncoderHelperHip::compressImage(const uint8_t* yBuffer, const uint8_t* 
   return rc == UHDR_HIP_NO_ERROR;
 }
 
-bool JpegDecoderHelperHip::decompressImage(const void* image, int length) {
+bool JpegDecoderHelperHip::decompressImage(const void* image, int length, decode_mode_t decodeTo) {
   mResultBuffer.clear();
   mWidth = mHeight = 0;
   if (image == nullptr || length <= 0 || uhdr_hip_init(0) != UHDR_HIP_NO_ERROR) return false;
   uhdr_hip_image_t desc;
+  if (decodeTo == DECODE_TO_RGBA) {
+    if (uhdr_hip_jpeg_decode_rgba(image, (size_t)length, nullptr, 0, &desc, UHDR_HIP_MEM_HOST, nullptr) != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return false;
+    mResultBuffer.resize(desc.width * desc.height * 4);   // jpegdecoderhelper.cpp:274
+    if (uhdr_hip_jpeg_decode_rgba(image, (size_t)length, mResultBuffer.data(), mResultBuffer.size(), &desc, UHDR_HIP_MEM_HOST, nullptr) != UHDR_HIP_NO_ERROR) {
+      mResultBuffer.clear();
+      return false;
+    }
+    mWidth = desc.width; mHeight = desc.height; mSingleChannel = false;
+    return true;
+  }
   int rc = uhdr_hip_jpeg_decode(image, (size_t)length, nullptr, 0, &desc, UHDR_HIP_MEM_HOST, nullptr);
   if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return false;   // unreadable header, unsupported process, too large
   mSingleChannel = desc.pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;

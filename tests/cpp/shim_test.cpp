@@ -135,6 +135,9 @@ int main(int argc, char** argv) {
   CHECK(dec.decompressImage(enc_map.getCompressedImagePtr(), (int)enc_map.getCompressedImageSize()) && dec.isSingleChannel());
   dump(out + "/map_q85_decoded.bin", dec.getDecompressedImagePtr(), dec.getDecompressedImageSize());
   CHECK(!dec.decompressImage("not a jpeg", 10));
+  CHECK(dec.decompressImage(enc_sdr.getCompressedImagePtr(), (int)enc_sdr.getCompressedImageSize(), DECODE_TO_RGBA) && dec.getDecompressedImageSize() == w * h * 4);
+  dump(out + "/sdr_q95_rgba.bin", dec.getDecompressedImagePtr(), dec.getDecompressedImageSize());
+  CHECK(!dec.decompressImage(enc_map.getCompressedImagePtr(), (int)enc_map.getCompressedImageSize(), DECODE_TO_RGBA));   // single plane: :258-262
   // ---- JpegRHip: the calls of the reference's own encode / decode tests (tests/jpegr_test.cpp: EncodeAPI0..4AndDecodeTest) -------------
   {
     JpegRHip codec;

@@ -70,6 +70,7 @@ def test_cpp_shim_on_reference_fixture(hip, orc, tmp_path):
     assert open(tmp_path / "sdr_q95.jpg", "rb").read() == want
     st, planes, dw, dh, gray = orc.jpeg_decode("orc", want)
     assert st > 0 and np.array_equal(np.fromfile(tmp_path / "sdr_q95_decoded.bin", np.uint8), planes)
+    assert np.array_equal(np.fromfile(tmp_path / "sdr_q95_rgba.bin", np.uint8).reshape(h, w, 4), orc.ycc420_to_rgba(planes, w, h))
     st, planes, dw, dh, gray = orc.jpeg_decode("orc", open(tmp_path / "map_q85.jpg", "rb").read())
     assert st > 0 and gray and np.array_equal(np.fromfile(tmp_path / "map_q85_decoded.bin", np.uint8), planes)
     # JpegRHip: every encodeJPEGR overload and decodeJPEGR against the CPU restatement (oracle/jpegr_oracle.py, pinned to the reference's

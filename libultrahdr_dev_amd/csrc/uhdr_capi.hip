@@ -45,8 +45,7 @@ struct DeviceState {
   // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
   void* stage[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // uhdr_hip_jpegr_decode[_batch]: a pool of streams the JPEGs of a call are decompressed on side by side, and their buffers
-  std::vector<hipStream_t> streams;
+  // uhdr_hip_jpegr_decode[_batch]: per-file decoder workspaces and planes
   std::vector<void*> pool;
   std::vector<size_t> pool_bytes;
 };
@@ -483,7 +482,6 @@ int uhdr_hip_shutdown(void) {
     (void)hipDeviceSynchronize();
     for (auto& t : kv.second.idw) (void)hipFree(t.second);
     if (kv.second.lut) (void)hipFree(kv.second.lut);
-    for (hipStream_t q : kv.second.streams) (void)hipStreamDestroy(q);
     for (void* q : kv.second.pool) if (q) (void)hipFree(q);
     for (int i = 0; i < 12; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
@@ -702,7 +700,7 @@ int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bo
   return UHDR_HIP_NO_ERROR;
 }
 
-// grow-only device buffers / streams of the JPEG/R decode entry points (guarded by g_jpegr_mu)
+// grow-only device buffers of the JPEG/R decode entry points (guarded by g_jpegr_mu)
 int pool_reserve(DeviceState* st, size_t idx, size_t bytes) {
   if (st->pool.size() <= idx) { st->pool.resize(idx + 1, nullptr); st->pool_bytes.resize(idx + 1, 0); }
   if (bytes == 0) bytes = 256;
@@ -713,7 +711,6 @@ int pool_reserve(DeviceState* st, size_t idx, size_t bytes) {
   st->pool_bytes[idx] = bytes;
   return UHDR_HIP_NO_ERROR;
 }
-constexpr size_t kDecodeStreams = 8;
 }  // namespace
 
 extern "C" {
@@ -748,9 +745,9 @@ int uhdr_hip_jpeg_decode_rgba(const void* jpeg, size_t jpeg_size, void* out, siz
   return UHDR_HIP_NO_ERROR;
 }
 
-// JpegR::decodeJPEGR (jpegr.cpp:655-822), HDR outputs, for n files at once.  A JPEG decode on the device is latency-bound (tens of
-// synchronisation rounds of one lane's work each, uhdr_jpeg_dec.hip), so the 2 n images advance in lock step on a pool of streams
-// and their rounds overlap: n files take little longer than one.
+// JpegR::decodeJPEGR (jpegr.cpp:655-822) for n files at once.  A JPEG decode on the device is latency-bound (tens of synchronisation
+// rounds of one lane's work each, uhdr_jpeg_dec.hip), so all images of the call share every kernel launch (blockIdx.y = image) and
+// their rounds run side by side.
 int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* jpegr_size, int output_format, float max_display_boost,
                                 void* const* dest_data, const size_t* dest_capacity, uhdr_hip_image_t* dests, uhdr_hip_metadata_t* metadata,
                                 int* status, int apply_mode, int mem_space, void* stream) {
@@ -761,9 +758,24 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   std::vector<int> st_((size_t)n, UHDR_HIP_NO_ERROR);
   std::vector<size_t> out_bytes((size_t)n, 0);
   int live = 0;
+  {
+    // walking a 2 MB file's markers (memchr over the entropy-coded data, twice: container split and scan length) costs ~0.2 ms of
+    // host time per file and touches nothing shared: the files of a batch are parsed by a few threads side by side
+    auto parse_range = [&](int lo, int hi) {
+      for (int i = lo; i < hi; ++i)
+        st_[i] = jpegr[i] == nullptr ? UHDR_HIP_ERROR_BAD_PTR : parse_jpegr_file(jpegr[i], jpegr_size[i], output_format, metadata != nullptr, &files[i]);
+    };
+    const int nthreads = std::min(n / 2, 8);
+    if (nthreads <= 1) {
+      parse_range(0, n);
+    } else {
+      std::vector<std::thread> workers;
+      for (int t = 0; t < nthreads; ++t) workers.emplace_back(parse_range, (int)((long)n * t / nthreads), (int)((long)n * (t + 1) / nthreads));
+      for (auto& w : workers) w.join();
+    }
+  }
   for (int i = 0; i < n; ++i) {
-    if (jpegr[i] == nullptr) { st_[i] = UHDR_HIP_ERROR_BAD_PTR; continue; }
-    if ((st_[i] = parse_jpegr_file(jpegr[i], jpegr_size[i], output_format, metadata != nullptr, &files[i])) != UHDR_HIP_NO_ERROR) continue;
+    if (st_[i] != UHDR_HIP_NO_ERROR) continue;
     if (metadata != nullptr) metadata[i] = files[i].md;
     dests[i].width = (size_t)files[i].info[0].w; dests[i].height = (size_t)files[i].info[0].h; dests[i].colorGamut = files[i].gamut;
     out_bytes[i] = dests[i].width * dests[i].height * apply_bpp(output_format);
@@ -783,17 +795,11 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lk(g_jpegr_mu);
   const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
-  while (st->streams.size() < kDecodeStreams) {
-    hipStream_t q = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-    st->streams.push_back(q);
-  }
   // per file: two decoder workspaces, two sets of planes, (host callers) the rendition before it goes down
   std::vector<const jpeg::DecInfo*> infos;
   std::vector<jpeg::DecLayout> layouts;
   std::vector<uint8_t*> wss;
   std::vector<jpeg::DecPlane> planes;       // 3 per image
-  std::vector<hipStream_t> streams;
   std::vector<int> owner;
   std::vector<const uint8_t*> srcs;         // the entropy-coded segment of each image in the caller's file
   const bool sdr = output_format == UHDR_HIP_OUTPUT_SDR;
@@ -816,8 +822,7 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
       if ((rc = pool_reserve(st, 5 * (size_t)i + 2 + k, (f.info[k].gray ? luma : luma + 2 * chroma) + 64)) != 0) return rc;
       uint8_t* ws = static_cast<uint8_t*>(st->pool[5 * (size_t)i + k]);
       uint8_t* out = static_cast<uint8_t*>(st->pool[5 * (size_t)i + 2 + k]);
-      const hipStream_t q = st->streams[infos.size() % kDecodeStreams];
-      infos.push_back(&f.info[k]); layouts.push_back(l); wss.push_back(ws); streams.push_back(q); owner.push_back(i);
+      infos.push_back(&f.info[k]); layouts.push_back(l); wss.push_back(ws); owner.push_back(i);
       srcs.push_back(f.jpg[k] + f.info[k].scan_offset);
       planes.push_back(mk(out, w, h));
       planes.push_back(f.info[k].gray ? jpeg::DecPlane{} : mk(out + luma, w / 2, h / 2));
@@ -830,44 +835,13 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   for (int k = 0; k < nimg; ++k) pl[k] = reinterpret_cast<jpeg::DecPlane (*)[3]>(&planes[3 * (size_t)k]);
   std::vector<int> image_rc((size_t)nimg, 0);
   hipError_t herr = hipSuccess;
-  int drc = 0;
-  // A decode is ~70 kernel launches and the host needs ~5 us for each: one host thread cannot keep more than two images' streams
-  // busy.  The files of a batch are therefore driven by up to kDecodeStreams / 2 host threads, two images (one file) in lock step each.
-  const int nthreads = sdr ? 1 : std::min<int>(nimg / 2, (int)kDecodeStreams / 2);
-  if (nthreads <= 1) {
-    for (int g = 0; g < nimg; ++g)
-      HIP_TRY(hipMemcpyAsync(wss[g] + layouts[g].src, srcs[g], infos[g]->scan_bytes, hipMemcpyHostToDevice, streams[g]));
-    drc = jpeg::decode_device_multi(nimg, infos.data(), layouts.data(), wss.data(), pl.data(), streams.data(), &herr, image_rc.data());
-  } else {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    std::vector<std::thread> workers;
-    std::vector<int> trc((size_t)nthreads, 0);
-    std::vector<hipError_t> terr((size_t)nthreads, hipSuccess);
-    for (int t = 0; t < nthreads; ++t)
-      workers.emplace_back([&, t]() {
-        if (hipSetDevice(dev) != hipSuccess) { trc[t] = 1; terr[t] = hipErrorInvalidDevice; return; }
-        // thread t takes files t, t + nthreads, ... (images 2f, 2f + 1), always on its own two streams
-        std::vector<const jpeg::DecInfo*> ti; std::vector<jpeg::DecLayout> tl; std::vector<uint8_t*> tw; std::vector<jpeg::DecPlane (*)[3]> tp;
-        std::vector<hipStream_t> ts; std::vector<int> idx;
-        for (int f = t; 2 * f + 1 < nimg; f += nthreads)
-          for (int k = 0; k < 2; ++k) {
-            const int g = 2 * f + k;
-            ti.push_back(infos[g]); tl.push_back(layouts[g]); tw.push_back(wss[g]); tp.push_back(pl[g]); ts.push_back(st->streams[2 * (size_t)t + k]); idx.push_back(g);
-          }
-        // uploads (pageable host memory: each copy occupies the calling thread) happen here, side by side with the other threads'
-        for (size_t q = 0; q < idx.size(); ++q)
-          if (hipMemcpyAsync(tw[q] + tl[q].src, srcs[idx[q]], ti[q]->scan_bytes, hipMemcpyHostToDevice, ts[q]) != hipSuccess) { trc[t] = 1; terr[t] = hipGetLastError(); return; }
-        std::vector<int> lrc(idx.size(), 0);
-        trc[t] = jpeg::decode_device_multi((int)idx.size(), ti.data(), tl.data(), tw.data(), tp.data(), ts.data(), &terr[t], lrc.data());
-        for (size_t q = 0; q < idx.size(); ++q) image_rc[idx[q]] = lrc[q];
-      });
-    for (auto& w : workers) w.join();
-    for (int t = 0; t < nthreads; ++t) {
-      if (trc[t] > 0) { drc = 1; herr = terr[t]; }
-      else if (trc[t] < 0 && drc == 0) drc = -1;
-    }
-  }
+  // one launch per decoder step for all images of the call (jpeg::decode_device_batch): the files' latency-bound synchronisation
+  // rounds run side by side and a batch costs the launches of one image plus its per-image prefix sums
+  if ((rc = pool_reserve(st, 5 * (size_t)n, jpeg::dec_batch_scratch_bytes(nimg))) != 0) return rc;
+  for (int g = 0; g < nimg; ++g)
+    HIP_TRY(hipMemcpyAsync(wss[g] + layouts[g].src, srcs[g], infos[g]->scan_bytes, hipMemcpyHostToDevice, s));
+  const int drc = jpeg::decode_device_batch(nimg, infos.data(), layouts.data(), wss.data(), pl.data(), s, static_cast<uint8_t*>(st->pool[5 * (size_t)n]), &herr,
+                                            image_rc.data());
   if (drc > 0) { set_err("uhdr_hip_jpegr_decode", herr); return UHDR_HIP_UNKNOWN_ERROR; }
   for (int k = 0; k < nimg; ++k)
     if (image_rc[k] != 0) st_[owner[k]] = UHDR_HIP_ERROR_DECODE_ERROR;

@@ -103,5 +103,11 @@ int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane
 int decode_device_multi(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3],
                         const hipStream_t streams[], hipError_t* herr, int* image_rc);
 
+// n images on one stream with one launch per decoder step for all of them (blockIdx.y = image); batch_ws: device scratch of
+// dec_batch_scratch_bytes(n)
+size_t dec_batch_scratch_bytes(int n);
+int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3], hipStream_t s,
+                        uint8_t* batch_ws, hipError_t* herr, int* image_rc);
+
 }  // namespace jpeg
 }  // namespace uhdr

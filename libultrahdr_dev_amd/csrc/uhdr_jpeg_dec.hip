@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ bool dropped_byte(const uint8_t* src, uint32_t n, uin
   if (prev == 0xFF && (v == 0 || (rst && (v & 0xF8) == 0xD0))) return true;
   return rst && v == 0xFF && at + 1u < n && (src[at + 1u] & 0xF8) == 0xD0;
 }
-__global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, uint32_t n, uint32_t* kept, int rst) {
+__device__ __forceinline__ void unstuff_count_body(const uint8_t* src, uint32_t n, uint32_t* kept, int rst) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t b0 = t * kUnstuffChunk;
   if (b0 >= n) return;
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, ui
   kept[t] = k;
 }
 // a workgroup compacts its 16 KiB into LDS and writes the run out as aligned dwords (its start in `dst` is arbitrary)
-__global__ void __launch_bounds__(256) k_jd_unstuff_copy(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst, int rst) {
+__device__ __forceinline__ void unstuff_copy_body(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst, int rst) {
   __shared__ uint8_t s_buf[256 * kUnstuffChunk + 8];
   __shared__ uint32_t s_len;
   const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
@@ -118,7 +119,7 @@ constexpr uint32_t kFastBitsEarly = 9;   // == kFastBits (first-level table widt
 // adv[x]: what the position-only passes need from a symbol, in one 16-bit entry: bit 15 = the code is longer than
 // kFastBits, bits 8..12 = bits consumed (code + value bits, <= 27), bits 0..6 = advance of the coefficient index
 // (DC: 1; AC: run + 1, ZRL 16, EOB 64).  No code: one bit consumed, index unchanged.
-__global__ void __launch_bounds__(256) k_jd_build_lut(const DecTables t, uint16_t* lut, uint16_t* adv) {
+__device__ __forceinline__ void build_lut_body(const DecTables& t, uint16_t* lut, uint16_t* adv) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;   // 4 tables x 65536
   const uint32_t tb = g >> 16, x = g & 0xFFFFu;
   const HuffSpec& h = t.huff[tb];
@@ -276,8 +277,8 @@ __device__ __forceinline__ bool sub_is_last(const DecJob& j, uint32_t i) { retur
 // previous subsequence as of the last round.  Both: decode until the subsequence's end is crossed, record the state.
 // Only subsequences whose start state changed in the previous round are decoded again (dirty_in).
 template <int ROUND>
-__global__ void __launch_bounds__(256) k_jd_sync(const DecJob j, const DState* prev, DState* next, const uint8_t* dirty_in,
-                                                 uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {
+__device__ __forceinline__ void sync_body(const DecJob& j, const DState* prev, DState* next, const uint8_t* dirty_in,
+                                          uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {
   __shared__ uint16_t s_adv[4][1u << kFastBits];
   load_fast_adv(j, s_adv);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256) k_jd_sync(const DecJob j, const DState* p
   dirty_out[i + 1u] = ch;     // the next subsequence starts from a new state
 }
 
-__global__ void __launch_bounds__(256) k_jd_write(const DecJob j, const DState* st, const uint32_t* first_block, uint32_t* error) {
+__device__ __forceinline__ void write_body(const DecJob& j, const DState* st, const uint32_t* first_block, uint32_t* error) {
   __shared__ uint16_t s_lut[4][1u << kFastBits];
   load_fast_lut(j, s_lut);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -348,7 +349,7 @@ struct BlkKey {   // restart interval a block belongs to: the DC predictors star
   uint32_t per;
   __host__ __device__ uint32_t operator()(uint32_t b) const { return b / per; }
 };
-__global__ void __launch_bounds__(256) k_jd_dc_apply(const DecJob j, const int* sum0, const int* sum1, const int* sum2) {
+__device__ __forceinline__ void dc_apply_body(const DecJob& j, const int* sum0, const int* sum1, const int* sum2) {
   const uint32_t b = blockIdx.x * 256u + threadIdx.x;
   if (b >= j.nblk) return;
   const int c = j.gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
@@ -381,7 +382,7 @@ __device__ __forceinline__ void idct8(int (&d)[64], int base, int stride) {   //
   d[base + 3 * stride] = dscale(tmp13 + tmp0, sh); d[base + 4 * stride] = dscale(tmp13 - tmp0, sh);
 }
 
-__global__ void __launch_bounds__(128) k_jd_idct(const DecJob j) {
+__device__ __forceinline__ void idct_body(const DecJob& j) {
   const uint32_t b = blockIdx.x * 128u + threadIdx.x;
   if (b >= j.nblk) return;
   int comp, br, bc;
@@ -434,6 +435,55 @@ __global__ void __launch_bounds__(128) k_jd_idct(const DecJob j) {
 
 // ---- host side -----------------------------------------------------------------------------------------------------
 // parse_header: csrc/uhdr_jpeg_hdr.cpp (plain C++, so that it can be fuzzed under AddressSanitizer on the CPU)
+
+// ---- the kernels: one image per launch (the job travels as a kernel argument), or one image per blockIdx.y of a single launch
+// (the jobs sit in device memory) -- the latter so that a batch of files costs the launches of one (decode_device_batch) ----------
+struct DecBatchJob {
+  DecJob j;
+  const uint8_t* src; uint32_t src_bytes; int rst;     // unstuffing: stuffed segment -> j.raw
+  uint32_t* kept; const uint32_t* kept_off; uint8_t* raw_out;
+  DecTables tables; uint16_t* lut_out; uint16_t* adv_out;
+  DState* st[2]; uint8_t* dirty[2]; uint32_t* nblocks; uint32_t* flags;
+  const uint32_t* first_block; const int* dc[3];
+  uint8_t* zero[3]; uint32_t zero_words[3];            // ranges k_jd_zero_multi clears (16-byte multiples)
+};
+__global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, uint32_t n, uint32_t* kept, int rst) { unstuff_count_body(src, n, kept, rst); }
+__global__ void __launch_bounds__(256) k_jd_unstuff_copy(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst, int rst) { unstuff_copy_body(src, n, off, dst, rst); }
+__global__ void __launch_bounds__(256) k_jd_build_lut(const DecTables t, uint16_t* lut, uint16_t* adv) { build_lut_body(t, lut, adv); }
+template <int ROUND>
+__global__ void __launch_bounds__(256) k_jd_sync(const DecJob j, const DState* prev, DState* next, const uint8_t* dirty_in, uint8_t* dirty_out,
+                                                 uint32_t* nblocks, uint32_t* changed) { sync_body<ROUND>(j, prev, next, dirty_in, dirty_out, nblocks, changed); }
+__global__ void __launch_bounds__(256) k_jd_write(const DecJob j, const DState* st, const uint32_t* first_block, uint32_t* error) { write_body(j, st, first_block, error); }
+__global__ void __launch_bounds__(256) k_jd_dc_apply(const DecJob j, const int* sum0, const int* sum1, const int* sum2) { dc_apply_body(j, sum0, sum1, sum2); }
+__global__ void __launch_bounds__(128) k_jd_idct(const DecJob j) { idct_body(j); }
+
+__global__ void __launch_bounds__(256) k_jd_zero_multi(const DecBatchJob* jobs) {
+  const DecBatchJob& b = jobs[blockIdx.y];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint4* p = reinterpret_cast<uint4*>(b.zero[k]);
+    const uint32_t n16 = b.zero_words[k];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+__global__ void __launch_bounds__(256) k_jd_unstuff_count_multi(const DecBatchJob* jobs) {
+  const DecBatchJob& b = jobs[blockIdx.y];
+  if (blockIdx.x == 0u && threadIdx.x == 0u) b.kept[(b.src_bytes + kUnstuffChunk - 1u) / kUnstuffChunk] = 0u;   // the scan's last input
+  unstuff_count_body(b.src, b.src_bytes, b.kept, b.rst);
+}
+__global__ void __launch_bounds__(256) k_jd_unstuff_copy_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; unstuff_copy_body(b.src, b.src_bytes, b.kept_off, b.raw_out, b.rst); }
+__global__ void __launch_bounds__(256) k_jd_build_lut_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; build_lut_body(b.tables, b.lut_out, b.adv_out); }
+// parity: which of the two state / dirty buffers is read (the other one is written); changed_all[image] collects "a round of the
+// last pair changed something" for one read-back per batch
+template <int ROUND>
+__global__ void __launch_bounds__(256) k_jd_sync_multi(const DecBatchJob* jobs, int parity, uint32_t* changed_all) {
+  const DecBatchJob& b = jobs[blockIdx.y];
+  if (ROUND == 0) sync_body<0>(b.j, nullptr, b.st[0], nullptr, b.dirty[0], b.nblocks, changed_all + blockIdx.y);
+  else sync_body<1>(b.j, b.st[parity], b.st[parity ^ 1], b.dirty[parity], b.dirty[parity ^ 1], b.nblocks, changed_all + blockIdx.y);
+}
+__global__ void __launch_bounds__(256) k_jd_write_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; write_body(b.j, b.st[0], b.first_block, b.flags + 1); }
+__global__ void __launch_bounds__(256) k_jd_dc_apply_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; dc_apply_body(b.j, b.dc[0], b.dc[1], b.dc[2]); }
+__global__ void __launch_bounds__(128) k_jd_idct_multi(const DecBatchJob* jobs) { idct_body(jobs[blockIdx.y].j); }
 
 size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -670,6 +720,150 @@ int decode_device_multi(int n, const DecInfo* const info[], const DecLayout l[],
     if (image_rc) image_rc[k] = bad[k] ? -1 : 0;
   }
   return out;
+}
+
+// The same for n images on ONE stream with one launch per decoder step for all of them (blockIdx.y = image): a batch of files costs
+// the kernel launches of a single image plus the per-image prefix sums, so the launch-submission bound of decode_device_multi is
+// gone and the images' synchronisation rounds run side by side by construction.  batch_ws: device scratch of at least
+// dec_batch_scratch_bytes(n).  image_rc / return value as decode_device_multi.
+size_t dec_batch_scratch_bytes(int n) { return (size_t)n * (sizeof(DecBatchJob) + 256 + 64) + 1024; }
+
+int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3], hipStream_t s,
+                        uint8_t* batch_ws, hipError_t* herr, int* image_rc) {
+#define JD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *herr = _e; (void)hipStreamSynchronize(s); return 1; } } while (0)
+  if (n < 1) return -1;
+  std::vector<DecBatchJob> jobs((size_t)n);
+  std::vector<int> bad((size_t)n, 0);
+  std::vector<std::vector<uint32_t>> keep;   // restart-interval tables: alive until the uploads have happened
+  DecBatchJob* djobs = reinterpret_cast<DecBatchJob*>(batch_ws);
+  uint32_t* dflags = reinterpret_cast<uint32_t*>(batch_ws + (((size_t)n * sizeof(DecBatchJob) + 255) / 256) * 256);   // 64 words per image
+  uint32_t* dchanged = dflags + 64u * (uint32_t)n;
+  uint32_t gu = 1, gsync = 1, gblk = 1, gidct = 1;
+  for (int k = 0; k < n; ++k) {
+    DecBatchJob& b = jobs[k];
+    memset(&b, 0, sizeof(b));
+    const DecInfo& in = *info[k];
+    const DecLayout& L = l[k];
+    uint8_t* w = ws[k];
+    b.src = w + L.src; b.src_bytes = (uint32_t)in.scan_bytes; b.rst = in.restart_interval != 0 ? 1 : 0;
+    b.kept = reinterpret_cast<uint32_t*>(w + L.kept); b.kept_off = reinterpret_cast<const uint32_t*>(w + L.kept_off); b.raw_out = w + L.raw;
+    b.tables = in.tables; b.lut_out = reinterpret_cast<uint16_t*>(w + L.lut); b.adv_out = reinterpret_cast<uint16_t*>(w + L.adv);
+    b.st[0] = reinterpret_cast<DState*>(w + L.st_a); b.st[1] = reinterpret_cast<DState*>(w + L.st_b);
+    b.dirty[0] = w + L.dirty_a; b.dirty[1] = w + L.dirty_b;
+    b.nblocks = reinterpret_cast<uint32_t*>(w + L.nblocks);
+    b.flags = dflags + 64u * (uint32_t)k;
+    b.first_block = reinterpret_cast<const uint32_t*>(w + L.first_block);
+    for (int c = 0; c < 3; ++c) b.dc[c] = reinterpret_cast<const int*>(w + L.dc[c]);
+    DecJob& j = b.j;
+    j.raw = reinterpret_cast<const uint32_t*>(w + L.raw);
+    j.lut = b.lut_out; j.adv = b.adv_out;
+    j.total_bits = in.raw_bytes * 8u;
+    j.nsub = (j.total_bits + kSubBits - 1u) / kSubBits;
+    j.gray = in.gray; j.nblk = L.nblk; j.mcus_x = L.mcus_x;
+    j.dc_tbl[0] = 0; j.ac_tbl[0] = 1; j.dc_tbl[1] = 2; j.ac_tbl[1] = 3;
+    j.coef = reinterpret_cast<int16_t*>(w + L.coef);
+    for (int c = 0; c < 3; ++c) { j.plane[c] = (*planes[k])[c]; memcpy(j.quant[c], in.quant[c], sizeof(j.quant[c])); }
+    if (b.rst) {
+      const size_t nint = in.interval_start.size();
+      std::vector<uint32_t> sb_, se_, sk_;
+      for (size_t q = 0; q < nint && !bad[k]; ++q) {
+        const uint32_t b0 = in.interval_start[q] * 8u, b1 = (q + 1 < nint ? in.interval_start[q + 1] : in.raw_bytes) * 8u;
+        if (b1 <= b0) { bad[k] = 1; break; }
+        for (uint32_t x = b0; x < b1; x += kSubBits) { sb_.push_back(x); se_.push_back(x + kSubBits < b1 ? x + kSubBits : b1); sk_.push_back((uint32_t)q); }
+      }
+      j.nsub = (uint32_t)sb_.size();
+      if (!bad[k] && j.nsub != 0u && j.nsub <= L.nsub_max) {
+        sk_.push_back(0xFFFFFFFFu);
+        JD_TRY(hipMemcpyAsync(w + L.sub_start, sb_.data(), sb_.size() * 4, hipMemcpyHostToDevice, s));
+        JD_TRY(hipMemcpyAsync(w + L.sub_end, se_.data(), se_.size() * 4, hipMemcpyHostToDevice, s));
+        JD_TRY(hipMemcpyAsync(w + L.sub_key, sk_.data(), sk_.size() * 4, hipMemcpyHostToDevice, s));
+        keep.push_back(std::move(sb_)); keep.push_back(std::move(se_)); keep.push_back(std::move(sk_));
+        j.sub_start = reinterpret_cast<const uint32_t*>(w + L.sub_start);
+        j.sub_end = reinterpret_cast<const uint32_t*>(w + L.sub_end);
+        j.sub_key = reinterpret_cast<const uint32_t*>(w + L.sub_key);
+        j.restart_blocks = in.restart_interval * (in.gray ? 1u : 6u);
+      }
+    }
+    if (j.nsub == 0u || j.nsub > L.nsub_max) bad[k] = 1;
+    if (bad[k]) { j.nsub = 0u; j.nblk = 0u; b.src_bytes = 0u; }   // every kernel's bounds check then skips this image
+    b.zero[0] = reinterpret_cast<uint8_t*>(b.flags); b.zero_words[0] = 16u;
+    b.zero[1] = w + L.raw; b.zero_words[1] = bad[k] ? 0u : (uint32_t)((((size_t)in.scan_bytes + 64 + 255) / 256 * 256) / 16);
+    b.zero[2] = reinterpret_cast<uint8_t*>(j.coef); b.zero_words[2] = (uint32_t)(((size_t)j.nblk * 128) / 16);
+    gu = std::max(gu, (L.nchunks + 255u) / 256u);
+    gsync = std::max(gsync, (j.nsub + 255u) / 256u);
+    gblk = std::max(gblk, (j.nblk + 255u) / 256u);
+    gidct = std::max(gidct, (j.nblk + 127u) / 128u);
+  }
+  JD_TRY(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(DecBatchJob), hipMemcpyHostToDevice, s));
+  JD_TRY(hipStreamSynchronize(s));   // jobs / restart tables are in pageable host memory
+  keep.clear();
+  const dim3 b256(256);
+  const unsigned ny = (unsigned)n;
+  hipLaunchKernelGGL(k_jd_zero_multi, dim3(512, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  hipLaunchKernelGGL(k_jd_unstuff_count_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  for (int k = 0; k < n; ++k) {
+    if (bad[k]) continue;
+    size_t tmp = l[k].scan_tmp_bytes;
+    JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws[k] + l[k].scan_tmp, tmp, jobs[k].kept, const_cast<uint32_t*>(jobs[k].kept_off), (int)(l[k].nchunks + 1u), s));
+  }
+  hipLaunchKernelGGL(k_jd_unstuff_copy_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  hipLaunchKernelGGL(k_jd_build_lut_multi, dim3(4u * 65536u / 256u, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  hipLaunchKernelGGL(k_jd_sync_multi<0>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, dchanged);
+  std::vector<uint32_t> changed((size_t)n, 0u);
+  uint32_t max_nsub = 0;
+  for (int k = 0; k < n; ++k) max_nsub = std::max(max_nsub, jobs[k].j.nsub);
+  uint32_t done_rounds = 0;
+  for (uint32_t batch = 4;; batch = batch < 16u ? batch * 2u : 16u) {
+    if (done_rounds > max_nsub + 32u) { (void)hipStreamSynchronize(s); return -1; }   // cannot happen: every round fixes at least one more subsequence
+    for (uint32_t r = 0; r < batch; r += 2) {
+      if (r == batch - 2) JD_TRY(hipMemsetAsync(dchanged, 0, (size_t)n * 4, s));
+      hipLaunchKernelGGL(k_jd_sync_multi<1>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, dchanged);
+      hipLaunchKernelGGL(k_jd_sync_multi<1>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 1, dchanged);
+    }
+    done_rounds += batch;
+    JD_TRY(hipMemcpyAsync(changed.data(), dchanged, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    JD_TRY(hipStreamSynchronize(s));
+    bool any = false;
+    for (int k = 0; k < n; ++k) any = any || changed[k] != 0u;
+    if (!any) break;
+  }
+  for (int k = 0; k < n; ++k) {
+    if (bad[k]) continue;
+    size_t tmp = l[k].scan_tmp_bytes;
+    uint32_t* first_block = const_cast<uint32_t*>(jobs[k].first_block);
+    if (jobs[k].rst) JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(ws[k] + l[k].scan_tmp, tmp, jobs[k].j.sub_key, jobs[k].nblocks, first_block, (int)jobs[k].j.nsub, hipcub::Equality(), s));
+    else JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws[k] + l[k].scan_tmp, tmp, jobs[k].nblocks, first_block, (int)jobs[k].j.nsub, s));
+  }
+  hipLaunchKernelGGL(k_jd_write_multi, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  for (int k = 0; k < n; ++k) {
+    if (bad[k]) continue;
+    const DecJob& j = jobs[k].j;
+    for (int c = 0; c < (j.gray ? 1 : 3); ++c) {
+      hipcub::CountingInputIterator<uint32_t> cnt(0u);
+      hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{j.coef, c, j.gray});
+      size_t tmp = l[k].scan_tmp_bytes;
+      int* dc = const_cast<int*>(jobs[k].dc[c]);
+      if (jobs[k].rst) {
+        hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{j.restart_blocks});
+        JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(ws[k] + l[k].scan_tmp, tmp, keys, it, dc, (int)j.nblk, hipcub::Equality(), s));
+      } else {
+        JD_TRY(hipcub::DeviceScan::InclusiveSum(ws[k] + l[k].scan_tmp, tmp, it, dc, (int)j.nblk, s));
+      }
+    }
+  }
+  hipLaunchKernelGGL(k_jd_dc_apply_multi, dim3(gblk, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  hipLaunchKernelGGL(k_jd_idct_multi, dim3(gidct, ny), dim3(128), 0, s, (const DecBatchJob*)djobs);
+  std::vector<uint32_t> flags((size_t)n * 64u, 0u);
+  JD_TRY(hipMemcpyAsync(flags.data(), dflags, flags.size() * 4, hipMemcpyDeviceToHost, s));
+  JD_TRY(hipStreamSynchronize(s));
+  JD_TRY(hipGetLastError());
+  int out = 0;
+  for (int k = 0; k < n; ++k) {
+    if (bad[k] || flags[64u * (size_t)k + 1u]) { bad[k] = 1; out = -1; }
+    if (image_rc) image_rc[k] = bad[k] ? -1 : 0;
+  }
+  return out;
+#undef JD_TRY
 }
 
 int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr) {

@@ -247,6 +247,34 @@ def other_configs(lib, stream):
         out["JPEG/R %dx%d HLG q95: encodeJPEGR API-0 / API-1, decodeJPEGR -> RGBA1010102 (wall clock per call)" % (cw, ch)] = {
             "encode_api0_ms": round(t_api0, 3), "encode_api1_ms": round(t_api1, 3), "decode_ms": round(t_dec, 3), "file_bytes": int(fbytes.size),
             "encode_api1_MPix/s": round(cw * ch / 1e6 / (t_api1 * 1e-3), 1), "decode_MPix/s": round(cw * ch / 1e6 / (t_dec * 1e-3), 1)}
+    # ... and 16 files per call (uhdr_hip_jpegr_decode_batch: every decoder kernel covers all images of the call)
+    nb16 = 16
+    blobs = []
+    for i in range(nb16):
+        bp, by = synth.smooth_frame(W, H, 300 + i)
+        bpi, byi = api.p010_image(bp.data_ptr(), W, H, api.CG_BT2100), api.yuv420_image(by.data_ptr(), W, H, api.CG_BT709)
+        fb, fnn = np.zeros(W * H * 3, np.uint8), C.c_size_t()
+        assert lib.uhdr_hip_jpegr_encode_api1(C.byref(bpi), C.byref(byi), api.TF_HLG, 95, None, 0, C.c_void_p(fb.ctypes.data), fb.size, C.byref(fnn), api.MEM_DEVICE, stream) == 0
+        blobs.append(fb[:fnn.value].copy())
+    del bp, by
+    bptr = (C.c_void_p * nb16)(*[b.ctypes.data for b in blobs])
+    bsz = (C.c_size_t * nb16)(*[b.size for b in blobs])
+    bouts = [torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda") for _ in range(nb16)]
+    boptr = (C.c_void_p * nb16)(*[o.data_ptr() for o in bouts])
+    bocap = (C.c_size_t * nb16)(*[o.numel() for o in bouts])
+    bdests, bmds, bstat = (api.Image * nb16)(), (api.Metadata * nb16)(), (C.c_int * nb16)()
+
+    def dec16():
+        assert lib.uhdr_hip_jpegr_decode_batch(nb16, bptr, bsz, api.OUTPUT_HDR_HLG, api.FLT_MAX, boptr, bocap, bdests, bmds, bstat, api.APPLY_FAST, api.MEM_DEVICE, stream) == 0
+    for _ in range(3):
+        dec16()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dec16()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    out["JPEG/R decode, 16 x 4K files per call (uhdr_hip_jpegr_decode_batch) -> RGBA1010102"] = {
+        "ms_per_call": round(ms, 3), "ms_per_file": round(ms / nb16, 3), "MPix/s": round(nb16 * W * H / 1e6 / (ms * 1e-3), 1)}
+    del bouts
     # configs[4]: 7680x4320 decode-side apply
     w8, h8 = 7680, 4320
     _, y8 = synth.lcg_frame(w8, h8, 1234)

@@ -482,7 +482,7 @@ def main():
         per_launch = (APP_BYTES if dominant == "apply" else GEN_BYTES) * min(CHUNK, a.frames)
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command
+        if os.path.exists(tp) and min(CHUNK, a.frames) == 64:   # HBM bytes per 64-frame launch from rocprofv3 --pmc passes of this same command
             try:
                 tj = json.load(open(tp))
                 traffic, traffic_src = tj.get(dominant), tj.get("source")

@@ -647,7 +647,11 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
   planes[0] = mk(dout, w, h);
   if (!info.gray) { planes[1] = mk(dout + luma, w / 2, h / 2); planes[2] = mk(dout + luma + chroma, w / 2, h / 2); }
   hipError_t herr = hipSuccess;
-  const int drc = jpeg::decode_device(info, l, ws, planes, s, &herr);
+  if ((rc = stage_reserve(st, 11, jpeg::dec_batch_scratch_bytes(1))) != 0) return rc;
+  const jpeg::DecInfo* infos[1] = {&info};
+  uint8_t* wss[1] = {ws};
+  jpeg::DecPlane (*pl[1])[3] = {&planes};
+  const int drc = jpeg::decode_device_batch(1, infos, &l, wss, pl, s, static_cast<uint8_t*>(st->stage[11]), &herr, nullptr);
   if (drc > 0) { set_err("uhdr_hip_jpeg_decode", herr); return UHDR_HIP_UNKNOWN_ERROR; }
   if (drc < 0) { snprintf(t_err, sizeof(t_err), "uhdr_hip_jpeg_decode: corrupt entropy-coded data"); return UHDR_HIP_UNKNOWN_ERROR; }
   if (mem_space != UHDR_HIP_MEM_DEVICE) {

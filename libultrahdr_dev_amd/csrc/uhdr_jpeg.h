@@ -96,13 +96,6 @@ struct DecJob {
 // 0 ok, -1 malformed, -2 outside what this decoder (or the reference: sampling) supports
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info);
 size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l);
-// the entropy-coded segment must already sit at ws + l.src; 0 ok, -1 corrupt stream, 1 HIP error (*herr)
-int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr);
-// the same for n images advancing in lock step, image k with its own workspace on streams[k] (their latency-bound synchronisation
-// rounds overlap); image_rc (optional): 0 / -1 per image
-int decode_device_multi(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3],
-                        const hipStream_t streams[], hipError_t* herr, int* image_rc);
-
 // n images on one stream with one launch per decoder step for all of them (blockIdx.y = image); batch_ws: device scratch of
 // dec_batch_scratch_bytes(n)
 size_t dec_batch_scratch_bytes(int n);

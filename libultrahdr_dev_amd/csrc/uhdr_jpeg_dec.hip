@@ -8,24 +8,26 @@
 // A baseline scan without restart markers is ONE bit string: where a code starts is only known once everything before
 // it has been decoded.  The decoder uses the self-synchronisation of Huffman codes (Klein & Wiseman 2003; Weissenberger &
 // Schmidt 2018): a decoder started at a wrong bit position falls in step with the true decoder after a few symbols.
-//   k_jd_unstuff_*   drop the 0x00 after every 0xFF (count per 256-byte chunk, scan, compact) -> raw bit string
-//   k_jd_build_lut   16-bit lookup tables (length, symbol) of the file's own Huffman tables
-//   k_jd_sync<0>     every thread decodes one 512-bit subsequence from a guessed state (block 0, coefficient 0) and
+//   k_jd_unstuff_*_multi   drop the 0x00 after every 0xFF (count per 256-byte chunk, scan, compact) -> raw bit string
+//   k_jd_build_lut_multi   16-bit lookup tables (length, symbol) of the file's own Huffman tables
+//   k_jd_sync_multi<0>     every thread decodes one 512-bit subsequence from a guessed state (block 0, coefficient 0) and
 //                    records the state (bit, block-in-MCU, coefficient) it crosses the subsequence's end with
-//   k_jd_sync<1>     rounds: thread i re-decodes subsequence i from the end state of i-1 (only if that state changed);
+//   k_jd_sync_multi<1>     rounds: thread i re-decodes subsequence i from the end state of i-1 (only if that state changed);
 //                    when no end state changes any more, every subsequence's start state is the true one (thread 0
 //                    starts from the true state).  Bit and coefficient position fall in step within tens of bits, the
 //                    block-in-MCU index (which decides luma vs. chroma tables) only after ~7 MCUs of a 4:2:0 file, so
 //                    a 4K frame takes 5-8 rounds at quality 75 and 21-24 at quality 95; a round is one lane decoding
 //                    512 bits (~25 us), whatever the number of subsequences: that product is the decoder's latency.
 //   (scan of the blocks completed per subsequence -> index of the block each subsequence starts in)
-//   k_jd_write       final decode from the true start states: DC differences and AC values into zeroed coefficient blocks
+//   k_jd_write_multi       final decode from the true start states: DC differences and AC values into zeroed coefficient blocks
 //   (three masked scans turn DC differences into DC values per component)
-//   k_jd_idct        one thread per block: dequantise, "islow" IDCT, +128, clamp, store cropped to the plane
+//   k_jd_idct_multi        one thread per block: dequantise, "islow" IDCT, +128, clamp, store cropped to the plane
 // Restart intervals (DRI / RSTn) make the job easier, not harder: every interval is a byte-aligned bit string of its own whose
 // start state is known, so its first subsequence plays the role of subsequence 0, nothing is carried across an interval boundary,
 // and the block index and the DC predictors restart with it (segmented scans).  The host finds the markers while it looks for the
 // end of the segment (parse_header) and the unstuffing pass drops them like the stuffed zeros.
+// Every kernel has a second grid dimension over images (blockIdx.y; the per-image jobs sit in device memory): a JPEG/R file is two
+// JPEGs and a server decodes many files at once, and since a decode is latency-bound the images of a call cost little more than one.
 // Progressive or arithmetic-coded files return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE (libjpeg reads them, the reference's encoder
 // never writes them); samplings other than 4:2:0 / grayscale fail as they do in the reference.
 #include <hip/hip_runtime.h>
@@ -436,8 +438,8 @@ __device__ __forceinline__ void idct_body(const DecJob& j) {
 // ---- host side -----------------------------------------------------------------------------------------------------
 // parse_header: csrc/uhdr_jpeg_hdr.cpp (plain C++, so that it can be fuzzed under AddressSanitizer on the CPU)
 
-// ---- the kernels: one image per launch (the job travels as a kernel argument), or one image per blockIdx.y of a single launch
-// (the jobs sit in device memory) -- the latter so that a batch of files costs the launches of one (decode_device_batch) ----------
+// ---- the kernels: one image per blockIdx.y of a launch, the jobs sit in device memory -- so that a batch of files costs the
+// launches of one image (decode_device_batch); the bodies above take blockIdx.x / threadIdx.x as "their" image's grid --------------
 struct DecBatchJob {
   DecJob j;
   const uint8_t* src; uint32_t src_bytes; int rst;     // unstuffing: stuffed segment -> j.raw
@@ -447,16 +449,6 @@ struct DecBatchJob {
   const uint32_t* first_block; const int* dc[3];
   uint8_t* zero[3]; uint32_t zero_words[3];            // ranges k_jd_zero_multi clears (16-byte multiples)
 };
-__global__ void __launch_bounds__(256) k_jd_unstuff_count(const uint8_t* src, uint32_t n, uint32_t* kept, int rst) { unstuff_count_body(src, n, kept, rst); }
-__global__ void __launch_bounds__(256) k_jd_unstuff_copy(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst, int rst) { unstuff_copy_body(src, n, off, dst, rst); }
-__global__ void __launch_bounds__(256) k_jd_build_lut(const DecTables t, uint16_t* lut, uint16_t* adv) { build_lut_body(t, lut, adv); }
-template <int ROUND>
-__global__ void __launch_bounds__(256) k_jd_sync(const DecJob j, const DState* prev, DState* next, const uint8_t* dirty_in, uint8_t* dirty_out,
-                                                 uint32_t* nblocks, uint32_t* changed) { sync_body<ROUND>(j, prev, next, dirty_in, dirty_out, nblocks, changed); }
-__global__ void __launch_bounds__(256) k_jd_write(const DecJob j, const DState* st, const uint32_t* first_block, uint32_t* error) { write_body(j, st, first_block, error); }
-__global__ void __launch_bounds__(256) k_jd_dc_apply(const DecJob j, const int* sum0, const int* sum1, const int* sum2) { dc_apply_body(j, sum0, sum1, sum2); }
-__global__ void __launch_bounds__(128) k_jd_idct(const DecJob j) { idct_body(j); }
-
 __global__ void __launch_bounds__(256) k_jd_zero_multi(const DecBatchJob* jobs) {
   const DecBatchJob& b = jobs[blockIdx.y];
 #pragma unroll
@@ -542,190 +534,11 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   return o;
 }
 
-// One decode in flight: the decoder's kernels are enqueued in three phases so that two images (the primary image and the gain
-// map of a JPEG/R file) can advance in lock step on two streams -- their latency-bound synchronisation rounds then overlap.
-//   begin()    unstuffing, table building, the first pass
-//   rounds(n)  n more synchronisation rounds; poll() enqueues the read-back of "did the last pair change anything"
-//   finish()   block indices, final pass, DC scans, IDCT; the error flag is read back by poll_error()
-// Every method returns 0, -1 (corrupt stream) or 1 (HIP error in herr).  The caller synchronises the stream between poll and
-// the use of `changed` / `error`.
-struct DecRun {
-  const DecInfo* info = nullptr;
-  DecLayout l;
-  uint8_t* ws = nullptr;
-  hipStream_t s = nullptr;
-  hipError_t herr = hipSuccess;
-  DecJob j;
-  DState* sa = nullptr;
-  DState* sb = nullptr;
-  uint8_t* da = nullptr;
-  uint8_t* db = nullptr;
-  uint32_t* nblocks = nullptr;
-  uint32_t* flags = nullptr;
-  dim3 gs;
-  int rst = 0;
-  uint32_t done_rounds = 0, changed = 1, error = 0;
-  bool converged = false;
-
-#define JD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { herr = _e; return 1; } } while (0)
-  int begin(const DecInfo& info_, const DecLayout& l_, uint8_t* ws_, DecPlane planes[3], hipStream_t s_) {
-    info = &info_; l = l_; ws = ws_; s = s_;
-    const uint32_t nbytes = (uint32_t)info->scan_bytes;
-    uint8_t* src = ws + l.src;
-    uint8_t* raw = ws + l.raw;
-    uint32_t* kept = reinterpret_cast<uint32_t*>(ws + l.kept);
-    uint32_t* kept_off = reinterpret_cast<uint32_t*>(ws + l.kept_off);
-    flags = reinterpret_cast<uint32_t*>(ws + l.flags);
-    JD_TRY(hipMemsetAsync(flags, 0, 256, s));
-    JD_TRY(hipMemsetAsync(raw, 0, ((size_t)nbytes + 64 + 255) / 256 * 256, s));
-    JD_TRY(hipMemsetAsync(kept + l.nchunks, 0, 4, s));
-    const dim3 gu((l.nchunks + 255u) / 256u), b256(256);
-    rst = info->restart_interval != 0 ? 1 : 0;
-    hipLaunchKernelGGL(k_jd_unstuff_count, gu, b256, 0, s, src, nbytes, kept, rst);
-    size_t tmp = l.scan_tmp_bytes;
-    JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, kept, kept_off, (int)(l.nchunks + 1u), s));
-    hipLaunchKernelGGL(k_jd_unstuff_copy, gu, b256, 0, s, src, nbytes, kept_off, raw, rst);
-    const uint32_t raw_bytes = info->raw_bytes;   // the host counted the stuffed zeros and markers while it looked for the segment's end: no round trip
-    hipLaunchKernelGGL(k_jd_build_lut, dim3(4u * 65536u / 256u), b256, 0, s, info->tables, reinterpret_cast<uint16_t*>(ws + l.lut),
-                       reinterpret_cast<uint16_t*>(ws + l.adv));
-
-    memset(&j, 0, sizeof(j));
-    j.raw = reinterpret_cast<const uint32_t*>(raw);
-    j.lut = reinterpret_cast<const uint16_t*>(ws + l.lut);
-    j.adv = reinterpret_cast<const uint16_t*>(ws + l.adv);
-    j.total_bits = raw_bytes * 8u;
-    j.nsub = (j.total_bits + kSubBits - 1u) / kSubBits;
-    if (rst) {
-      // one table row per subsequence: the intervals found by the host scan, cut into 512-bit pieces
-      const size_t nint = info->interval_start.size();
-      std::vector<uint32_t> sb_, se_, sk_;
-      for (size_t k = 0; k < nint; ++k) {
-        const uint32_t b0 = info->interval_start[k] * 8u, b1 = (k + 1 < nint ? info->interval_start[k + 1] : raw_bytes) * 8u;
-        if (b1 <= b0) return -1;   // an empty interval
-        for (uint32_t b = b0; b < b1; b += kSubBits) { sb_.push_back(b); se_.push_back(b + kSubBits < b1 ? b + kSubBits : b1); sk_.push_back((uint32_t)k); }
-      }
-      j.nsub = (uint32_t)sb_.size();
-      if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
-      sk_.push_back(0xFFFFFFFFu);
-      JD_TRY(hipMemcpyAsync(ws + l.sub_start, sb_.data(), sb_.size() * 4, hipMemcpyHostToDevice, s));
-      JD_TRY(hipMemcpyAsync(ws + l.sub_end, se_.data(), se_.size() * 4, hipMemcpyHostToDevice, s));
-      JD_TRY(hipMemcpyAsync(ws + l.sub_key, sk_.data(), sk_.size() * 4, hipMemcpyHostToDevice, s));
-      JD_TRY(hipStreamSynchronize(s));   // the vectors go out of scope
-      j.sub_start = reinterpret_cast<const uint32_t*>(ws + l.sub_start);
-      j.sub_end = reinterpret_cast<const uint32_t*>(ws + l.sub_end);
-      j.sub_key = reinterpret_cast<const uint32_t*>(ws + l.sub_key);
-      j.restart_blocks = info->restart_interval * (info->gray ? 1u : 6u);
-    }
-    if (j.nsub == 0u || j.nsub > l.nsub_max) return -1;
-    j.gray = info->gray;
-    j.nblk = l.nblk;
-    j.mcus_x = l.mcus_x;
-    j.dc_tbl[0] = 0; j.ac_tbl[0] = 1; j.dc_tbl[1] = 2; j.ac_tbl[1] = 3;
-    j.coef = reinterpret_cast<int16_t*>(ws + l.coef);
-    for (int c = 0; c < 3; ++c) { j.plane[c] = planes[c]; memcpy(j.quant[c], info->quant[c], sizeof(j.quant[c])); }
-    sa = reinterpret_cast<DState*>(ws + l.st_a);
-    sb = reinterpret_cast<DState*>(ws + l.st_b);
-    gs = dim3((j.nsub + 255u) / 256u);
-    da = ws + l.dirty_a;
-    db = ws + l.dirty_b;
-    nblocks = reinterpret_cast<uint32_t*>(ws + l.nblocks);
-    hipLaunchKernelGGL(k_jd_sync<0>, gs, b256, 0, s, j, (const DState*)nullptr, sa, (const uint8_t*)nullptr, da, nblocks, flags);
-    return 0;
-  }
-  // rounds until a round changes nothing.  A host check costs a stream round trip (~25 us), a round that has nothing left to do a
-  // launch (~4 us): the callers enqueue rounds in growing batches (4, 8, 16, 16, ...); only the last pair of a batch reports
-  int rounds(uint32_t batch) {
-    if (done_rounds > j.nsub + 32u) return -1;   // cannot happen: every round fixes at least one more subsequence
-    const dim3 b256(256);
-    for (uint32_t r = 0; r < batch; r += 2) {
-      if (r == batch - 2) JD_TRY(hipMemsetAsync(flags, 0, 4, s));
-      hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sa, sb, (const uint8_t*)da, db, nblocks, flags);
-      hipLaunchKernelGGL(k_jd_sync<1>, gs, b256, 0, s, j, (const DState*)sb, sa, (const uint8_t*)db, da, nblocks, flags);
-    }
-    done_rounds += batch;
-    return 0;
-  }
-  int poll() { JD_TRY(hipMemcpyAsync(&changed, flags, 4, hipMemcpyDeviceToHost, s)); return 0; }
-  int finish() {
-    const dim3 b256(256);
-    uint32_t* first_block = reinterpret_cast<uint32_t*>(ws + l.first_block);
-    size_t tmp = l.scan_tmp_bytes;
-    if (rst) JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(ws + l.scan_tmp, tmp, j.sub_key, nblocks, first_block, (int)j.nsub, hipcub::Equality(), s));
-    else JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, nblocks, first_block, (int)j.nsub, s));
-    JD_TRY(hipMemsetAsync(j.coef, 0, (size_t)j.nblk * 128, s));
-    hipLaunchKernelGGL(k_jd_write, gs, b256, 0, s, j, (const DState*)sa, (const uint32_t*)first_block, flags + 1);
-    int* dc[3] = {reinterpret_cast<int*>(ws + l.dc[0]), reinterpret_cast<int*>(ws + l.dc[1]), reinterpret_cast<int*>(ws + l.dc[2])};
-    for (int c = 0; c < (info->gray ? 1 : 3); ++c) {
-      hipcub::CountingInputIterator<uint32_t> cnt(0u);
-      hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{j.coef, c, info->gray});
-      tmp = l.scan_tmp_bytes;
-      if (rst) {
-        hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{j.restart_blocks});
-        JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(ws + l.scan_tmp, tmp, keys, it, dc[c], (int)j.nblk, hipcub::Equality(), s));
-      } else {
-        JD_TRY(hipcub::DeviceScan::InclusiveSum(ws + l.scan_tmp, tmp, it, dc[c], (int)j.nblk, s));
-      }
-    }
-    const dim3 gb256((j.nblk + 255u) / 256u);
-    hipLaunchKernelGGL(k_jd_dc_apply, gb256, b256, 0, s, j, (const int*)dc[0], (const int*)dc[1], (const int*)dc[2]);
-    hipLaunchKernelGGL(k_jd_idct, dim3((j.nblk + 127u) / 128u), dim3(128), 0, s, j);
-    return 0;
-  }
-  int poll_error() { JD_TRY(hipMemcpyAsync(&error, flags + 1, 4, hipMemcpyDeviceToHost, s)); return 0; }
-#undef JD_TRY
-};
-
-// Runs the whole decoder for n images advancing in lock step, image k with its own workspace on streams[k] (streams may repeat:
-// images on one stream run one after the other, images on different streams side by side).  Synchronises: the number of
-// synchronisation rounds is data dependent.  The entropy-coded segment of image k must already sit at ws[k] + l[k].src.
+// Runs the whole decoder for n images on one stream with ONE launch per decoder step for all of them (blockIdx.y = image): a batch of
+// files costs the kernel launches of a single image plus the per-image prefix sums, and the images' latency-bound synchronisation
+// rounds run side by side by construction.  Synchronises (the number of rounds is data dependent).  The entropy-coded segment of
+// image k must already sit at ws[k] + l[k].src; batch_ws: device scratch of at least dec_batch_scratch_bytes(n).
 // image_rc[k] (optional) receives 0 or -1 (corrupt stream) per image; returns 0, -1 (some image corrupt) or 1 (HIP error in *herr).
-int decode_device_multi(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3],
-                        const hipStream_t streams[], hipError_t* herr, int* image_rc) {
-  if (n < 1) return -1;
-  std::vector<DecRun> run((size_t)n);
-  std::vector<int> bad((size_t)n, 0);
-  auto fail = [&](int k) { *herr = run[k].herr; for (int q = 0; q < n; ++q) (void)hipStreamSynchronize(streams[q]); return 1; };
-  int rc;
-  for (int k = 0; k < n; ++k) {
-    rc = run[k].begin(*info[k], l[k], ws[k], *planes[k], streams[k]);
-    if (rc > 0) return fail(k);
-    if (rc < 0) { bad[k] = 1; run[k].converged = true; }
-  }
-  for (uint32_t batch = 4;; batch = batch < 16u ? batch * 2u : 16u) {
-    bool any = false;
-    for (int k = 0; k < n; ++k)
-      if (!run[k].converged) {
-        any = true;
-        rc = run[k].rounds(batch);
-        if (rc > 0) return fail(k);
-        if (rc < 0) { bad[k] = 1; run[k].converged = true; }
-      }
-    if (!any) break;
-    // read-backs after everything is enqueued: a copy into pageable memory may block the host until its stream gets there
-    for (int k = 0; k < n; ++k)
-      if (!run[k].converged && run[k].poll() != 0) return fail(k);
-    for (int k = 0; k < n; ++k)
-      if (!run[k].converged) {
-        if (hipStreamSynchronize(streams[k]) != hipSuccess) { run[k].herr = hipGetLastError(); return fail(k); }
-        run[k].converged = run[k].changed == 0u;
-        if (run[k].converged && run[k].finish() != 0) return fail(k);   // the epilogue of one runs under the rounds of the others
-      }
-  }
-  for (int k = 0; k < n; ++k)
-    if (!bad[k] && run[k].poll_error() != 0) return fail(k);
-  int out = 0;
-  for (int k = 0; k < n; ++k) {
-    if (hipStreamSynchronize(streams[k]) != hipSuccess || hipGetLastError() != hipSuccess) { run[k].herr = hipErrorUnknown; return fail(k); }
-    if (bad[k] || run[k].error) { bad[k] = 1; out = -1; }
-    if (image_rc) image_rc[k] = bad[k] ? -1 : 0;
-  }
-  return out;
-}
-
-// The same for n images on ONE stream with one launch per decoder step for all of them (blockIdx.y = image): a batch of files costs
-// the kernel launches of a single image plus the per-image prefix sums, so the launch-submission bound of decode_device_multi is
-// gone and the images' synchronisation rounds run side by side by construction.  batch_ws: device scratch of at least
-// dec_batch_scratch_bytes(n).  image_rc / return value as decode_device_multi.
 size_t dec_batch_scratch_bytes(int n) { return (size_t)n * (sizeof(DecBatchJob) + 256 + 64) + 1024; }
 
 int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3], hipStream_t s,
@@ -864,13 +677,6 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   }
   return out;
 #undef JD_TRY
-}
-
-int decode_device(const DecInfo& info, const DecLayout& l, uint8_t* ws, DecPlane planes[3], hipStream_t s, hipError_t* herr) {
-  const DecInfo* infos[1] = {&info};
-  uint8_t* wss[1] = {ws};
-  DecPlane (*pl[1])[3] = {reinterpret_cast<DecPlane (*)[3]>(planes)};
-  return decode_device_multi(1, infos, &l, wss, pl, &s, herr, nullptr);
 }
 
 }  // namespace jpeg

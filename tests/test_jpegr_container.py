@@ -785,3 +785,52 @@ def test_gpu_sdr_rendition_is_libjpeg_turbos(hip, orc, device):
     rc, got, dest, _ = _gpu_decode(lib, hip, data, hip.OUTPUT_SDR, FLT_MAX, hip.APPLY_FAST, device)
     turbo = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
     assert np.array_equal(got.reshape(720, 1280, 4)[..., :3], turbo)
+
+
+@pytest.mark.gpu
+def test_gpu_codec_random_sweep(hip, orc):
+    """the reference's fuzzers draw API / gamuts / transfer function / quality / dimensions at random (fuzzer/ultrahdr_enc_fuzzer.cpp:87-319);
+    the same sweep as a parity test: 160 random configurations, every file byte for byte against the CPU restatement, then decoded to a
+    random output format and compared again"""
+    from oracle import jpegr_oracle as J
+    from tests.test_gpu_parity import smooth_frame
+    lib = hip.load()
+    rng = np.random.RandomState(20261004)
+    fmts = (hip.OUTPUT_SDR, hip.OUTPUT_HDR_LINEAR, hip.OUTPUT_HDR_PQ, hip.OUTPUT_HDR_HLG)
+    ofmt = {hip.OUTPUT_SDR: orc.OUT_SDR, hip.OUTPUT_HDR_LINEAR: orc.OUT_HDR_LINEAR, hip.OUTPUT_HDR_PQ: orc.OUT_HDR_PQ, hip.OUTPUT_HDR_HLG: orc.OUT_HDR_HLG}
+    for case in range(160):
+        w, h = 2 * int(rng.randint(4, 200)), 2 * int(rng.randint(4, 150))
+        if case % 6 == 0:
+            w, h = 4 * int(rng.randint(2, 100)), 4 * int(rng.randint(2, 75))
+        pg, sg, tf, q = int(rng.randint(0, 3)), int(rng.randint(0, 3)), int(rng.randint(0, 3)), int(rng.randint(0, 101))
+        api_n, device = int(rng.randint(0, 4)), bool(rng.randint(0, 2))
+        p010, yuv = smooth_frame(w, h, 1000 + case)
+        if case % 5 == 0:       # noise instead of smooth content
+            yuv = rng.randint(0, 256, yuv.size).astype(np.uint8)
+            p010 = (rng.randint(64, 941, p010.size).astype(np.uint16) << 6)
+        e = _Enc(hip, device)
+        if api_n == 0:
+            want = J.encode_api0(p010, w, h, pg, tf, q)
+            rc, got = e.run("api0", e.p010(p010, w, h, pg), tf, q, None)
+        elif api_n == 1:
+            want = J.encode_api1(p010, yuv, w, h, sg, pg, tf, q)
+            rc, got = e.run("api1", e.p010(p010, w, h, pg), e.yuv(yuv, w, h, sg), tf, q, None)
+        else:
+            sdr_jpeg = orc.jpeg_encode("orc", yuv[:w * h], yuv[w * h:], w, h, q, icc=J.icc_profile_srgb_transfer(sg) if case % 2 else None)
+            if api_n == 2:
+                want = J.encode_api2(p010, yuv, w, h, sg, pg, sdr_jpeg, sg, tf)
+                rc, got = e.run("api2", e.p010(p010, w, h, pg), e.yuv(yuv, w, h, sg), sdr_jpeg, sg, tf)
+            else:
+                want = J.encode_api3(p010, w, h, pg, sdr_jpeg, sg, tf)
+                rc, got = e.run("api3", e.p010(p010, w, h, pg), sdr_jpeg, sg, tf)
+        tag = (case, api_n, w, h, pg, sg, tf, q, device)
+        assert isinstance(want, bytes) and rc == 0 and got == want, tag
+        fmt = fmts[int(rng.randint(0, 4))]
+        boost = float(rng.choice([FLT_MAX, 1.0, 2.5]))
+        st, ref, ow, oh, gamut, md = J.decode(got, ofmt[fmt], boost)
+        rc, dec, dest, _ = _gpu_decode(lib, hip, got, fmt, boost, hip.APPLY_EXACT, device)
+        assert rc == st, tag + (fmt, boost, rc, st)
+        if st == 0:
+            assert (dest.width, dest.height) == (w, h) and np.array_equal(dec, ref), tag + (fmt, boost)
+        else:   # a width or height that is not a multiple of 4 encodes, but its map no longer divides the image (ultrahdr.cpp:388-406)
+            assert st == hip.ERROR_UNSUPPORTED_MAP_SCALE_FACTOR and (w % 4 or h % 4) and fmt != hip.OUTPUT_SDR, tag

@@ -132,28 +132,32 @@ def other_configs(lib, stream):
                                                      api.MEM_DEVICE, stream))
     out["configs[1] single 4K HLG generate"] = {"ms": round(ms, 4), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1),
                                                 "GB/s": round(GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
-    # PQ generate (P010 BT.2100 PQ vs SDR BT.709): 2 f64 pow per HDR channel instead of 1 exp -- 8 frames in one launch
-    nb = 8
+    # PQ generate (P010 BT.2100 PQ vs SDR BT.709): 2 f64 pow per HDR channel instead of 1 exp on the exact path, the f32 pre-filter
+    # in front of it as for HLG -- 32 frames in one launch (8 left the chip half empty), plus the unfiltered kernel beside it
+    nb = 32
     pq = [synth.lcg_frame(W, H, 4321 + i) for i in range(nb)]
     pmaps = [torch.zeros((W // 4) * (H // 4), dtype=torch.uint8, device="cuda") for _ in range(nb)]
     ya = api.image_array([api.yuv420_image(q[1].data_ptr(), W, H, api.CG_BT709) for q in pq])
     pa = api.image_array([api.p010_image(q[0].data_ptr(), W, H, api.CG_BT2100) for q in pq])
     ma = api.image_array([api.out_image(t.data_ptr()) for t in pmaps])
     ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch(nb, ya, pa, api.TF_PQ, C.byref(md), ma, 0, None, stream), 10)
-    out["4K PQ generate, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
-                                             "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    out["4K PQ generate, 32-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+                                              "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch_ex(nb, ya, pa, api.TF_PQ, C.byref(md), ma, 0, api.GENERATE_UNFILTERED, None, stream), 10)
+    out["4K PQ generate, 32-frame launch, pre-filter off (UHDR_HIP_GENERATE_UNFILTERED)"] = {
+        "ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1), "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
     # opt-in LUT mode (upstream libultrahdr's USE_*_LUT configuration; bit-exact against the reference's LUT functions)
     ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch_ex(nb, ya, pa, api.TF_HLG, C.byref(md), ma, 0, api.GENERATE_LUT, None, stream), 10)
-    out["LUT mode: 4K HLG generate, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+    out["LUT mode: 4K HLG generate, 32-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
                                                         "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
     louts = [torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda") for _ in range(nb)]
     mia = api.image_array([api.mono_image(t.data_ptr(), W // 4, H // 4) for t in pmaps])
     loa = api.image_array([api.out_image(t.data_ptr()) for t in louts])
     ms = timed(lambda: lib.uhdr_hip_apply_gainmap_batch(nb, ya, mia, C.byref(md), api.OUTPUT_HDR_HLG, api.FLT_MAX, loa, api.APPLY_LUT, stream), 10)
-    out["LUT mode: 4K apply -> HLG RGBA1010102, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+    out["LUT mode: 4K apply -> HLG RGBA1010102, 32-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
                                                                     "GB/s": round(nb * APP_BYTES / (ms * 1e-3) / 1e9, 1)}
     ms = timed(lambda: lib.uhdr_hip_apply_gainmap_batch(nb, ya, mia, C.byref(md), api.OUTPUT_HDR_HLG, api.FLT_MAX, loa, api.APPLY_EXACT, stream), 3)
-    out["EXACT mode: 4K apply -> HLG RGBA1010102, 8-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+    out["EXACT mode: 4K apply -> HLG RGBA1010102, 32-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
                                                                       "GB/s": round(nb * APP_BYTES / (ms * 1e-3) / 1e9, 1)}
     del louts
     # the drop-in form a CPU caller uses: host planes in, host bytes out (PCIe Gen5 both ways; never `value`)

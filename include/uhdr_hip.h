@@ -379,7 +379,7 @@ int uhdr_hip_gain_lut(const uhdr_hip_metadata_t* metadata, int with_display_boos
  *   fn 0/1/2  sRGB / HLG / PQ inverse OETF as generate computes them (lean f64 + rounding test + exact fallback)
  *   fn 3      encodeGain byte (as float) of gain in[i] for (min_boost, max_boost), generate's version
  *   fn 10..13 the same four through the exact (ocml f64) path;  14/15 HLG / PQ OETF exact
- *   fn 20/24/25 apply-FAST sRGB EOTF / HLG OETF / PQ OETF
+ *   fn 20/24/25 apply-FAST sRGB EOTF / HLG OETF / PQ OETF;  21/22 the f32 HLG / PQ inverse OETF of generate's pre-filter; 23 v_log_f32
  *   fn 40/41/42/44/45 srgbInvOetfLUT / hlgInvOetfLUT / pqInvOetfLUT / hlgOetfLUT / pqOetfLUT; 46 GainLUT(min, max,
  *              displayBoost = max).getGainFactor(in[i])
  *   fn 30/31   gain-map byte -> float through the constant division / the IEEE division (in[i] = byte as float)

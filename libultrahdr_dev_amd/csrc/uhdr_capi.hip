@@ -243,11 +243,15 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   // f32 pre-filter (gen_pair; error budget in DESIGN.md section 5): the fast gain is within kRel of the exact one
   // (3.3e-6 by analysis on top of the exhaustively measured transfer-function errors), v_log_f32 within kLogAbs of
   // log2 on [0.25, 64]; the float evaluation of the code value adds < 2.5e-5.  x1.25 on top.
-  const double kRel = 4.0e-6, kLogAbs = 5.0e-7;
+  // PQ: the f32 inverse OETF (pq_inv_oetf_fast) is within 3.4e-6 instead of 3.4e-7 (the outer power multiplies every error by 6.28):
+  // HDR luminance <= 1.82 x 3.4e-6 + 1.5e-6, ratio <= 9e-6.  Its code scale is smaller (log2 range 5.6 instead of 2.3), so the
+  // distance in code units comes out the same.
+  const double kRel = hdr_tf == UHDR_HIP_TF_PQ ? 1.0e-5 : 4.0e-6, kLogAbs = 5.0e-7;
   c.flt_scale = (float)c.enc_scale;
   c.flt_delta = (float)(1.25 * (c.enc_scale * (kRel * 1.4426950408889634 + kLogAbs) + 4.0e-5));
   c.flt_lo = (float)((double)c.min_boost * (1.0 - 2.0 * kRel));
   c.flt_hi = (float)((double)c.max_boost * (1.0 + 2.0 * kRel));
+  c.flt_gain_rel = (float)(2.0 * kRel);
   return c;
 }
 

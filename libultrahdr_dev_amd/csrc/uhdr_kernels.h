@@ -36,6 +36,7 @@ struct GenConsts {
   // f32 pre-filter of the exact path (see gen_pair): code-value scale, half-width of the "too close to an integer"
   // band, and the gains below / above which the clamp certainly applies
   float flt_scale, flt_delta, flt_lo, flt_hi;
+  float flt_gain_rel;   // 2 x kRel: how far (relatively) a filter estimate of the gain may sit from the exact one
 };
 struct EvalConsts {
   float min_boost, max_boost, log2_min, log2_max;

@@ -183,7 +183,7 @@ __device__ __forceinline__ float cvt_word1(uint32_t w) {
 // truncated code value can only differ when it lies within flt_delta of an integer; only waves holding such a
 // pixel (or one whose clamp decision is in doubt) pay for the exact path.  Bytes are identical either way.
 // Returns a 2-bit mask: bit k set <=> gain[k] is the exact (reference) unclamped gain; a clear bit means gain[k] is the
-// filter's estimate, within kGainRelErr of it.
+// filter's estimate, within GenConsts::flt_gain_rel of it.
 template <int TF, bool LUT, bool FILTER>
 __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t (&hy)[2][4][2],
                                              const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
@@ -261,7 +261,7 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
     return 3u;
   }
 #endif
-  if (FILTER && !LUT && TF != 2) {
+  if (FILTER && !LUT) {
     const f2 fr = (f2){srgb_inv_oetf_fast(r.x), srgb_inv_oetf_fast(r.y)};
     const f2 fg = (f2){srgb_inv_oetf_fast(g.x), srgb_inv_oetf_fast(g.y)};
     const f2 fb = (f2){srgb_inv_oetf_fast(b.x), srgb_inv_oetf_fast(b.y)};
@@ -271,6 +271,10 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
       qr = (f2){hlg_inv_oetf_fast(hr.x), hlg_inv_oetf_fast(hr.y)};
       qg = (f2){hlg_inv_oetf_fast(hg.x), hlg_inv_oetf_fast(hg.y)};
       qb = (f2){hlg_inv_oetf_fast(hb.x), hlg_inv_oetf_fast(hb.y)};
+    } else if (TF == 2) {
+      qr = (f2){pq_inv_oetf_fast(hr.x), pq_inv_oetf_fast(hr.y)};
+      qg = (f2){pq_inv_oetf_fast(hg.x), pq_inv_oetf_fast(hg.y)};
+      qb = (f2){pq_inv_oetf_fast(hb.x), pq_inv_oetf_fast(hb.y)};
     }
     if (!c.gm_identity) {
       const f2 t0 = splat(c.gm[0]) * qr + splat(c.gm[1]) * qg + splat(c.gm[2]) * qb;
@@ -512,8 +516,7 @@ __device__ __forceinline__ void exact_pair_gains(const GenConsts& c, const GenIm
   gen_pair<TF, LUT, false>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);
 }
 
-// relative distance within which a filter estimate may sit from the exact gain (kRel of generate_consts, doubled)
-constexpr float kGainRelErr = 8.0e-6f;
+// (the relative distance within which a filter estimate may sit from the exact gain is GenConsts::flt_gain_rel: generate_consts' kRel, doubled)
 
 // Thread = 2 horizontally adjacent map pixels = an 8x4 pixel block of both images.
 // A wave64 therefore consumes 1 KiB contiguous per P010 row (dwordx4/lane), 512 B per 8-bit luma
@@ -605,7 +608,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
     wave_minmax(wmin, wmax);
     const float pub_min = fminf(k1 != 0u ? key_to_float(~k0) : __builtin_inff(), wmin);   // exact values only
     const float pub_max = fmaxf(k1 != 0u ? key_to_float(k1) : -__builtin_inff(), wmax);
-    const float e = kGainRelErr;
+    const float e = c.flt_gain_rel;
     const float min_hi = fminf(amin + e * __builtin_fabsf(amin), pub_min);   // an exact minimum cannot lie above this
     const float max_lo = fmaxf(amax - e * __builtin_fabsf(amax), pub_max);
     uint32_t cand = 0u;                      // one bit per tile of this lane
@@ -665,7 +668,7 @@ template <int TF>
 static hipError_t launch_generate_tf(const GenConsts& c, const GenBatch& b, int n, bool aligned, bool lut, bool filter,
                                      hipStream_t s) {
   if (lut) return aligned ? launch_generate_t<TF, true, true, false>(c, b, n, s) : launch_generate_t<TF, false, true, false>(c, b, n, s);
-  if (filter && TF != 2 && aligned) return launch_generate_t<TF, true, false, true>(c, b, n, s);
+  if (filter && aligned) return launch_generate_t<TF, true, false, true>(c, b, n, s);
   return aligned ? launch_generate_t<TF, true, false, false>(c, b, n, s) : launch_generate_t<TF, false, false, false>(c, b, n, s);
 }
 hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, bool lut,
@@ -1479,6 +1482,7 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 25: y = pq_oetf_fast(x); break;
     case 20: y = srgb_inv_oetf_fast(x); break;
     case 21: y = hlg_inv_oetf_fast(x); break;
+    case 22: y = pq_inv_oetf_fast(x); break;
     case 23: y = __builtin_amdgcn_logf(x); break;
     // the reference's LUT accessors over the device tables; 46: GainLUT(min, max, displayBoost = max).getGainFactor
     case 40: y = ec.lut[kLutSrgbInv + lut_index(x, kLutSrgbInvN)]; break;

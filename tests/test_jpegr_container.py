@@ -834,3 +834,48 @@ def test_gpu_codec_random_sweep(hip, orc):
             assert (dest.width, dest.height) == (w, h) and np.array_equal(dec, ref), tag + (fmt, boost)
         else:   # a width or height that is not a multiple of 4 encodes, but its map no longer divides the image (ultrahdr.cpp:388-406)
             assert st == hip.ERROR_UNSUPPORTED_MAP_SCALE_FACTOR and (w % 4 or h % 4) and fmt != hip.OUTPUT_SDR, tag
+
+
+@pytest.mark.gpu
+def test_gpu_entry_points_are_safe_to_call_from_several_threads(hip, orc):
+    """four host threads encode, decode and run generate / apply on their own images at once (ctypes releases the GIL): the shared
+    staging buffers and workspaces are serialised inside the library, every result must still be the single-threaded one"""
+    import threading
+    from oracle import jpegr_oracle as J
+    from tests.test_gpu_parity import smooth_frame
+    lib = hip.load()
+    jobs = []
+    for t, ((w, h), sg, tf, q) in enumerate((((640, 480), 0, 1, 95), ((200, 120), 1, 2, 80), ((320, 240), 2, 0, 90), ((1280, 720), 0, 1, 85))):
+        p010, yuv = smooth_frame(w, h, 50 + t)
+        want = J.encode_api1(p010, yuv, w, h, sg, hip.CG_BT2100, tf, q)
+        st, ref, _, _, _, _ = J.decode(want, orc.OUT_HDR_HLG, FLT_MAX)
+        assert st == 0
+        jobs.append((w, h, sg, tf, q, p010, yuv, want, ref))
+    errors = []
+
+    def worker(k):
+        try:
+            w, h, sg, tf, q, p010, yuv, want, ref = jobs[k]
+            out, n = np.zeros(w * h * 3 + 65536, np.uint8), C.c_size_t()
+            pi, yi = hip.p010_image(p010.ctypes.data, w, h, hip.CG_BT2100), hip.yuv420_image(yuv.ctypes.data, w, h, sg)
+            wb = np.frombuffer(want, np.uint8)
+            rend = np.zeros(w * h * 4, np.uint8)
+            for it in range(12):
+                rc = lib.uhdr_hip_jpegr_encode_api1(C.byref(pi), C.byref(yi), tf, q, None, 0, C.c_void_p(out.ctypes.data), out.size, C.byref(n), hip.MEM_HOST, None)
+                if rc != 0 or out[:n.value].tobytes() != want:
+                    errors.append((k, it, "encode", rc))
+                    return
+                dest, md = hip.Image(), hip.Metadata()
+                rc = lib.uhdr_hip_jpegr_decode(C.c_void_p(wb.ctypes.data), wb.size, hip.OUTPUT_HDR_HLG, FLT_MAX, C.c_void_p(rend.ctypes.data), rend.size, C.byref(dest),
+                                               C.byref(md), hip.APPLY_EXACT, hip.MEM_HOST, None)
+                if rc != 0 or not np.array_equal(rend, ref):
+                    errors.append((k, it, "decode", rc))
+                    return
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors and not any(t.is_alive() for t in threads), errors

@@ -651,7 +651,7 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
   planes[0] = mk(dout, w, h);
   if (!info.gray) { planes[1] = mk(dout + luma, w / 2, h / 2); planes[2] = mk(dout + luma + chroma, w / 2, h / 2); }
   hipError_t herr = hipSuccess;
-  if ((rc = stage_reserve(st, 11, jpeg::dec_batch_scratch_bytes(1))) != 0) return rc;
+  if ((rc = stage_reserve(st, 11, jpeg::dec_batch_scratch_bytes(1, &l))) != 0) return rc;
   const jpeg::DecInfo* infos[1] = {&info};
   uint8_t* wss[1] = {ws};
   jpeg::DecPlane (*pl[1])[3] = {&planes};
@@ -845,7 +845,7 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   hipError_t herr = hipSuccess;
   // one launch per decoder step for all images of the call (jpeg::decode_device_batch): the files' latency-bound synchronisation
   // rounds run side by side and a batch costs the launches of one image plus its per-image prefix sums
-  if ((rc = pool_reserve(st, 5 * (size_t)n, jpeg::dec_batch_scratch_bytes(nimg))) != 0) return rc;
+  if ((rc = pool_reserve(st, 5 * (size_t)n, jpeg::dec_batch_scratch_bytes(nimg, layouts.data()))) != 0) return rc;
   for (int g = 0; g < nimg; ++g)
     HIP_TRY(hipMemcpyAsync(wss[g] + layouts[g].src, srcs[g], infos[g]->scan_bytes, hipMemcpyHostToDevice, s));
   const int drc = jpeg::decode_device_batch(nimg, infos.data(), layouts.data(), wss.data(), pl.data(), s, static_cast<uint8_t*>(st->pool[5 * (size_t)n]), &herr,

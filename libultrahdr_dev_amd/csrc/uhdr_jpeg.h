@@ -97,8 +97,8 @@ struct DecJob {
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info);
 size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l);
 // n images on one stream with one launch per decoder step for all of them (blockIdx.y = image); batch_ws: device scratch of
-// dec_batch_scratch_bytes(n)
-size_t dec_batch_scratch_bytes(int n);
+// dec_batch_scratch_bytes(n, layouts)
+size_t dec_batch_scratch_bytes(int n, const DecLayout l[]);
 int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3], hipStream_t s,
                         uint8_t* batch_ws, hipError_t* herr, int* image_rc);
 

@@ -351,6 +351,18 @@ struct BlkKey {   // restart interval a block belongs to: the DC predictors star
   uint32_t per;
   __host__ __device__ uint32_t operator()(uint32_t b) const { return b / per; }
 };
+// ---- prefix sums over the concatenated per-image arrays of a batch: one segmented scan instead of one scan per image ----------
+struct DecBatchJob;
+struct SegOf {   // which image element g of a concatenation belongs to; off: n + 1 ascending element offsets (device memory)
+  const uint32_t* off;
+  int n;
+  __host__ __device__ uint32_t operator()(uint32_t g) const {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= g) lo = mid; else hi = mid; }
+    return (uint32_t)lo;
+  }
+};
+
 __device__ __forceinline__ void dc_apply_body(const DecJob& j, const int* sum0, const int* sum1, const int* sum2) {
   const uint32_t b = blockIdx.x * 256u + threadIdx.x;
   if (b >= j.nblk) return;
@@ -449,6 +461,40 @@ struct DecBatchJob {
   const uint32_t* first_block; const int* dc[3];
   uint8_t* zero[3]; uint32_t zero_words[3];            // ranges k_jd_zero_multi clears (16-byte multiples)
 };
+struct SubKeyBatch {   // (image, restart interval) of subsequence g of the concatenated nblocks arrays
+  const DecBatchJob* jobs;
+  SegOf seg;
+  __host__ __device__ uint64_t operator()(uint32_t g) const {
+    const uint32_t img = seg(g);
+    const uint32_t* sk = jobs[img].j.sub_key;
+    return ((uint64_t)img << 32) | (sk ? sk[g - seg.off[img]] : 0u);
+  }
+};
+struct BlkKeyBatch {   // (image, restart interval) of block g of the concatenated DC arrays
+  const DecBatchJob* jobs;
+  SegOf seg;
+  __host__ __device__ uint64_t operator()(uint32_t g) const {
+    const uint32_t img = seg(g), rb = jobs[img].j.restart_blocks;
+    return ((uint64_t)img << 32) | (rb ? (g - seg.off[img]) / rb : 0u);
+  }
+};
+struct DcPickBatch {   // DcPick through the concatenation
+  const DecBatchJob* jobs;
+  SegOf seg;
+  int comp;
+  __host__ __device__ int operator()(uint32_t g) const {
+    const uint32_t img = seg(g), b = g - seg.off[img];
+    const DecJob& j = jobs[img].j;
+    const int c = j.gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
+    return c == comp ? (int)j.coef[(size_t)b * 64u] : 0;
+  }
+};
+typedef hipcub::CountingInputIterator<uint32_t> CountIt;
+typedef hipcub::TransformInputIterator<uint32_t, SegOf, CountIt> SegKeyIt;
+typedef hipcub::TransformInputIterator<uint64_t, SubKeyBatch, CountIt> SubKeyIt;
+typedef hipcub::TransformInputIterator<uint64_t, BlkKeyBatch, CountIt> BlkKeyIt;
+typedef hipcub::TransformInputIterator<int, DcPickBatch, CountIt> DcPickIt;
+
 __global__ void __launch_bounds__(256) k_jd_zero_multi(const DecBatchJob* jobs) {
   const DecBatchJob& b = jobs[blockIdx.y];
 #pragma unroll
@@ -460,6 +506,7 @@ __global__ void __launch_bounds__(256) k_jd_zero_multi(const DecBatchJob* jobs) 
 }
 __global__ void __launch_bounds__(256) k_jd_unstuff_count_multi(const DecBatchJob* jobs) {
   const DecBatchJob& b = jobs[blockIdx.y];
+  if (b.src_bytes == 0u) return;   // an image that failed on the host: it owns no slice of the batch arrays
   if (blockIdx.x == 0u && threadIdx.x == 0u) b.kept[(b.src_bytes + kUnstuffChunk - 1u) / kUnstuffChunk] = 0u;   // the scan's last input
   unstuff_count_body(b.src, b.src_bytes, b.kept, b.rst);
 }
@@ -539,7 +586,39 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
 // rounds run side by side by construction.  Synchronises (the number of rounds is data dependent).  The entropy-coded segment of
 // image k must already sit at ws[k] + l[k].src; batch_ws: device scratch of at least dec_batch_scratch_bytes(n).
 // image_rc[k] (optional) receives 0 or -1 (corrupt stream) per image; returns 0, -1 (some image corrupt) or 1 (HIP error in *herr).
-size_t dec_batch_scratch_bytes(int n) { return (size_t)n * (sizeof(DecBatchJob) + 256 + 64) + 1024; }
+// where the batch-level arrays sit inside the scratch buffer
+struct BatchLayout {
+  size_t jobs, flags, changed, offs, kept, kept_off, nblocks, first_block, dc[3], tmp, tmp_bytes, total;
+  uint32_t n_kept, n_sub, n_blk;
+};
+static BatchLayout batch_layout(int n, const DecLayout l[]) {
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  BatchLayout B;
+  B.n_kept = B.n_sub = B.n_blk = 0;
+  for (int k = 0; k < n; ++k) { B.n_kept += l[k].nchunks + 1u; B.n_sub += l[k].nsub_max + 1u; B.n_blk += l[k].nblk; }
+  size_t o = 0;
+  B.jobs = o; o += up((size_t)n * sizeof(DecBatchJob));
+  B.flags = o; o += (size_t)n * 256;
+  B.changed = o; o += up((size_t)n * 4);
+  B.offs = o; o += up((size_t)3 * (n + 1) * 4);
+  B.kept = o; o += up((size_t)B.n_kept * 4);
+  B.kept_off = o; o += up((size_t)B.n_kept * 4);
+  B.nblocks = o; o += up((size_t)B.n_sub * 4);
+  B.first_block = o; o += up((size_t)B.n_sub * 4);
+  for (int c = 0; c < 3; ++c) { B.dc[c] = o; o += up((size_t)B.n_blk * 4 + 4); }
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  const SegOf seg{nullptr, n};
+  CountIt cnt(0u);
+  (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t1, SegKeyIt(cnt, seg), (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)B.n_kept);
+  (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t2, SubKeyIt(cnt, SubKeyBatch{nullptr, seg}), (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)B.n_sub);
+  (void)hipcub::DeviceScan::InclusiveSumByKey(nullptr, t3, BlkKeyIt(cnt, BlkKeyBatch{nullptr, seg}), DcPickIt(cnt, DcPickBatch{nullptr, seg, 0}), (int*)nullptr,
+                                              (int)(B.n_blk ? B.n_blk : 1u));
+  B.tmp_bytes = up(std::max(t1, std::max(t2, t3)) + 256);
+  B.tmp = o; o += B.tmp_bytes;
+  B.total = o;
+  return B;
+}
+size_t dec_batch_scratch_bytes(int n, const DecLayout l[]) { return batch_layout(n, l).total; }
 
 int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[], uint8_t* const ws[], DecPlane (*planes[])[3], hipStream_t s,
                         uint8_t* batch_ws, hipError_t* herr, int* image_rc) {
@@ -548,9 +627,13 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   std::vector<DecBatchJob> jobs((size_t)n);
   std::vector<int> bad((size_t)n, 0);
   std::vector<std::vector<uint32_t>> keep;   // restart-interval tables: alive until the uploads have happened
-  DecBatchJob* djobs = reinterpret_cast<DecBatchJob*>(batch_ws);
-  uint32_t* dflags = reinterpret_cast<uint32_t*>(batch_ws + (((size_t)n * sizeof(DecBatchJob) + 255) / 256) * 256);   // 64 words per image
-  uint32_t* dchanged = dflags + 64u * (uint32_t)n;
+  const BatchLayout B = batch_layout(n, l);
+  DecBatchJob* djobs = reinterpret_cast<DecBatchJob*>(batch_ws + B.jobs);
+  uint32_t* dflags = reinterpret_cast<uint32_t*>(batch_ws + B.flags);   // 64 words per image
+  uint32_t* dchanged = reinterpret_cast<uint32_t*>(batch_ws + B.changed);
+  uint32_t* doffs = reinterpret_cast<uint32_t*>(batch_ws + B.offs);      // three offset tables of n + 1 entries: kept, subsequences, blocks
+  std::vector<uint32_t> offs((size_t)3 * (n + 1), 0u);
+  uint32_t* koff = offs.data(); uint32_t* soff = koff + (n + 1); uint32_t* boff = soff + (n + 1);
   uint32_t gu = 1, gsync = 1, gblk = 1, gidct = 1;
   for (int k = 0; k < n; ++k) {
     DecBatchJob& b = jobs[k];
@@ -559,14 +642,16 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     const DecLayout& L = l[k];
     uint8_t* w = ws[k];
     b.src = w + L.src; b.src_bytes = (uint32_t)in.scan_bytes; b.rst = in.restart_interval != 0 ? 1 : 0;
-    b.kept = reinterpret_cast<uint32_t*>(w + L.kept); b.kept_off = reinterpret_cast<const uint32_t*>(w + L.kept_off); b.raw_out = w + L.raw;
+    // the arrays the prefix sums run over are slices of batch-level concatenations (one segmented scan for all images)
+    b.kept = reinterpret_cast<uint32_t*>(batch_ws + B.kept) + koff[k]; b.kept_off = reinterpret_cast<const uint32_t*>(batch_ws + B.kept_off) + koff[k];
+    b.raw_out = w + L.raw;
     b.tables = in.tables; b.lut_out = reinterpret_cast<uint16_t*>(w + L.lut); b.adv_out = reinterpret_cast<uint16_t*>(w + L.adv);
     b.st[0] = reinterpret_cast<DState*>(w + L.st_a); b.st[1] = reinterpret_cast<DState*>(w + L.st_b);
     b.dirty[0] = w + L.dirty_a; b.dirty[1] = w + L.dirty_b;
-    b.nblocks = reinterpret_cast<uint32_t*>(w + L.nblocks);
+    b.nblocks = reinterpret_cast<uint32_t*>(batch_ws + B.nblocks) + soff[k];
     b.flags = dflags + 64u * (uint32_t)k;
-    b.first_block = reinterpret_cast<const uint32_t*>(w + L.first_block);
-    for (int c = 0; c < 3; ++c) b.dc[c] = reinterpret_cast<const int*>(w + L.dc[c]);
+    b.first_block = reinterpret_cast<const uint32_t*>(batch_ws + B.first_block) + soff[k];
+    for (int c = 0; c < 3; ++c) b.dc[c] = reinterpret_cast<const int*>(batch_ws + B.dc[c]) + boff[k];
     DecJob& j = b.j;
     j.raw = reinterpret_cast<const uint32_t*>(w + L.raw);
     j.lut = b.lut_out; j.adv = b.adv_out;
@@ -602,22 +687,29 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     b.zero[0] = reinterpret_cast<uint8_t*>(b.flags); b.zero_words[0] = 16u;
     b.zero[1] = w + L.raw; b.zero_words[1] = bad[k] ? 0u : (uint32_t)((((size_t)in.scan_bytes + 64 + 255) / 256 * 256) / 16);
     b.zero[2] = reinterpret_cast<uint8_t*>(j.coef); b.zero_words[2] = (uint32_t)(((size_t)j.nblk * 128) / 16);
+    koff[k + 1] = koff[k] + (bad[k] ? 0u : L.nchunks + 1u);
+    soff[k + 1] = soff[k] + j.nsub;
+    boff[k + 1] = boff[k] + j.nblk;
     gu = std::max(gu, (L.nchunks + 255u) / 256u);
     gsync = std::max(gsync, (j.nsub + 255u) / 256u);
     gblk = std::max(gblk, (j.nblk + 255u) / 256u);
     gidct = std::max(gidct, (j.nblk + 127u) / 128u);
   }
   JD_TRY(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(DecBatchJob), hipMemcpyHostToDevice, s));
-  JD_TRY(hipStreamSynchronize(s));   // jobs / restart tables are in pageable host memory
+  JD_TRY(hipMemcpyAsync(doffs, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, s));
+  JD_TRY(hipStreamSynchronize(s));   // jobs / offsets / restart tables are in pageable host memory
+  const SegOf kseg{doffs, n}, sseg{doffs + (n + 1), n}, bseg{doffs + 2 * (n + 1), n};
+  const CountIt cnt0(0u);
+  uint8_t* stmp = batch_ws + B.tmp;
   keep.clear();
   const dim3 b256(256);
   const unsigned ny = (unsigned)n;
   hipLaunchKernelGGL(k_jd_zero_multi, dim3(512, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_unstuff_count_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
-  for (int k = 0; k < n; ++k) {
-    if (bad[k]) continue;
-    size_t tmp = l[k].scan_tmp_bytes;
-    JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws[k] + l[k].scan_tmp, tmp, jobs[k].kept, const_cast<uint32_t*>(jobs[k].kept_off), (int)(l[k].nchunks + 1u), s));
+  if (koff[n]) {
+    size_t tmp = B.tmp_bytes;
+    JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(stmp, tmp, SegKeyIt(cnt0, kseg), reinterpret_cast<const uint32_t*>(batch_ws + B.kept),
+                                                 reinterpret_cast<uint32_t*>(batch_ws + B.kept_off), (int)koff[n], hipcub::Equality(), s));
   }
   hipLaunchKernelGGL(k_jd_unstuff_copy_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_build_lut_multi, dim3(4u * 65536u / 256u, ny), b256, 0, s, (const DecBatchJob*)djobs);
@@ -640,29 +732,18 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     for (int k = 0; k < n; ++k) any = any || changed[k] != 0u;
     if (!any) break;
   }
-  for (int k = 0; k < n; ++k) {
-    if (bad[k]) continue;
-    size_t tmp = l[k].scan_tmp_bytes;
-    uint32_t* first_block = const_cast<uint32_t*>(jobs[k].first_block);
-    if (jobs[k].rst) JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(ws[k] + l[k].scan_tmp, tmp, jobs[k].j.sub_key, jobs[k].nblocks, first_block, (int)jobs[k].j.nsub, hipcub::Equality(), s));
-    else JD_TRY(hipcub::DeviceScan::ExclusiveSum(ws[k] + l[k].scan_tmp, tmp, jobs[k].nblocks, first_block, (int)jobs[k].j.nsub, s));
+  if (soff[n]) {   // blocks completed before each subsequence, counted from the start of its image (of its restart interval)
+    size_t tmp = B.tmp_bytes;
+    JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(stmp, tmp, SubKeyIt(cnt0, SubKeyBatch{djobs, sseg}), reinterpret_cast<const uint32_t*>(batch_ws + B.nblocks),
+                                                 reinterpret_cast<uint32_t*>(batch_ws + B.first_block), (int)soff[n], hipcub::Equality(), s));
   }
   hipLaunchKernelGGL(k_jd_write_multi, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs);
-  for (int k = 0; k < n; ++k) {
-    if (bad[k]) continue;
-    const DecJob& j = jobs[k].j;
-    for (int c = 0; c < (j.gray ? 1 : 3); ++c) {
-      hipcub::CountingInputIterator<uint32_t> cnt(0u);
-      hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{j.coef, c, j.gray});
-      size_t tmp = l[k].scan_tmp_bytes;
-      int* dc = const_cast<int*>(jobs[k].dc[c]);
-      if (jobs[k].rst) {
-        hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{j.restart_blocks});
-        JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(ws[k] + l[k].scan_tmp, tmp, keys, it, dc, (int)j.nblk, hipcub::Equality(), s));
-      } else {
-        JD_TRY(hipcub::DeviceScan::InclusiveSum(ws[k] + l[k].scan_tmp, tmp, it, dc, (int)j.nblk, s));
-      }
-    }
+  bool colour = false;
+  for (int k = 0; k < n; ++k) colour = colour || (!bad[k] && !jobs[k].j.gray);
+  for (int c = 0; c < (colour ? 3 : 1) && boff[n]; ++c) {   // DC differences -> DC values: per component, image and restart interval
+    size_t tmp = B.tmp_bytes;
+    JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(stmp, tmp, BlkKeyIt(cnt0, BlkKeyBatch{djobs, bseg}), DcPickIt(cnt0, DcPickBatch{djobs, bseg, c}),
+                                                 reinterpret_cast<int*>(batch_ws + B.dc[c]), (int)boff[n], hipcub::Equality(), s));
   }
   hipLaunchKernelGGL(k_jd_dc_apply_multi, dim3(gblk, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_idct_multi, dim3(gidct, ny), dim3(128), 0, s, (const DecBatchJob*)djobs);

@@ -72,7 +72,7 @@ struct DecInfo {
   uint32_t raw_bytes = 0;
 };
 struct DecLayout {
-  size_t src, raw, kept, kept_off, lut, adv, st_a, st_b, dirty_a, dirty_b, nblocks, first_block, coef, dc[3], flags, scan_tmp, scan_tmp_bytes;
+  size_t src, raw, lut, adv, st_a, st_b, dirty_a, dirty_b, coef;
   size_t sub_start, sub_end, sub_key;   // restart-interval files only
   uint32_t nchunks, nsub_max, nblk, mcus_x;
 };

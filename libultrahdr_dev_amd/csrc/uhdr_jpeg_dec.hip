@@ -534,58 +534,27 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   l->nchunks = (uint32_t)((nbytes + kUnstuffChunk - 1) / kUnstuffChunk);
   const uint32_t nint = (uint32_t)info.interval_start.size();   // 0 without restart intervals; each interval may end in a short subsequence
   l->nsub_max = (uint32_t)((nbytes * 8 + kSubBits - 1) / kSubBits) + 1u + nint;
+  // per image: the stuffed and the unstuffed segment, the Huffman tables, the two state / dirty buffers of the rounds, the
+  // coefficients; the arrays the prefix sums run over belong to the batch (batch_layout)
   size_t o = 0;
   l->src = o; o += up(nbytes + 16);
   l->raw = o; o += up(nbytes + 64);
-  l->kept = o; o += up((size_t)(l->nchunks + 1) * 4);
-  l->kept_off = o; o += up((size_t)(l->nchunks + 1) * 4);
   l->lut = o; o += up((size_t)4 * 65536 * 2);
   l->adv = o; o += up((size_t)4 * 65536 * 2);
   l->st_a = o; o += up((size_t)l->nsub_max * sizeof(DState));
   l->st_b = o; o += up((size_t)l->nsub_max * sizeof(DState));
   l->dirty_a = o; o += up((size_t)l->nsub_max + 2);
   l->dirty_b = o; o += up((size_t)l->nsub_max + 2);
-  l->nblocks = o; o += up((size_t)(l->nsub_max + 1) * 4);
-  l->first_block = o; o += up((size_t)(l->nsub_max + 1) * 4);
   l->coef = o; o += up((size_t)l->nblk * 128);
-  l->dc[0] = o; o += up((size_t)l->nblk * 4);
-  l->dc[1] = o; o += up((size_t)l->nblk * 4);
-  l->dc[2] = o; o += up((size_t)l->nblk * 4);
-  l->flags = o; o += 256;   // [0] changed, [1] error, [2] raw byte count
   l->sub_start = l->sub_end = l->sub_key = 0;
   if (nint) {
     l->sub_start = o; o += up((size_t)l->nsub_max * 4);
     l->sub_end = o; o += up((size_t)l->nsub_max * 4);
     l->sub_key = o; o += up((size_t)(l->nsub_max + 1) * 4);
   }
-  size_t t1 = 0, t2 = 0, t3 = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nchunks + 1));
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nsub_max + 1));
-  {
-    hipcub::CountingInputIterator<uint32_t> cnt(0u);
-    hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{nullptr, 0, 0});
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, t3, it, (int*)nullptr, (int)l->nblk);
-  }
-  if (nint) {   // the segmented forms of the last two
-    size_t t4 = 0, t5 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t4, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->nsub_max + 1));
-    hipcub::CountingInputIterator<uint32_t> cnt(0u);
-    hipcub::TransformInputIterator<int, DcPick, hipcub::CountingInputIterator<uint32_t>> it(cnt, DcPick{nullptr, 0, 0});
-    hipcub::TransformInputIterator<uint32_t, BlkKey, hipcub::CountingInputIterator<uint32_t>> keys(cnt, BlkKey{1u});
-    (void)hipcub::DeviceScan::InclusiveSumByKey(nullptr, t5, keys, it, (int*)nullptr, (int)l->nblk);
-    t2 = t2 > t4 ? t2 : t4;
-    t3 = t3 > t5 ? t3 : t5;
-  }
-  l->scan_tmp_bytes = up((t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3)) + 256);
-  l->scan_tmp = o; o += l->scan_tmp_bytes;
   return o;
 }
 
-// Runs the whole decoder for n images on one stream with ONE launch per decoder step for all of them (blockIdx.y = image): a batch of
-// files costs the kernel launches of a single image plus the per-image prefix sums, and the images' latency-bound synchronisation
-// rounds run side by side by construction.  Synchronises (the number of rounds is data dependent).  The entropy-coded segment of
-// image k must already sit at ws[k] + l[k].src; batch_ws: device scratch of at least dec_batch_scratch_bytes(n).
-// image_rc[k] (optional) receives 0 or -1 (corrupt stream) per image; returns 0, -1 (some image corrupt) or 1 (HIP error in *herr).
 // where the batch-level arrays sit inside the scratch buffer
 struct BatchLayout {
   size_t jobs, flags, changed, offs, kept, kept_off, nblocks, first_block, dc[3], tmp, tmp_bytes, total;

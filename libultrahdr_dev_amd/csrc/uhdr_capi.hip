@@ -43,8 +43,8 @@ struct DeviceState {
   std::map<int, float*> idw;  // scale -> device tables (4 * scale*scale*4 floats)
   float* lut = nullptr;       // the five static transfer-function tables (kLutTotal floats), built at init
   // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
-  void* stage[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t stage_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  void* stage[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   // uhdr_hip_jpegr_decode[_batch]: per-file decoder workspaces and planes
   std::vector<void*> pool;
   std::vector<size_t> pool_bytes;
@@ -487,7 +487,7 @@ int uhdr_hip_shutdown(void) {
     for (auto& t : kv.second.idw) (void)hipFree(t.second);
     if (kv.second.lut) (void)hipFree(kv.second.lut);
     for (void* q : kv.second.pool) if (q) (void)hipFree(q);
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 14; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
   }
   g_dev.clear();
@@ -514,6 +514,35 @@ int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float 
   return UHDR_HIP_NO_ERROR;
 }
 
+}  // extern "C"
+
+namespace {
+// block geometry and quantisation tables of one image (jpeg_set_quality(q, TRUE), jpegencoderhelper.cpp:119-136)
+void encode_job_tables(size_t w, size_t h, bool gray, int quality, jpeg::Job* jp) {
+  jpeg::Job& j = *jp;
+  memset(&j, 0, sizeof(j));
+  j.gray = gray ? 1 : 0;
+  j.ybw = (uint32_t)((w + 7) / 8); j.ybh = (uint32_t)((h + 7) / 8);
+  j.mcus_x = (uint32_t)((w + 15) / 16);
+  j.nblk = gray ? j.ybw * j.ybh : j.mcus_x * (uint32_t)((h + 15) / 16) * 6u;
+  uint16_t qn[64];
+  jpeg::quant_table(quality, false, qn); jpeg::zigzag_table(qn, j.q_lum);
+  jpeg::quant_table(quality, true, qn); jpeg::zigzag_table(qn, j.q_chr);
+  for (int i = 0; i < 64; ++i) {
+    j.m_lum[i] = (uint32_t)((1ull << 32) / ((uint32_t)j.q_lum[i] << 3)) + 1u;
+    j.m_chr[i] = (uint32_t)((1ull << 32) / ((uint32_t)j.q_chr[i] << 3)) + 1u;
+  }
+}
+jpeg::Plane encode_plane(const uint8_t* p, size_t pw, size_t ph, size_t stride, bool pad) {
+  jpeg::Plane q;
+  q.p = p; q.w = (int)pw; q.h = (int)ph; q.stride = (int)stride; q.pad_cols = pad ? 1 : 0;
+  q.aligned4 = (reinterpret_cast<uintptr_t>(p) % 4 == 0 && stride % 4 == 0) ? 1 : 0;
+  return q;
+}
+}  // namespace
+
+extern "C" {
+
 // JpegEncoderHelper::compressImage (jpegencoderhelper.cpp:39-52) on the device
 int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void* icc, size_t icc_size, void* out,
                          size_t out_capacity, size_t* out_size, int mem_space, void* stream) {
@@ -534,18 +563,7 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
   const size_t cs = gray ? 0 : image->chroma_stride;
   const size_t aw = (w + 15) / 16 * 16, acw = (w / 2 + 7) / 8 * 8;
   jpeg::Job j;
-  memset(&j, 0, sizeof(j));
-  j.gray = gray ? 1 : 0;
-  j.ybw = (uint32_t)((w + 7) / 8); j.ybh = (uint32_t)((h + 7) / 8);
-  j.mcus_x = (uint32_t)((w + 15) / 16);
-  j.nblk = gray ? j.ybw * j.ybh : j.mcus_x * (uint32_t)((h + 15) / 16) * 6u;
-  uint16_t qn[64];
-  jpeg::quant_table(quality, false, qn); jpeg::zigzag_table(qn, j.q_lum);
-  jpeg::quant_table(quality, true, qn); jpeg::zigzag_table(qn, j.q_chr);
-  for (int i = 0; i < 64; ++i) {
-    j.m_lum[i] = (uint32_t)((1ull << 32) / ((uint32_t)j.q_lum[i] << 3)) + 1u;
-    j.m_chr[i] = (uint32_t)((1ull << 32) / ((uint32_t)j.q_chr[i] << 3)) + 1u;
-  }
+  encode_job_tables(w, h, gray, quality, &j);
 
   const uint8_t* py = static_cast<const uint8_t*>(image->data);
   const uint8_t* pu = static_cast<const uint8_t*>(image->chroma_data);
@@ -565,12 +583,7 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
       pu = du;
     }
   }
-  auto plane = [](const uint8_t* p, size_t pw, size_t ph, size_t stride, bool pad) {
-    jpeg::Plane q;
-    q.p = p; q.w = (int)pw; q.h = (int)ph; q.stride = (int)stride; q.pad_cols = pad ? 1 : 0;
-    q.aligned4 = (reinterpret_cast<uintptr_t>(p) % 4 == 0 && stride % 4 == 0) ? 1 : 0;
-    return q;
-  };
+  auto plane = encode_plane;
   j.plane[0] = plane(py, w, h, dls, ls < aw);
   if (!gray) {
     const size_t v_off = mem_space != UHDR_HIP_MEM_DEVICE ? dcs * (h / 2) : cs * h / 2;   // chromaStride * height / 2 (:140)
@@ -1002,11 +1015,77 @@ int jpeg_to_host(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, const s
   return UHDR_HIP_ERROR_ENCODE_ERROR;
 }
 
+// The same for planes that live on the device, without a round trip: the kernels write the stream straight into the page-locked
+// host buffer (the device reaches it over the bus; that replaces the device-to-host copy) and its size into a page-locked word, so a
+// call can enqueue all its compressions and synchronise ONCE.  The size is valid after the stream has been synchronised; `dst` must
+// not be touched before.  ws_slot: encoder workspace, 12 or 13 (two compressions in flight need two; uhdr_hip_jpeg_encode has its own).
+constexpr size_t kPendingSize = ~(size_t)0;
+struct PendingJpeg {
+  HostBytes* dst = nullptr;
+  uint64_t* total = nullptr;
+  uhdr_hip_image_t img;
+  int q = 0;
+  std::vector<uint8_t> icc;
+  bool has_icc = false;
+};
+uint64_t* pinned_totals() {   // two page-locked size words per host thread
+  static thread_local HostBytes words;
+  if (words.size() < 64) words.resize(64);
+  return reinterpret_cast<uint64_t*>(words.data());
+}
+int jpeg_enqueue_device(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, const std::vector<uint8_t>* icc, HostBytes& dst, int ws_slot,
+                        uint64_t* total, PendingJpeg* pend) {
+  if (dst.data() == nullptr || total == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  const bool gray = img.pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
+  const size_t w = img.width, h = img.height;
+  if (w == 0 || h == 0 || w > 65500 || h > 65500 || (!gray && ((w | h) & 1))) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;
+  const size_t ls = img.luma_stride ? img.luma_stride : w, cs = gray ? 0 : img.chroma_stride;
+  const size_t aw = (w + 15) / 16 * 16, acw = (w / 2 + 7) / 8 * 8;
+  jpeg::Job j;
+  encode_job_tables(w, h, gray, q, &j);
+  const uint8_t* py = static_cast<const uint8_t*>(img.data);
+  const uint8_t* pu = static_cast<const uint8_t*>(img.chroma_data);
+  j.plane[0] = encode_plane(py, w, h, ls, ls < aw);
+  if (!gray) {
+    j.plane[1] = encode_plane(pu, w / 2, h / 2, cs, cs < acw);
+    j.plane[2] = encode_plane(pu + cs * h / 2, w / 2, h / 2, cs, cs < acw);   // chromaStride * height / 2 (jpegencoderhelper.cpp:140)
+  }
+  std::vector<uint8_t> header;
+  jpeg::build_header((int)w, (int)h, gray, q, icc ? icc->data() : nullptr, icc ? icc->size() : 0, header);
+  if (dst.size() < header.size()) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  jpeg::Layout l;
+  const size_t ws_bytes = jpeg::workspace_bytes(j.nblk, &l);
+  int rc;
+  if ((rc = stage_reserve(c.st, ws_slot, ws_bytes)) != 0) return rc;   // slots 12 / 13: only ever touched under g_jpegr_mu, which the caller holds
+  uint8_t* ws = static_cast<uint8_t*>(c.st->stage[ws_slot]);
+  memcpy(dst.data(), header.data(), header.size());   // host memory: no copy to enqueue
+  *total = 0;
+  HIP_TRY(jpeg::encode_async(j, l, ws, dst.data(), dst.size(), header.size(), c.s()));
+  HIP_TRY(hipMemcpyAsync(total, ws + l.totals + 8, 8, hipMemcpyDeviceToHost, c.s()));
+  pend->dst = &dst; pend->total = total; pend->img = img; pend->q = q;
+  pend->has_icc = icc != nullptr;
+  if (icc) pend->icc = *icc;
+  return UHDR_HIP_NO_ERROR;
+}
+// after the stream has been synchronised: the size, or (a stream larger than the buffer: it was cut off) the compression again
+int jpeg_collect(const EncodeCtx& c, PendingJpeg& p, size_t* n) {
+  const uint64_t total = *p.total;
+  if (total != 0 && total <= p.dst->size()) { *n = (size_t)total; return UHDR_HIP_NO_ERROR; }
+  if (total == 0) return UHDR_HIP_ERROR_ENCODE_ERROR;
+  p.dst->resize((size_t)total + 16);
+  return jpeg_to_host(c, p.img, p.q, p.has_icc ? &p.icc : nullptr, *p.dst, n);
+}
+PendingJpeg& pending_gainmap() { static thread_local PendingJpeg p; return p; }
+
 // compressGainMap (jpegr.cpp:806-821): one plane at kMapCompressQuality = 85
 int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, HostBytes& jpeg, size_t* n) {
   uhdr_hip_image_t g = map;
   g.chroma_data = nullptr; g.chroma_stride = 0; g.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
   jpeg.resize(map.width * map.height + 65536);
+  if (!c.host()) {   // enqueued; *n == kPendingSize until resolve_gainmap_jpeg() (or finish_from_planes) has synchronised
+    *n = kPendingSize;
+    return jpeg_enqueue_device(c, g, 85, nullptr, jpeg, 13, pinned_totals(), &pending_gainmap()) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
+  }
   return jpeg_to_host(c, g, 85, nullptr, jpeg, n) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
 }
 
@@ -1029,7 +1108,7 @@ int make_gainmap_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& yuv, const uhd
 // appendGainMap.  `enc` must be private to the call when it is not P3 (it is converted in place).
 int finish_from_planes(const EncodeCtx& c, uhdr_hip_image_t enc, int quality, const void* exif, size_t exif_size,
                        const HostBytes& gm_jpeg, size_t gm_n, const uhdr_hip_metadata_t& md, void* out, size_t out_capacity,
-                       size_t* out_size) {
+                       size_t* out_size) {   // gm_n may be kPendingSize: the gain-map JPEG is still being written (device callers)
   std::vector<uint8_t> icc;
   if (!jpegr::icc_profile_srgb_transfer(enc.colorGamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
   int rc;
@@ -1038,9 +1117,24 @@ int finish_from_planes(const EncodeCtx& c, uhdr_hip_image_t enc, int quality, co
   static thread_local HostBytes sdr_jpeg;
   sdr_jpeg.resize(enc.width * enc.height + 65536);
   size_t sdr_n = 0;
-  if (jpeg_to_host(c, enc, quality, &icc, sdr_jpeg, &sdr_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
+  if (!c.host()) {   // both compressions in flight, one synchronisation for the call
+    PendingJpeg sdr;
+    if (jpeg_enqueue_device(c, enc, quality, &icc, sdr_jpeg, 12, pinned_totals() + 1, &sdr) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
+    HIP_TRY(hipStreamSynchronize(c.s()));
+    if (gm_n == kPendingSize && jpeg_collect(c, pending_gainmap(), &gm_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
+    if (jpeg_collect(c, sdr, &sdr_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
+  } else if (jpeg_to_host(c, enc, quality, &icc, sdr_jpeg, &sdr_n) != UHDR_HIP_NO_ERROR) {
+    return UHDR_HIP_ERROR_ENCODE_ERROR;
+  }
   return jpegr::append_gainmap_to(sdr_jpeg.data(), sdr_n, gm_jpeg.data(), gm_n, static_cast<const uint8_t*>(exif), exif_size, nullptr, 0, md,
                                   static_cast<uint8_t*>(out), out_capacity, out_size);
+}
+
+// for the callers that need the gain-map JPEG at once (API-2 / API-3 / API-x): wait for it
+int resolve_gainmap_jpeg(const EncodeCtx& c, size_t* n) {
+  if (*n != kPendingSize) return UHDR_HIP_NO_ERROR;
+  HIP_TRY(hipStreamSynchronize(c.s()));
+  return jpeg_collect(c, pending_gainmap(), n) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
 }
 
 }  // namespace
@@ -1173,6 +1267,7 @@ int uhdr_hip_jpegr_encode_api2(const uhdr_hip_image_t* p010_in, const uhdr_hip_i
   {
     std::lock_guard<std::mutex> lk(g_jpegr_mu);
     if ((rc = make_gainmap_jpeg(c, yuv, p010, hdr_tf, 0, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;   // :416-434
+    if ((rc = resolve_gainmap_jpeg(c, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;
   }
   return uhdr_hip_jpegr_encode_api4(sdr_jpeg, sdr_jpeg_size, sdr_jpeg_gamut, gm_jpeg.data(), gm_n, &md, out, out_capacity, out_size);
 }
@@ -1219,6 +1314,7 @@ int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_in, const void* sdr_
     }
     if (p010.width != w || p010.height != h) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;                           // :496-499
     if ((rc = make_gainmap_jpeg(c, ydesc, p010, hdr_tf, 1 /* sdr_is_601 */, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;
+    if ((rc = resolve_gainmap_jpeg(c, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;
   }
   return uhdr_hip_jpegr_encode_api4(sdr_jpeg, sdr_jpeg_size, sdr_jpeg_gamut, gm_jpeg.data(), gm_n, &md, out, out_capacity, out_size);
 }
@@ -1241,6 +1337,7 @@ int uhdr_hip_jpegr_encode_apix(const uhdr_hip_image_t* yuv_in, const uhdr_hip_im
   std::vector<uint8_t> icc;
   size_t gm_n = 0;
   if ((rc = gainmap_to_jpeg(c, *gainmap, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;                        // :590-597
+  if ((rc = resolve_gainmap_jpeg(c, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;
   if (!jpegr::icc_profile_srgb_transfer(yuv.colorGamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;           // :599-600
   static thread_local HostBytes sdr_jpeg;
   sdr_jpeg.resize(yuv.width * yuv.height + 65536);

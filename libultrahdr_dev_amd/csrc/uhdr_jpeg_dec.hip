@@ -593,7 +593,18 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
                         uint8_t* batch_ws, hipError_t* herr, int* image_rc) {
 #define JD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *herr = _e; (void)hipStreamSynchronize(s); return 1; } } while (0)
   if (n < 1) return -1;
-  std::vector<DecBatchJob> jobs((size_t)n);
+  // jobs and offset tables are assembled in page-locked memory that lives across calls (per host thread): their upload is then a
+  // real asynchronous copy and needs no synchronisation of its own (every call ends with the stream idle, so reuse is safe)
+  static thread_local void* t_pinned = nullptr;
+  static thread_local size_t t_pinned_cap = 0;
+  const size_t pinned_need = (size_t)n * sizeof(DecBatchJob) + (size_t)3 * (n + 1) * 4 + 64;
+  if (pinned_need > t_pinned_cap) {
+    if (t_pinned) (void)hipHostFree(t_pinned);
+    t_pinned = nullptr; t_pinned_cap = 0;
+    JD_TRY(hipHostMalloc(&t_pinned, pinned_need * 2, hipHostMallocDefault));
+    t_pinned_cap = pinned_need * 2;
+  }
+  DecBatchJob* jobs = static_cast<DecBatchJob*>(t_pinned);
   std::vector<int> bad((size_t)n, 0);
   std::vector<std::vector<uint32_t>> keep;   // restart-interval tables: alive until the uploads have happened
   const BatchLayout B = batch_layout(n, l);
@@ -601,8 +612,10 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   uint32_t* dflags = reinterpret_cast<uint32_t*>(batch_ws + B.flags);   // 64 words per image
   uint32_t* dchanged = reinterpret_cast<uint32_t*>(batch_ws + B.changed);
   uint32_t* doffs = reinterpret_cast<uint32_t*>(batch_ws + B.offs);      // three offset tables of n + 1 entries: kept, subsequences, blocks
-  std::vector<uint32_t> offs((size_t)3 * (n + 1), 0u);
-  uint32_t* koff = offs.data(); uint32_t* soff = koff + (n + 1); uint32_t* boff = soff + (n + 1);
+  uint32_t* offs = reinterpret_cast<uint32_t*>(jobs + n);
+  const size_t noffs = (size_t)3 * (n + 1);
+  uint32_t* koff = offs; uint32_t* soff = koff + (n + 1); uint32_t* boff = soff + (n + 1);
+  koff[0] = soff[0] = boff[0] = 0u;
   uint32_t gu = 1, gsync = 1, gblk = 1, gidct = 1;
   for (int k = 0; k < n; ++k) {
     DecBatchJob& b = jobs[k];
@@ -664,9 +677,9 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     gblk = std::max(gblk, (j.nblk + 255u) / 256u);
     gidct = std::max(gidct, (j.nblk + 127u) / 128u);
   }
-  JD_TRY(hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(DecBatchJob), hipMemcpyHostToDevice, s));
-  JD_TRY(hipMemcpyAsync(doffs, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, s));
-  JD_TRY(hipStreamSynchronize(s));   // jobs / offsets / restart tables are in pageable host memory
+  JD_TRY(hipMemcpyAsync(djobs, jobs, (size_t)n * sizeof(DecBatchJob), hipMemcpyHostToDevice, s));
+  JD_TRY(hipMemcpyAsync(doffs, offs, noffs * 4, hipMemcpyHostToDevice, s));
+  if (!keep.empty()) JD_TRY(hipStreamSynchronize(s));   // restart tables are in pageable host memory
   const SegOf kseg{doffs, n}, sseg{doffs + (n + 1), n}, bseg{doffs + 2 * (n + 1), n};
   const CountIt cnt0(0u);
   uint8_t* stmp = batch_ws + B.tmp;

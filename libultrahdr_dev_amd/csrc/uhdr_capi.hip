@@ -786,7 +786,7 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
       for (int i = lo; i < hi; ++i)
         st_[i] = jpegr[i] == nullptr ? UHDR_HIP_ERROR_BAD_PTR : parse_jpegr_file(jpegr[i], jpegr_size[i], output_format, metadata != nullptr, &files[i]);
     };
-    const int nthreads = std::min(n / 2, 8);
+    const int nthreads = n >= 2 ? std::min(n, 8) : 1;
     if (nthreads <= 1) {
       parse_range(0, n);
     } else {

@@ -411,6 +411,16 @@ __device__ __forceinline__ uint2 pack_f16(float r, float g, float b) {
   return make_uint2(float_to_half(r) | (float_to_half(g) << 16), float_to_half(b) | (0x3C00u << 16));
 }
 
+// FAST apply only: the hardware conversion (v_cvt_f16_f32, round to nearest even, half subnormals kept) instead of the ~20 integer
+// slots per value of the routine above.  The reference rounds half UP (the + 0x1000), so the two differ on exact ties only (one
+// value in 8192) and then by one half-ULP, which is FAST mode's stated tolerance; values here are <= 1, far from the 0x7FFF
+// saturation branch.
+__device__ __forceinline__ uint2 pack_f16_hw(float r, float g, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 rg = {(_Float16)r, (_Float16)g}, ba = {(_Float16)b, (_Float16)1.0f};
+  return make_uint2(__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, ba));
+}
+
 // ---- order-preserving float <-> uint key for atomicMin/atomicMax -------------------------------
 __device__ __forceinline__ uint32_t float_to_key(float f) {
   uint32_t b = __float_as_uint(f);

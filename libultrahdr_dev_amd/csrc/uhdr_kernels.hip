@@ -930,8 +930,8 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
       o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
       st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), o);
     } else if (FMT == 1) {
-      const uint2 a = pack_f16(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16(po[0].r.y, po[0].g.y, po[0].b.y);
-      const uint2 cc = pack_f16(po[1].r.x, po[1].g.x, po[1].b.x), d = pack_f16(po[1].r.y, po[1].g.y, po[1].b.y);
+      const uint2 a = pack_f16_hw(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16_hw(po[0].r.y, po[0].g.y, po[0].b.y);
+      const uint2 cc = pack_f16_hw(po[1].r.x, po[1].g.x, po[1].b.x), d = pack_f16_hw(po[1].r.y, po[1].g.y, po[1].b.y);
       uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
       o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
       o[1] = make_uint4(cc.x, cc.y, d.x, d.y);

@@ -578,3 +578,48 @@ def test_full_size_properties_4k(hip, orc):
     a, b = to_host(outs[0], w * h * 4), to_host(outs[1], w * h * 4)
     assert np.array_equal(a, b)
     assert ((a.view(np.uint32) >> 30) == 3).all()
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3, 4])
+def test_fast_apply_against_exact_apply_on_sixteen_4k_frames(hip, fmt):
+    """BASELINE configs[2]-sized content without the CPU in the loop: FAST (the LDS line-table kernel) against the bit-exact kernel on the
+    device, 16 x 4K LCG frames (133 M pixels) per output format, full and capped display boost (the latter lets channels exceed 1.0 and
+    wrap through the reference's & 0x3ff): within 1 LSB / 1 half-ULP everywhere, alpha equal"""
+    import torch
+    from libultrahdr_dev_amd import synth
+    from tests.gpu_util import stream_ptr
+    lib = hip.load()
+    w, h, n = 3840, 2160, 16
+    bpp = {1: 8, 2: 4, 3: 4, 4: 6}[fmt]
+    frames = [synth.lcg_frame(w, h, 7000 + i) for i in range(n)]
+    maps = [torch.randint(0, 256, ((w // 4) * (h // 4),), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    ya = hip.image_array([hip.yuv420_image(f[1].data_ptr(), w, h, hip.CG_BT709) for f in frames])
+    ma = hip.image_array([hip.mono_image(m.data_ptr(), w // 4, h // 4) for m in maps])
+    fast = [torch.zeros(w * h * bpp, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    exact = [torch.zeros(w * h * bpp, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    fa = hip.image_array([hip.out_image(t.data_ptr()) for t in fast])
+    ea = hip.image_array([hip.out_image(t.data_ptr()) for t in exact])
+    mb = float(np.float32(1000.0) / np.float32(203.0))
+    md = hip.metadata(mb)
+    for boost in (FLT_MAX, 2.0):
+        assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), fmt, boost, fa, hip.APPLY_FAST, stream_ptr()) == 0
+        assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), fmt, boost, ea, hip.APPLY_EXACT, stream_ptr()) == 0
+        torch.cuda.synchronize()
+        worst, ndiff, total = 0, 0, 0
+        for a, b in zip(fast, exact):
+            if fmt in (2, 3):
+                x, y = a.view(torch.int32), b.view(torch.int32)
+                assert bool(((x >> 30) & 3 == (y >> 30) & 3).all())
+                for sh in (0, 10, 20):
+                    d = (((x >> sh) & 0x3ff) - ((y >> sh) & 0x3ff)).abs()
+                    d = torch.minimum(d, 1024 - d)
+                    worst = max(worst, int(d.max())); ndiff += int((d != 0).sum()); total += d.numel()
+            else:
+                x, y = a.view(torch.int16).to(torch.int32), b.view(torch.int16).to(torch.int32)
+                if fmt == 4:
+                    d = torch.minimum((x - y).abs(), 1024 - (x - y).abs())
+                else:
+                    d = (x - y).abs()
+                worst = max(worst, int(d.max())); ndiff += int((d != 0).sum()); total += d.numel()
+        print("fmt %d boost %s: worst %d, differing fraction %.2e" % (fmt, "max" if boost == FLT_MAX else "2.0", worst, ndiff / total))
+        assert worst <= 1, (fmt, boost, worst)

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -623,7 +624,13 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
                          int mem_space, void* stream) {
   if (jpeg == nullptr || desc == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   jpeg::DecInfo info;
+#ifdef UHDR_JD_TIMING
+  const auto T0 = std::chrono::steady_clock::now();
+#endif
   const int prc = jpeg::parse_header(static_cast<const uint8_t*>(jpeg), jpeg_size, &info);
+#ifdef UHDR_JD_TIMING
+  const auto T1 = std::chrono::steady_clock::now();
+#endif
   if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
   if (prc != 0) return UHDR_HIP_UNKNOWN_ERROR;
   const size_t w = (size_t)info.w, h = (size_t)info.h;
@@ -648,6 +655,9 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
   if ((rc = stage_reserve(st, 7, ws_bytes)) != 0) return rc;
   uint8_t* ws = static_cast<uint8_t*>(st->stage[7]);
   HIP_TRY(hipMemcpyAsync(ws + l.src, static_cast<const uint8_t*>(jpeg) + info.scan_offset, info.scan_bytes, hipMemcpyHostToDevice, s));
+#ifdef UHDR_JD_TIMING
+  const auto T2 = std::chrono::steady_clock::now();
+#endif
   uint8_t* dout = static_cast<uint8_t*>(out);
   if (mem_space != UHDR_HIP_MEM_DEVICE) {
     if ((rc = stage_reserve(st, 5, need)) != 0) return rc;
@@ -669,6 +679,13 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
   uint8_t* wss[1] = {ws};
   jpeg::DecPlane (*pl[1])[3] = {&planes};
   const int drc = jpeg::decode_device_batch(1, infos, &l, wss, pl, s, static_cast<uint8_t*>(st->stage[11]), &herr, nullptr);
+#ifdef UHDR_JD_TIMING
+  {
+    const auto T3 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[jd] parse %.0f  lock+reserve+src copy %.0f  device %.0f us\n", us(T0, T1), us(T1, T2), us(T2, T3));
+  }
+#endif
   if (drc > 0) { set_err("uhdr_hip_jpeg_decode", herr); return UHDR_HIP_UNKNOWN_ERROR; }
   if (drc < 0) { snprintf(t_err, sizeof(t_err), "uhdr_hip_jpeg_decode: corrupt entropy-coded data"); return UHDR_HIP_UNKNOWN_ERROR; }
   if (mem_space != UHDR_HIP_MEM_DEVICE) {

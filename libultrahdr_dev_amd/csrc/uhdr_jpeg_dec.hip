@@ -34,6 +34,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -115,21 +117,32 @@ __device__ __forceinline__ void unstuff_copy_body(const uint8_t* src, uint32_t n
   if (threadIdx.x < len - tail0) d0[tail0 + threadIdx.x] = s_buf[tail0 + threadIdx.x];
 }
 
-constexpr uint32_t kFastBitsEarly = 9;   // == kFastBits (first-level table width), needed before its definition
+#ifndef UHDR_JD_FASTBITS
+#define UHDR_JD_FASTBITS 11
+#endif
+constexpr uint32_t kFastBitsEarly = UHDR_JD_FASTBITS;   // == kFastBits (first-level table width), needed before its definition
 // ---- Huffman lookup tables -----------------------------------------------------------------------------------------
-// entry x (the next 16 bits of the stream): (code length << 8) | symbol, 0 when no code matches
-// adv[x]: what the position-only passes need from a symbol, in one 16-bit entry: bit 15 = the code is longer than
-// kFastBits, bits 8..12 = bits consumed (code + value bits, <= 27), bits 0..6 = advance of the coefficient index
-// (DC: 1; AC: run + 1, ZRL 16, EOB 64).  No code: one bit consumed, index unchanged.
+// First-level tables, indexed by the next kFastBits bits of the stream; a workgroup that decodes copies them into LDS.
+// lut[x]: (code length << 8) | symbol, 0 when no code of at most kFastBits bits matches.
+// adv[x]: what the position-only passes need from a symbol, in one 16-bit entry: bits 8..12 = bits consumed (code + value bits,
+// <= 27), bits 0..6 = advance of the coefficient index (DC: 1; AC: run + 1, ZRL 16, EOB 64); 0x8000 when no such code matches.
+// Longer codes (and "no code at all") are resolved from the canonical form of the table, also in LDS (LongCodes): a decoding loop
+// must not load from memory -- a wave waits for all its outstanding vector memory operations at once, coefficient stores included.
+__device__ __forceinline__ uint32_t adv_entry(uint32_t tb, uint32_t len, uint32_t sym) {
+  const uint32_t vb = sym & 15u, r = sym >> 4;
+  const uint32_t dz = (tb & 1u) == 0u ? 1u : (vb != 0u ? r + 1u : (r == 15u ? 16u : 64u));
+  return ((len + vb) << 8) | dz;
+}
 __device__ __forceinline__ void build_lut_body(const DecTables& t, uint16_t* lut, uint16_t* adv) {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;   // 4 tables x 65536
-  const uint32_t tb = g >> 16, x = g & 0xFFFFu;
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;   // 4 tables x 2^kFastBits
+  if (g >= (4u << kFastBitsEarly)) return;
+  const uint32_t tb = g >> kFastBitsEarly, x = g & ((1u << kFastBitsEarly) - 1u);
   const HuffSpec& h = t.huff[tb];
   uint16_t e = 0;
   if (h.present) {
 #pragma unroll 1
-    for (uint32_t l = 1; l <= 16u; ++l) {
-      const uint32_t code = x >> (16u - l);
+    for (uint32_t l = 1; l <= kFastBitsEarly; ++l) {
+      const uint32_t code = x >> (kFastBitsEarly - l);
       if (code >= h.first_code[l] && code - h.first_code[l] < h.count[l]) {
         e = (uint16_t)((l << 8) | h.vals[h.first_val[l] + code - h.first_code[l]]);
         break;
@@ -137,40 +150,69 @@ __device__ __forceinline__ void build_lut_body(const DecTables& t, uint16_t* lut
     }
   }
   lut[g] = e;
-  const uint32_t len = e >> 8, sym = e & 0xFFu, vb = sym & 15u, r = sym >> 4;
-  uint32_t a = (1u << 8);   // no code
-  if (len != 0u) {
-    const uint32_t dz = (tb & 1u) == 0u ? 1u : (vb != 0u ? r + 1u : (r == 15u ? 16u : 64u));
-    a = ((len > kFastBitsEarly ? 1u : 0u) << 15) | ((len + vb) << 8) | dz;
-  }
-  adv[g] = (uint16_t)a;
+  adv[g] = e != 0 ? (uint16_t)adv_entry(tb, e >> 8, e & 0xFFu) : (uint16_t)0x8000u;
 }
 
 // ---- the sequential decoder one thread runs over a stretch of bits ------------------------------------------------------
 struct DState { uint32_t p; uint32_t cz; };   // bit position; (block-in-MCU << 8) | coefficient index
 __device__ __forceinline__ int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }   // T.81 F.2.2.1
 
-// A symbol costs two dependent memory reads (stream bits, then the code table); from L2 that is ~1000 cycles per symbol.
-// So: the bit window lives in registers (64 bits, refilled one word at a time, the word after next already in flight) and
-// the first kFastBits bits of every code are looked up in LDS; only longer codes go to the 16-bit table in global memory.
+// A symbol costs two dependent memory reads (stream bits, then the code table); from L2 that is ~1000 cycles per symbol, and a
+// wave waits for the slowest of its lanes at every symbol (one s_waitcnt covers all outstanding loads).  So nothing in the
+// symbol loop touches global memory but the rare code longer than kFastBits: a workgroup first copies the stretch of the bit
+// string its 256 subsequences cover into LDS (stage_bits), the bit window lives in registers (64 bits, refilled one word at a
+// time from there), and the first kFastBits bits of every code are looked up in LDS.
 constexpr uint32_t kFastBits = kFastBitsEarly;
+// The codes of more than kFastBits bits, in canonical form (T.81 Annex C): a code of length l is the l-bit number in
+// [first_code[l], first_code[l] + count[l]); with lim[l] = that upper bound shifted to 16 bits, the lengths' ranges follow one another,
+// so the length of the code in front of a 16-bit peek is the first l with peek < lim[l].
+constexpr uint32_t kLongLens = 16u - kFastBits;
+struct LongCodes {
+  uint32_t lim[4][kLongLens];   // [table][l - kFastBits - 1]
+  int32_t off[4][kLongLens];    // first_val[l] - first_code[l]
+  uint8_t vals[4][256];
+};
+// workgroup prologue (before a barrier)
+__device__ __forceinline__ void load_long_codes(const DecTables& t, LongCodes& lc) {
+  const uint32_t g = threadIdx.x;
+  if (g < 4u * kLongLens) {
+    const uint32_t tb = g / kLongLens, k = g - tb * kLongLens, l = kFastBits + 1u + k;
+    const HuffSpec& h = t.huff[tb];
+    lc.lim[tb][k] = h.present ? ((uint32_t)h.first_code[l] + (uint32_t)h.count[l]) << (16u - l) : 0u;
+    lc.off[tb][k] = (int32_t)h.first_val[l] - (int32_t)h.first_code[l];
+  }
+  for (uint32_t q = g; q < 4u * 64u; q += blockDim.x)
+    reinterpret_cast<uint32_t*>(&lc.vals[0][0])[q] = reinterpret_cast<const uint32_t*>(t.huff[q >> 6].vals)[q & 63u];
+}
+// (length << 8) | symbol of the code of more than kFastBits bits in front of `peek`, 0 if there is none
+__device__ __forceinline__ uint32_t long_code(const LongCodes& lc, uint32_t tb, uint32_t peek) {
+  uint32_t k = 0;
+  while (k < kLongLens && peek >= lc.lim[tb][k]) ++k;
+  if (k == kLongLens) return 0u;
+  const uint32_t l = kFastBits + 1u + k;
+  const uint32_t at = (uint32_t)(lc.off[tb][k] + (int32_t)(peek >> (16u - l))) & 255u;   // (in range for a table that is a prefix code; never outside vals)
+  return (l << 8) | lc.vals[tb][at];
+}
+constexpr uint32_t kStageWords = 256u * (kSubBits / 32u) + 8u;   // 256 subsequences + the words a decoder reads past its end
 struct Reader {
-  const uint32_t* words;
+  const uint32_t* words;   // LDS copy of words [word0, word0 + kStageWords) of the stream
+  uint32_t word0;
   uint64_t win;     // bits [base, base + 64) of the stream, MSB first
-  uint32_t nextw;   // bits [base + 64, base + 96), still in memory byte order (swapped on use: the load stays in flight)
+  uint32_t nextw;   // bits [base + 64, base + 96), still in memory byte order
   uint32_t base;    // multiple of 32
-  __device__ __forceinline__ void init(const uint32_t* w, uint32_t p) {
-    words = w;
-    const uint32_t i = p >> 5;
-    base = i << 5;
-    win = ((uint64_t)__builtin_bswap32(w[i]) << 32) | (uint64_t)__builtin_bswap32(w[i + 1]);
-    nextw = w[i + 2];
+  __device__ __forceinline__ void init(const uint32_t* staged, uint32_t first_word, uint32_t p) {
+    words = staged;
+    word0 = first_word;
+    const uint32_t i = (p >> 5) - word0;
+    base = (p >> 5) << 5;
+    win = ((uint64_t)__builtin_bswap32(staged[i]) << 32) | (uint64_t)__builtin_bswap32(staged[i + 1]);
+    nextw = staged[i + 2];
   }
   __device__ __forceinline__ void advance_to(uint32_t p) {   // p - base < 64
     if (p - base >= 32u) {
       win = (win << 32) | (uint64_t)__builtin_bswap32(nextw);
       base += 32u;
-      nextw = words[(base >> 5) + 2u];
+      nextw = words[(base >> 5) + 2u - word0];
     }
   }
 };
@@ -178,18 +220,20 @@ struct Reader {
 // One symbol.  MODE 0: advance only; MODE 1: also report the coefficient (position zpos, value val; has = true).
 // A bit pattern that is no code (only possible off-sync, or in a corrupt file) consumes one bit: any deterministic rule
 // will do for the synchronisation, and the final pass flags it.
+// gray: the job's field by value -- read through the job it would be loaded again after every coefficient store (the compiler
+// must assume the store hit it), and the wait for that load would sit out the store.
 template <int MODE>
-__device__ __forceinline__ bool step(const DecJob& j, const uint16_t (*s_lut)[1u << kFastBits], Reader& rd, DState& s,
+__device__ __forceinline__ bool step(const bool gray, const LongCodes& lc, const uint16_t (*s_lut)[1u << kFastBits], Reader& rd, DState& s,
                                      bool& block_done, int& zpos, int& val, bool& has) {
   const uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
-  const uint32_t comp_chroma = j.gray ? 0u : (c >= 4u ? 1u : 0u);
+  const uint32_t comp_chroma = gray ? 0u : (c >= 4u ? 1u : 0u);
   const uint32_t tb = 2u * comp_chroma + (z != 0u ? 1u : 0u);   // slots: 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma (no table in memory: a
                                                                  // lane-indexed kernel-argument array is a ~500-cycle load per symbol)
   const uint32_t sh = s.p - rd.base;
   const uint64_t w = rd.win;
   const uint32_t peek = (uint32_t)(w >> (48u - sh)) & 0xFFFFu;
   uint32_t e = s_lut[tb][peek >> (16u - kFastBits)];
-  if (e == 0u) e = j.lut[(tb << 16) | peek];
+  if (e == 0u) e = long_code(lc, tb, peek);
   const uint32_t len = e >> 8, sym = e & 0xFFu;
   block_done = false;
   has = false;
@@ -220,47 +264,39 @@ __device__ __forceinline__ bool step(const DecJob& j, const uint16_t (*s_lut)[1u
   s.p += len + vbits;
   rd.advance_to(s.p);
   if (nz >= 64u) { block_done = true; nz = 0u; }
-  const uint32_t bpm = j.gray ? 1u : 6u;
+  const uint32_t bpm = gray ? 1u : 6u;
   const uint32_t nc = block_done ? (c + 1u == bpm ? 0u : c + 1u) : c;
   s.cz = (nc << 8) | nz;
   return ok;
 }
 
 // The position-only form of step() for the synchronisation passes: no branches but the rare long-code lookup.
-__device__ __forceinline__ void step_pos(const DecJob& j, const uint16_t (*s_adv)[1u << kFastBits], Reader& rd, DState& s, uint32_t& blocks) {
+__device__ __forceinline__ void step_pos(const bool gray, const LongCodes& lc, const uint16_t (*s_adv)[1u << kFastBits], Reader& rd, DState& s,
+                                         uint32_t& blocks) {
   const uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
-  const uint32_t tb = (j.gray ? 0u : (c >= 4u ? 2u : 0u)) + (z != 0u ? 1u : 0u);
+  const uint32_t tb = (gray ? 0u : (c >= 4u ? 2u : 0u)) + (z != 0u ? 1u : 0u);
   const uint32_t sh = s.p - rd.base;
   const uint32_t peek = (uint32_t)(rd.win >> (48u - sh)) & 0xFFFFu;
   uint32_t a = s_adv[tb][peek >> (16u - kFastBits)];
-  if (a & 0x8000u) a = j.adv[(tb << 16) | peek];
+  if (a & 0x8000u) {
+    const uint32_t e = long_code(lc, tb, peek);
+    a = e != 0u ? adv_entry(tb, e >> 8, e & 0xFFu) : 0x0100u;   // no code: one bit consumed, index unchanged
+  }
   s.p += (a >> 8) & 31u;
   rd.advance_to(s.p);
   uint32_t nz = z + (a & 127u);
   const bool done = nz >= 64u;
   nz = done ? 0u : nz;
-  const uint32_t bpm = j.gray ? 1u : 6u;
+  const uint32_t bpm = gray ? 1u : 6u;
   const uint32_t nc = done ? (c + 1u == bpm ? 0u : c + 1u) : c;
   blocks += done ? 1u : 0u;
   s.cz = (nc << 8) | nz;
 }
-__device__ __forceinline__ void load_fast_adv(const DecJob& j, uint16_t (*s_adv)[1u << kFastBits]) {
-  for (uint32_t g = threadIdx.x; g < 4u << kFastBits; g += blockDim.x) {
-    const uint32_t tb = g >> kFastBits, x = g & ((1u << kFastBits) - 1u);
-    // final only for a code of at most kFastBits bits; "no code" for this particular completion says nothing about the others
-    const uint16_t a = j.adv[(tb << 16) | (x << (16u - kFastBits))];
-    s_adv[tb][x] = (a == (uint16_t)0x0100u) ? (uint16_t)0x8000u : a;
-  }
-  __syncthreads();
-}
-
-// workgroup prologue: the first-level tables (codes of at most kFastBits bits; 0 = look in the full table)
-__device__ __forceinline__ void load_fast_lut(const DecJob& j, uint16_t (*s_lut)[1u << kFastBits]) {
-  for (uint32_t g = threadIdx.x; g < 4u << kFastBits; g += blockDim.x) {
-    const uint32_t tb = g >> kFastBits, x = g & ((1u << kFastBits) - 1u);
-    const uint16_t e = j.lut[(tb << 16) | (x << (16u - kFastBits))];
-    s_lut[tb][x] = (e >> 8) <= kFastBits ? e : (uint16_t)0;
-  }
+// workgroup prologue: one of the two first-level tables -> LDS (16 bytes per lane and turn; ends with a barrier)
+__device__ __forceinline__ void load_fast_table(const uint16_t* table, uint16_t (*s_tab)[1u << kFastBits]) {
+  const uint4* src = reinterpret_cast<const uint4*>(table);
+  uint4* dst = reinterpret_cast<uint4*>(&s_tab[0][0]);
+  for (uint32_t g = threadIdx.x; g < (4u << kFastBits) / 8u; g += blockDim.x) dst[g] = src[g];
   __syncthreads();
 }
 
@@ -275,51 +311,151 @@ __device__ __forceinline__ uint32_t sub_end_bit(const DecJob& j, uint32_t i) {
 __device__ __forceinline__ bool sub_is_first(const DecJob& j, uint32_t i) { return i == 0u || (j.sub_key && j.sub_key[i] != j.sub_key[i - 1u]); }
 __device__ __forceinline__ bool sub_is_last(const DecJob& j, uint32_t i) { return i + 1u == j.nsub || (j.sub_key && j.sub_key[i + 1u] != j.sub_key[i]); }
 
-// ROUND 0: start from the guess (subsequence start, block 0, coefficient 0); ROUND 1: start from the end state of the
-// previous subsequence as of the last round.  Both: decode until the subsequence's end is crossed, record the state.
-// Only subsequences whose start state changed in the previous round are decoded again (dirty_in).
-template <int ROUND>
-__device__ __forceinline__ void sync_body(const DecJob& j, const DState* prev, DState* next, const uint8_t* dirty_in,
-                                          uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {
-  __shared__ uint16_t s_adv[4][1u << kFastBits];
-  load_fast_adv(j, s_adv);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= j.nsub) return;
-  const bool first = sub_is_first(j, i);
-  if (ROUND == 1 && (first || !dirty_in[i])) {
-    next[i] = prev[i];
-    dirty_out[i + 1u] = 0;
-    return;
+// workgroup prologue: words [first word of subsequence i0, last word a decoder of subsequence i1 - 1 can read] of the bit string -> LDS.
+// A decoder starts inside its subsequence (or, in a round, less than one symbol past its start), stops with the first symbol that
+// crosses its end (a symbol is at most 27 bits) and keeps three words in its window: 8 words of slack.  The buffer behind the
+// bit string is zero-filled for 64 bytes (dec_workspace_bytes), so the slack of the last workgroup is there to read.
+__device__ __forceinline__ uint32_t stage_bits(const DecJob& j, uint32_t i0, uint32_t* s_bits) {
+  const uint32_t i1 = i0 + 256u < j.nsub ? i0 + 256u : j.nsub;
+  const uint32_t w0 = sub_begin(j, i0) >> 5;
+  const uint32_t w1 = ((sub_end_bit(j, i1 - 1u) + 27u) >> 5) + 3u;
+  const uint32_t cnt = w1 - w0 + 1u < kStageWords ? w1 - w0 + 1u : kStageWords;
+  if ((w0 & 3u) == 0u) {   // always, unless restart intervals put the subsequences at odd bytes (reads up to 3 words more: inside the slack)
+    const uint4* src = reinterpret_cast<const uint4*>(j.raw + w0);
+    uint4* dst = reinterpret_cast<uint4*>(s_bits);
+    for (uint32_t k = threadIdx.x; k < (cnt + 3u) / 4u; k += 256u) dst[k] = src[k];
+  } else {
+    for (uint32_t k = threadIdx.x; k < cnt; k += 256u) s_bits[k] = j.raw[w0 + k];
   }
-  DState s;
-  if (first || ROUND == 0) { s.p = sub_begin(j, i); s.cz = 0u; }
-  else s = prev[i - 1u];
-  const uint32_t end = sub_end_bit(j, i);
-  Reader rd;
-  rd.init(j.raw, s.p);
-  uint32_t nb = 0;
-  while (s.p < end) step_pos(j, s_adv, rd, s, nb);
-  uint8_t ch = 1;
-  if (ROUND == 1) {
-    const DState old = prev[i];
-    ch = (old.p != s.p || old.cz != s.cz) ? 1 : 0;
-    if (ch) *changed = 1u;
-  }
-  next[i] = s;
-  nblocks[i] = nb;            // blocks completed inside this subsequence, valid once its start state is the true one
-  dirty_out[i + 1u] = ch;     // the next subsequence starts from a new state
+  return w0;
 }
 
-__device__ __forceinline__ void write_body(const DecJob& j, const DState* st, const uint32_t* first_block, uint32_t* error) {
-  __shared__ uint16_t s_lut[4][1u << kFastBits];
-  load_fast_lut(j, s_lut);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+// One position-only decode of subsequence i from state s until its end is crossed; nb: blocks completed on the way.
+// (A corrupt state cannot come out of the rounds -- positions only grow, by at most one symbol past an end -- but a read outside
+// the staged words must be impossible, not unlikely: such a state decodes nothing and keeps its value.)
+__device__ __forceinline__ void decode_positions(const DecJob& j, const LongCodes& lc, const uint16_t (*s_adv)[1u << kFastBits], const uint32_t* s_bits,
+                                                 uint32_t w0, uint32_t i, DState& s, uint32_t& nb) {
+  const uint32_t end = sub_end_bit(j, i);
+  const bool gray = j.gray != 0;
+  nb = 0;
+  if ((s.p >> 5) >= w0 && (s.p >> 5) - w0 + 3u < kStageWords && end > s.p && end - s.p <= kSubBits + 32u) {
+    Reader rd;
+    rd.init(s_bits, w0, s.p);
+    while (s.p < end) step_pos(gray, lc, s_adv, rd, s, nb);
+  }
+}
+
+// The first pass: every subsequence from the guess (its own start, block 0, coefficient 0; the true state for the first one of the
+// scan or of a restart interval).  Records the state each crosses its end with; every start state counts as new (dirty).
+__device__ __forceinline__ void sync_first_body(const DecJob& j, const DecTables& tables, DState* next, uint8_t* dirty_out, uint32_t* nblocks) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_adv[4][1u << kFastBits];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits[kStageWords];
+  __shared__ LongCodes s_long;
+  const uint32_t i0 = blockIdx.x * 256u, i = i0 + threadIdx.x;
+  if (i0 >= j.nsub) return;
+  const uint32_t w0 = stage_bits(j, i0, s_bits);
+  load_long_codes(tables, s_long);
+  load_fast_table(j.adv, s_adv);   // (ends with the barrier that also covers s_bits and s_long)
+  if (i >= j.nsub) return;
+  DState s;
+  s.p = sub_begin(j, i); s.cz = 0u;
+  uint32_t nb;
+  decode_positions(j, s_long, s_adv, s_bits, w0, i, s, nb);
+  next[i] = s;
+  nblocks[i] = nb;            // blocks completed inside this subsequence, valid once its start state is the true one
+  dirty_out[i + 1u] = 1;
+}
+
+// A launch of rounds.  In a round, every subsequence whose start state (the end state of its left neighbour) changed is decoded
+// again from it; when nothing changes any more every start state is the true one.  A round is one lane's walk over 512 bits --
+// latency, ~20 us, whatever the number of subsequences -- so the price of a launch around it (the gap between dependent kernels,
+// the tables and the bits brought into LDS) is worth sharing: a workgroup runs kLocalRounds rounds on its 256 subsequences with
+// the states in LDS.  Only its first lane depends on another workgroup (the end state of the subsequence in front, as of the
+// previous launch), and only its last lane is waited for by one (dirty_out[i + 1]: "changed during this launch").
+// dirty[i]: subsequence i has not been decoded from the current end state of i - 1 yet.
+#ifndef UHDR_JD_LOCAL_ROUNDS
+#define UHDR_JD_LOCAL_ROUNDS 4
+#endif
+constexpr uint32_t kLocalRounds = UHDR_JD_LOCAL_ROUNDS;
+// launches the host enqueues before it looks at the ring: a quality-75 4K file needs 5-8 rounds, a quality-95 one 21-24
+constexpr uint32_t kFirstLaunches = 2u * ((8u + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
+constexpr uint32_t kMoreLaunches = 2u * ((16u + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
+__device__ __forceinline__ void sync_rounds_body(const DecJob& j, const DecTables& tables, const DState* prev, DState* next, const uint8_t* dirty_in,
+                                                 uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_adv[4][1u << kFastBits];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits[kStageWords];
+  __shared__ LongCodes s_long;
+  __shared__ DState s_st[256];
+  __shared__ uint8_t s_dirty[260];
+  const uint32_t t = threadIdx.x, i0 = blockIdx.x * 256u, i = i0 + t;
+  if (i0 >= j.nsub) return;
+  const bool in = i < j.nsub;
+  const bool live = in && !sub_is_first(j, i);          // a first subsequence starts from a state that is known
+  const bool last = in && (t == 255u || i + 1u == j.nsub);
+  DState mine; mine.p = 0u; mine.cz = 0u;
+  if (in) mine = prev[i];
+  const bool d0 = live && dirty_in[i] != 0;
+  // a launch in which none of the workgroup's subsequences starts from a new state: nothing to decode, nothing to load
+  if (!__syncthreads_or(d0 ? 1 : 0)) {
+    if (in) {
+      next[i] = mine;
+      if (t != 0u) dirty_out[i] = 0;
+      if (last) dirty_out[i + 1u] = 0;
+    }
+    return;
+  }
+  const uint32_t w0 = stage_bits(j, i0, s_bits);
+  s_st[t] = mine;
+  s_dirty[t] = d0 ? 1 : 0;
+  DState start0; start0.p = 0u; start0.cz = 0u;
+  if (t == 0u && live) start0 = prev[i - 1u];
+  load_long_codes(tables, s_long);
+  load_fast_table(j.adv, s_adv);   // (ends with the barrier that also covers s_bits, s_long, s_st and s_dirty)
+  uint32_t nb = 0;
+  bool decoded = false, changed_any = false;
+  for (uint32_t r = 0; r < kLocalRounds; ++r) {
+    const bool dd = live && s_dirty[t] != 0;
+    DState s = start0;
+    if (t != 0u) s = s_st[t - 1u];
+    if (!__syncthreads_or(dd ? 1 : 0)) break;           // (the barrier also separates these reads from the writes below)
+    bool ch = false;
+    if (dd) {
+      decode_positions(j, s_long, s_adv, s_bits, w0, i, s, nb);
+      ch = s.p != mine.p || s.cz != mine.cz;
+      mine = s;
+      decoded = true;
+      s_st[t] = s;
+    }
+    changed_any = changed_any || ch;
+    if (t == 0u) s_dirty[0] = 0;                        // its start state cannot change during a launch
+    s_dirty[t + 1u] = ch ? 1 : 0;                       // every entry is rewritten every round ([256]: nobody's)
+    __syncthreads();
+  }
+  if (!in) return;
+  next[i] = mine;
+  if (decoded) nblocks[i] = nb;   // blocks completed inside this subsequence, valid once its start state is the true one
+  if (t != 0u) dirty_out[i] = (live && s_dirty[t] != 0) ? 1 : 0;
+  if (last) dirty_out[i + 1u] = changed_any ? 1 : 0;
+  if (changed_any) *changed = 1u;
+}
+
+__device__ __forceinline__ void write_body(const DecJob& j, const DecTables& tables, const DState* st, const uint32_t* first_block, uint32_t* error) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_lut[4][1u << kFastBits];
+  __shared__ __attribute__((aligned(16))) uint32_t s_bits[kStageWords];
+  const uint32_t i0 = blockIdx.x * 256u, i = i0 + threadIdx.x;
+  if (i0 >= j.nsub) return;
+  __shared__ LongCodes s_long;
+  const uint32_t w0 = stage_bits(j, i0, s_bits);
+  load_long_codes(tables, s_long);
+  load_fast_table(j.lut, s_lut);
   if (i >= j.nsub) return;
   DState s;
   if (sub_is_first(j, i)) { s.p = sub_begin(j, i); s.cz = 0u; } else s = st[i - 1u];
   const uint32_t end = sub_end_bit(j, i);
+  // (as in decode_positions: a start outside the staged words is impossible with states that came out of the rounds; never read there)
+  if ((s.p >> 5) < w0 || (s.p >> 5) - w0 + 3u >= kStageWords || (end > s.p && end - s.p > kSubBits + 32u)) { *error = 1u; return; }
   Reader rd;
-  rd.init(j.raw, s.p);
+  rd.init(s_bits, w0, s.p);
   // first_block: blocks completed before this subsequence, counted from the start of its restart interval (of the scan without them)
   uint32_t blk = first_block[i], blk_end = j.nblk;
   if (j.sub_key) {
@@ -329,13 +465,20 @@ __device__ __forceinline__ void write_body(const DecJob& j, const DState* st, co
   }
   bool bd, has;
   int zp = 0, v = 0;
+  // The pointer comes out of a structure in memory, so the compiler would store through a FLAT instruction -- and those count as
+  // LDS traffic too: the wait in front of the next symbol's table lookup would then sit out the scattered store of this one.
+  // A global store is waited for by nothing in this loop (which is why the loop must not load from memory either).
+  typedef __attribute__((address_space(1))) int16_t GlobalI16;
+  GlobalI16* coef = (GlobalI16*)j.coef;
+  const bool gray = j.gray != 0;
+  bool bad = false;
   while (s.p < end && blk < blk_end) {   // (stops in front of the 1-bits that pad an interval to its byte boundary)
-    const bool ok = step<1>(j, s_lut, rd, s, bd, zp, v, has);
-    if (!ok) *error = 1u;
-    if (has) j.coef[(size_t)blk * 64u + (uint32_t)zp] = (int16_t)v;
+    const bool ok = step<1>(gray, s_long, s_lut, rd, s, bd, zp, v, has);
+    bad = bad || !ok;
+    if (has) coef[(size_t)blk * 64u + (uint32_t)zp] = (int16_t)v;
     blk += bd;
   }
-  if (sub_is_last(j, i) && (blk != blk_end || s.p > end)) *error = 1u;   // an interval (the scan) must end exactly after its last block
+  if (bad || (sub_is_last(j, i) && (blk != blk_end || s.p > end))) *error = 1u;   // an interval (the scan) must end exactly after its last block
 }
 
 // ---- DC prediction: value = running sum of the differences of the same component ---------------------------------------
@@ -512,15 +655,21 @@ __global__ void __launch_bounds__(256) k_jd_unstuff_count_multi(const DecBatchJo
 }
 __global__ void __launch_bounds__(256) k_jd_unstuff_copy_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; unstuff_copy_body(b.src, b.src_bytes, b.kept_off, b.raw_out, b.rst); }
 __global__ void __launch_bounds__(256) k_jd_build_lut_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; build_lut_body(b.tables, b.lut_out, b.adv_out); }
-// parity: which of the two state / dirty buffers is read (the other one is written); changed_all[image] collects "a round of the
-// last pair changed something" for one read-back per batch
+// parity: which of the two state / dirty buffers is read (the other one is written).  round: number of the launch, 1, 2, ... --
+// words 64..127 of an image's flags are a ring of "launch r changed an end state".  A launch that follows one without a change has
+// nothing to do (both state buffers are equal by then) and returns at once, image by image: the host enqueues launches without
+// knowing how many a file needs, and the surplus costs launches, not decodes.  Every launch clears the ring slot of the next one.
+constexpr uint32_t kFlagWords = 128;   // per image: [1] = corrupt data, [64, 128) = the ring
 template <int ROUND>
-__global__ void __launch_bounds__(256) k_jd_sync_multi(const DecBatchJob* jobs, int parity, uint32_t* changed_all) {
+__global__ void __launch_bounds__(256) k_jd_sync_multi(const DecBatchJob* jobs, int parity, uint32_t round) {
   const DecBatchJob& b = jobs[blockIdx.y];
-  if (ROUND == 0) sync_body<0>(b.j, nullptr, b.st[0], nullptr, b.dirty[0], b.nblocks, changed_all + blockIdx.y);
-  else sync_body<1>(b.j, b.st[parity], b.st[parity ^ 1], b.dirty[parity], b.dirty[parity ^ 1], b.nblocks, changed_all + blockIdx.y);
+  uint32_t* ring = b.flags + 64;
+  if (ROUND == 0) { sync_first_body(b.j, b.tables, b.st[0], b.dirty[0], b.nblocks); return; }
+  if (blockIdx.x == 0u && threadIdx.x == 0u) ring[(round + 1u) & 63u] = 0u;
+  if (round >= 2u && ring[(round - 1u) & 63u] == 0u) return;
+  sync_rounds_body(b.j, b.tables, b.st[parity], b.st[parity ^ 1], b.dirty[parity], b.dirty[parity ^ 1], b.nblocks, ring + (round & 63u));
 }
-__global__ void __launch_bounds__(256) k_jd_write_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; write_body(b.j, b.st[0], b.first_block, b.flags + 1); }
+__global__ void __launch_bounds__(256) k_jd_write_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; write_body(b.j, b.tables, b.st[0], b.first_block, b.flags + 1); }
 __global__ void __launch_bounds__(256) k_jd_dc_apply_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; dc_apply_body(b.j, b.dc[0], b.dc[1], b.dc[2]); }
 __global__ void __launch_bounds__(128) k_jd_idct_multi(const DecBatchJob* jobs) { idct_body(jobs[blockIdx.y].j); }
 
@@ -539,8 +688,8 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   size_t o = 0;
   l->src = o; o += up(nbytes + 16);
   l->raw = o; o += up(nbytes + 64);
-  l->lut = o; o += up((size_t)4 * 65536 * 2);
-  l->adv = o; o += up((size_t)4 * 65536 * 2);
+  l->lut = o; o += up((size_t)(4u << kFastBits) * 2);   // the first-level tables
+  l->adv = o; o += up((size_t)(4u << kFastBits) * 2);
   l->st_a = o; o += up((size_t)l->nsub_max * sizeof(DState));
   l->st_b = o; o += up((size_t)l->nsub_max * sizeof(DState));
   l->dirty_a = o; o += up((size_t)l->nsub_max + 2);
@@ -557,7 +706,7 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
 
 // where the batch-level arrays sit inside the scratch buffer
 struct BatchLayout {
-  size_t jobs, flags, changed, offs, kept, kept_off, nblocks, first_block, dc[3], tmp, tmp_bytes, total;
+  size_t jobs, flags, offs, kept, kept_off, nblocks, first_block, dc[3], tmp, tmp_bytes, total;
   uint32_t n_kept, n_sub, n_blk;
 };
 static BatchLayout batch_layout(int n, const DecLayout l[]) {
@@ -567,8 +716,7 @@ static BatchLayout batch_layout(int n, const DecLayout l[]) {
   for (int k = 0; k < n; ++k) { B.n_kept += l[k].nchunks + 1u; B.n_sub += l[k].nsub_max + 1u; B.n_blk += l[k].nblk; }
   size_t o = 0;
   B.jobs = o; o += up((size_t)n * sizeof(DecBatchJob));
-  B.flags = o; o += (size_t)n * 256;
-  B.changed = o; o += up((size_t)n * 4);
+  B.flags = o; o += up((size_t)n * kFlagWords * 4);
   B.offs = o; o += up((size_t)3 * (n + 1) * 4);
   B.kept = o; o += up((size_t)B.n_kept * 4);
   B.kept_off = o; o += up((size_t)B.n_kept * 4);
@@ -593,6 +741,13 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
                         uint8_t* batch_ws, hipError_t* herr, int* image_rc) {
 #define JD_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { *herr = _e; (void)hipStreamSynchronize(s); return 1; } } while (0)
   if (n < 1) return -1;
+#ifdef UHDR_JD_TIMING
+  auto TT = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[jd]   %-28s %.0f us\n", what, std::chrono::duration<double, std::micro>(t - TT).count()); TT = t; };
+#define JD_LAP(x) lap(x)
+#else
+#define JD_LAP(x) do {} while (0)
+#endif
   // jobs and offset tables are assembled in page-locked memory that lives across calls (per host thread): their upload is then a
   // real asynchronous copy and needs no synchronisation of its own (every call ends with the stream idle, so reuse is safe)
   static thread_local void* t_pinned = nullptr;
@@ -609,8 +764,7 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   std::vector<std::vector<uint32_t>> keep;   // restart-interval tables: alive until the uploads have happened
   const BatchLayout B = batch_layout(n, l);
   DecBatchJob* djobs = reinterpret_cast<DecBatchJob*>(batch_ws + B.jobs);
-  uint32_t* dflags = reinterpret_cast<uint32_t*>(batch_ws + B.flags);   // 64 words per image
-  uint32_t* dchanged = reinterpret_cast<uint32_t*>(batch_ws + B.changed);
+  uint32_t* dflags = reinterpret_cast<uint32_t*>(batch_ws + B.flags);   // kFlagWords per image
   uint32_t* doffs = reinterpret_cast<uint32_t*>(batch_ws + B.offs);      // three offset tables of n + 1 entries: kept, subsequences, blocks
   uint32_t* offs = reinterpret_cast<uint32_t*>(jobs + n);
   const size_t noffs = (size_t)3 * (n + 1);
@@ -631,7 +785,7 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     b.st[0] = reinterpret_cast<DState*>(w + L.st_a); b.st[1] = reinterpret_cast<DState*>(w + L.st_b);
     b.dirty[0] = w + L.dirty_a; b.dirty[1] = w + L.dirty_b;
     b.nblocks = reinterpret_cast<uint32_t*>(batch_ws + B.nblocks) + soff[k];
-    b.flags = dflags + 64u * (uint32_t)k;
+    b.flags = dflags + kFlagWords * (uint32_t)k;
     b.first_block = reinterpret_cast<const uint32_t*>(batch_ws + B.first_block) + soff[k];
     for (int c = 0; c < 3; ++c) b.dc[c] = reinterpret_cast<const int*>(batch_ws + B.dc[c]) + boff[k];
     DecJob& j = b.j;
@@ -666,7 +820,7 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     }
     if (j.nsub == 0u || j.nsub > L.nsub_max) bad[k] = 1;
     if (bad[k]) { j.nsub = 0u; j.nblk = 0u; b.src_bytes = 0u; }   // every kernel's bounds check then skips this image
-    b.zero[0] = reinterpret_cast<uint8_t*>(b.flags); b.zero_words[0] = 16u;
+    b.zero[0] = reinterpret_cast<uint8_t*>(b.flags); b.zero_words[0] = kFlagWords / 4u;
     b.zero[1] = w + L.raw; b.zero_words[1] = bad[k] ? 0u : (uint32_t)((((size_t)in.scan_bytes + 64 + 255) / 256 * 256) / 16);
     b.zero[2] = reinterpret_cast<uint8_t*>(j.coef); b.zero_words[2] = (uint32_t)(((size_t)j.nblk * 128) / 16);
     koff[k + 1] = koff[k] + (bad[k] ? 0u : L.nchunks + 1u);
@@ -680,6 +834,7 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   JD_TRY(hipMemcpyAsync(djobs, jobs, (size_t)n * sizeof(DecBatchJob), hipMemcpyHostToDevice, s));
   JD_TRY(hipMemcpyAsync(doffs, offs, noffs * 4, hipMemcpyHostToDevice, s));
   if (!keep.empty()) JD_TRY(hipStreamSynchronize(s));   // restart tables are in pageable host memory
+  JD_LAP("jobs assembled + uploaded");
   const SegOf kseg{doffs, n}, sseg{doffs + (n + 1), n}, bseg{doffs + 2 * (n + 1), n};
   const CountIt cnt0(0u);
   uint8_t* stmp = batch_ws + B.tmp;
@@ -694,24 +849,24 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
                                                  reinterpret_cast<uint32_t*>(batch_ws + B.kept_off), (int)koff[n], hipcub::Equality(), s));
   }
   hipLaunchKernelGGL(k_jd_unstuff_copy_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
-  hipLaunchKernelGGL(k_jd_build_lut_multi, dim3(4u * 65536u / 256u, ny), b256, 0, s, (const DecBatchJob*)djobs);
-  hipLaunchKernelGGL(k_jd_sync_multi<0>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, dchanged);
-  std::vector<uint32_t> changed((size_t)n, 0u);
+  hipLaunchKernelGGL(k_jd_build_lut_multi, dim3((4u << kFastBits) / 256u, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  hipLaunchKernelGGL(k_jd_sync_multi<0>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, 0u);
+  JD_LAP("enqueued through sync<0>");
+  std::vector<uint32_t> flags((size_t)n * kFlagWords, 0u);
   uint32_t max_nsub = 0;
   for (int k = 0; k < n; ++k) max_nsub = std::max(max_nsub, jobs[k].j.nsub);
-  uint32_t done_rounds = 0;
-  for (uint32_t batch = 4;; batch = batch < 16u ? batch * 2u : 16u) {
-    if (done_rounds > max_nsub + 32u) { (void)hipStreamSynchronize(s); return -1; }   // cannot happen: every round fixes at least one more subsequence
-    for (uint32_t r = 0; r < batch; r += 2) {
-      if (r == batch - 2) JD_TRY(hipMemsetAsync(dchanged, 0, (size_t)n * 4, s));
-      hipLaunchKernelGGL(k_jd_sync_multi<1>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, dchanged);
-      hipLaunchKernelGGL(k_jd_sync_multi<1>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 1, dchanged);
+  uint32_t round = 1;
+  for (uint32_t batch = kFirstLaunches;; batch = kMoreLaunches) {   // (even numbers)
+    if (round > max_nsub + 34u) { (void)hipStreamSynchronize(s); return -1; }   // cannot happen: every launch fixes at least one more subsequence
+    for (uint32_t r = 0; r < batch; r += 2, round += 2) {   // odd rounds read buffer 0, even ones buffer 1: the result is in buffer 0
+      hipLaunchKernelGGL(k_jd_sync_multi<1>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, round);
+      hipLaunchKernelGGL(k_jd_sync_multi<1>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 1, round + 1u);
     }
-    done_rounds += batch;
-    JD_TRY(hipMemcpyAsync(changed.data(), dchanged, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    JD_TRY(hipMemcpyAsync(flags.data(), dflags, flags.size() * 4, hipMemcpyDeviceToHost, s));
     JD_TRY(hipStreamSynchronize(s));
+    JD_LAP("round batch synced");
     bool any = false;
-    for (int k = 0; k < n; ++k) any = any || changed[k] != 0u;
+    for (int k = 0; k < n; ++k) any = any || flags[(size_t)k * kFlagWords + 64u + ((round - 1u) & 63u)] != 0u;
     if (!any) break;
   }
   if (soff[n]) {   // blocks completed before each subsequence, counted from the start of its image (of its restart interval)
@@ -729,13 +884,14 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   }
   hipLaunchKernelGGL(k_jd_dc_apply_multi, dim3(gblk, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_idct_multi, dim3(gidct, ny), dim3(128), 0, s, (const DecBatchJob*)djobs);
-  std::vector<uint32_t> flags((size_t)n * 64u, 0u);
+  JD_LAP("tail enqueued");
   JD_TRY(hipMemcpyAsync(flags.data(), dflags, flags.size() * 4, hipMemcpyDeviceToHost, s));
   JD_TRY(hipStreamSynchronize(s));
+  JD_LAP("final sync");
   JD_TRY(hipGetLastError());
   int out = 0;
   for (int k = 0; k < n; ++k) {
-    if (bad[k] || flags[64u * (size_t)k + 1u]) { bad[k] = 1; out = -1; }
+    if (bad[k] || flags[kFlagWords * (size_t)k + 1u]) { bad[k] = 1; out = -1; }
     if (image_rc) image_rc[k] = bad[k] ? -1 : 0;
   }
   return out;

@@ -1,8 +1,11 @@
 // uhdr_jpeg_hdr.cpp -- the host-side JPEG header parser of the device decoder (baseline sequential, 8 bit, Huffman, 4:2:0 or
-// single plane, no restart intervals).  Everything it returns sizes or indexes device buffers, so it sees the untrusted file first;
+// single plane, with or without restart intervals).  Everything it returns sizes or indexes device buffers, so it sees the untrusted file first;
 // plain C++ on purpose: tests/cpp/fuzz_host_parsers.cpp builds it with AddressSanitizer / UBSan on the CPU.
 // Follows what jpeg_read_header + the checks of JpegDecoderHelper::decode accept (lib/src/jpegdecoderhelper.cpp:190-300).
 #include <cstring>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "uhdr_jpeg.h"
 
@@ -10,6 +13,45 @@ namespace uhdr {
 namespace jpeg {
 
 static unsigned rd16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+// The walk over the entropy-coded segment (megabytes): every 0xFF is classified by the byte behind it -- 0x00: a stuffed zero (counted),
+// 0xFF: a fill byte (skipped), anything else: a marker.  A quality-95 scan holds a 0xFF every ~250 bytes, and a branch per hit
+// (mispredicted: the positions are random) costs more than the search, so 16 bytes at a time are classified without one and the
+// zeros counted in byte lanes; only a real marker (RSTn, or the one that ends the segment) leaves the loop.  Returns the position of
+// the next marker's 0xFF at or behind `e`, or of the first byte the loop did not look at, with `stuffed` advanced up to there.
+static size_t skip_to_marker(const uint8_t* p, size_t e, size_t n, uint32_t* stuffed) {
+#if defined(__SSE2__)
+  const __m128i ff = _mm_set1_epi8((char)0xFF), zero = _mm_setzero_si128();
+  __m128i acc = zero;
+  unsigned pending = 0;
+  auto flush = [&]() {
+    const __m128i sad = _mm_sad_epu8(acc, zero);
+    *stuffed += (uint32_t)_mm_cvtsi128_si32(sad) + (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(sad, 8));
+    acc = zero;
+    pending = 0;
+  };
+  while (e + 17 <= n) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + e));
+    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + e + 1));
+    const __m128i is_ff = _mm_cmpeq_epi8(a, ff);
+    const __m128i z = _mm_cmpeq_epi8(b, zero);
+    const __m128i st = _mm_and_si128(is_ff, z);
+    const int mk = _mm_movemask_epi8(_mm_andnot_si128(_mm_or_si128(z, _mm_cmpeq_epi8(b, ff)), is_ff));
+    if (mk != 0) {
+      const unsigned m = (unsigned)__builtin_ctz((unsigned)mk);
+      flush();
+      *stuffed += (uint32_t)__builtin_popcount((unsigned)_mm_movemask_epi8(st) & ((1u << m) - 1u));
+      return e + m;
+    }
+    acc = _mm_sub_epi8(acc, st);   // a set lane is 0xFF = -1
+    if (++pending == 255u) flush();
+    e += 16;
+  }
+  flush();
+#endif
+  (void)stuffed;
+  return e;
+}
 
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
   if (jpg == nullptr || n < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return -1;
@@ -53,6 +95,7 @@ int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
           h.first_code[l] = (uint16_t)code;
           h.first_val[l] = (uint16_t)p;
           h.count[l] = seg[o + l];
+          if (code + h.count[l] > (1u << l)) return -1;   // more codes than l bits hold: not a prefix code (libjpeg: JERR_BAD_HUFF_TABLE)
           code += h.count[l];
           p += h.count[l];
           code <<= 1;
@@ -96,10 +139,10 @@ int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
       size_t e = info->scan_offset;
       uint32_t stuffed = 0, markers = 0;
       if (info->restart_interval != 0) info->interval_start.push_back(0u);
-      for (;;) {   // memchr: the segment is megabytes long and 0xFF is rare in it
-        const void* f = e + 1 < n ? memchr(jpg + e, 0xFF, n - 1 - e) : nullptr;
-        if (f == nullptr) return -1;
-        e = (size_t)(static_cast<const uint8_t*>(f) - jpg);
+      for (;;) {
+        e = skip_to_marker(jpg, e, n, &stuffed);
+        while (e + 1 < n && jpg[e] != 0xFF) ++e;
+        if (e + 1 >= n) return -1;
         const uint8_t b = jpg[e + 1];
         if (b == 0x00) { ++stuffed; e += 2; continue; }
         if (b == 0xFF) { e += 1; continue; }

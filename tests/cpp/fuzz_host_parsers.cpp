@@ -22,6 +22,42 @@ static uint32_t rnd() {
   return (uint32_t)(rng_state >> 16);
 }
 
+// the walk over the entropy-coded segment, byte by byte (what parse_header's 16-bytes-at-a-time classification must equal):
+// returns false where parse_header has to fail
+static bool walk_scan(const uint8_t* jpg, size_t n, size_t from, bool dri, size_t* scan_bytes, uint32_t* raw_bytes, std::vector<uint32_t>* starts) {
+  size_t e = from;
+  uint32_t stuffed = 0, markers = 0;
+  starts->clear();
+  if (dri) starts->push_back(0u);
+  for (;;) {
+    while (e + 1 < n && jpg[e] != 0xFF) ++e;
+    if (e + 1 >= n) return false;
+    const uint8_t b = jpg[e + 1];
+    if (b == 0x00) { ++stuffed; e += 2; continue; }
+    if (b == 0xFF) { e += 1; continue; }
+    if ((b & 0xF8) == 0xD0) {
+      if (!dri) return false;
+      ++markers; e += 2;
+      starts->push_back((uint32_t)(e - from - stuffed - 2u * markers));
+      continue;
+    }
+    break;
+  }
+  *scan_bytes = e - from;
+  *raw_bytes = (uint32_t)(*scan_bytes - stuffed - 2u * markers);
+  return true;
+}
+
+static void check_walk(const uint8_t* j, size_t n, int rc, const jpeg::DecInfo& info) {
+  if (rc != 0) return;   // (a failure can have many causes; the walk is compared where the header was accepted)
+  size_t sb = 0; uint32_t rb = 0; std::vector<uint32_t> st;
+  if (!walk_scan(j, n, info.scan_offset, info.restart_interval != 0, &sb, &rb, &st)) { fprintf(stderr, "walk: accepted a scan the byte walk rejects\n"); abort(); }
+  if (sb != info.scan_bytes || rb != info.raw_bytes || st != info.interval_start) {
+    fprintf(stderr, "walk: scan %zu/%zu raw %u/%u intervals %zu/%zu\n", info.scan_bytes, sb, info.raw_bytes, rb, info.interval_start.size(), st.size());
+    abort();
+  }
+}
+
 static void exercise(const std::vector<uint8_t>& in) {
   // exact-size heap copy so that any read past the end is an ASan report
   uint8_t* d = static_cast<uint8_t*>(malloc(in.size() ? in.size() : 1));
@@ -45,7 +81,9 @@ static void exercise(const std::vector<uint8_t>& in) {
     int w, h;
     (void)jpegr::dimensions(j, img[i].len, &w, &h);
     jpeg::DecInfo info;
-    if (jpeg::parse_header(j, img[i].len, &info) == 0) {
+    const int prc = jpeg::parse_header(j, img[i].len, &info);
+    check_walk(j, img[i].len, prc, info);
+    if (prc == 0) {
       if (info.scan_offset + info.scan_bytes > img[i].len || info.w <= 0 || info.h <= 0 || info.w > 65535 || info.h > 65535) { fprintf(stderr, "bad DecInfo\n"); abort(); }
       if (info.raw_bytes > info.scan_bytes) { fprintf(stderr, "raw > scan\n"); abort(); }
       for (size_t k = 0; k < info.interval_start.size(); ++k)   // what the device decoder indexes its bit string with
@@ -82,6 +120,41 @@ int main(int argc, char** argv) {
   }
   const long iters = atol(argv[argc - 1]);
   for (const auto& s : seeds) exercise(s);
+  // scans made of the bytes the walk cares about, at every alignment and length: the header of a seed that parses, then a random
+  // mix of 0xFF / 0x00 / RSTn / fill / data bytes, then EOI (with and without a DRI segment in front of the scan)
+  for (const auto& sd : seeds) {
+    jpeg::DecInfo hdr;
+    if (jpeg::parse_header(sd.data(), sd.size(), &hdr) != 0) continue;
+    for (int it = 0; it < 4000; ++it) {
+      std::vector<uint8_t> v(sd.begin(), sd.begin() + (long)hdr.scan_offset);
+      const size_t len = rnd() % 700;
+      const int ff_rate = 2 + (int)(rnd() % 30);
+      for (size_t k = 0; k < len; ++k) {
+        const uint32_t r = rnd();
+        if ((int)(r % 32u) < ff_rate) {
+          v.push_back(0xFF);
+          const uint32_t q = (r >> 8) % 8u;
+          if (q < 4) v.push_back(0x00);
+          else if (q == 4 && hdr.restart_interval != 0) v.push_back((uint8_t)(0xD0 + ((r >> 16) & 7)));
+          else if (q == 5) v.push_back(0xFF);
+          else v.push_back((uint8_t)(r >> 24) == 0xFF ? 0x12 : (uint8_t)(r >> 24) & 0x7F);
+        } else {
+          v.push_back((uint8_t)((r >> 8) & 0xFE));
+        }
+      }
+      v.push_back(0xFF); v.push_back(0xD9);
+      jpeg::DecInfo info;
+      const int prc = jpeg::parse_header(v.data(), v.size(), &info);
+      size_t sb = 0; uint32_t rb = 0; std::vector<uint32_t> st;
+      const bool ok = walk_scan(v.data(), v.size(), hdr.scan_offset, hdr.restart_interval != 0, &sb, &rb, &st);
+      // (parse_header also checks the number of intervals against the image size, so it may refuse what the walk accepts)
+      if (prc == 0) check_walk(v.data(), v.size(), prc, info);
+      else if (ok && hdr.restart_interval == 0 && prc != 0) {
+        size_t sb2; uint32_t rb2; std::vector<uint32_t> st2;
+        if (walk_scan(v.data(), v.size(), hdr.scan_offset, false, &sb2, &rb2, &st2)) { fprintf(stderr, "walk: refused a scan the byte walk accepts (%d)\n", prc); abort(); }
+      }
+    }
+  }
   for (long it = 0; it < iters; ++it) {
     std::vector<uint8_t> v = seeds[rnd() % seeds.size()];
     const int kind = rnd() % 6;

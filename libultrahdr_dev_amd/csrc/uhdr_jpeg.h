@@ -78,8 +78,8 @@ struct DecLayout {
 };
 struct DecJob {
   const uint32_t* raw;       // unstuffed entropy-coded bits, big-endian words, zero padded
-  const uint16_t* lut;       // 4 first-level tables (length << 8 | symbol), see build_lut_body
-  const uint16_t* adv;       // 4 first-level tables of position-only entries
+  const uint32_t* lut;       // 4 first-level tables of the final pass (coef_entry), see build_lut_body
+  const uint32_t* adv;       // 4 first-level tables of position-only entries (one symbol | two symbols)
   uint32_t total_bits, nsub, nblk, mcus_x;
   // restart-interval files: subsequence i covers bits [sub_start[i], sub_end[i]) of restart interval sub_key[i] (it never spans
   // two intervals); restart_blocks = blocks per interval.  NULL / 0: one interval, subsequence i = bits [512 i, 512 (i + 1))

@@ -8,8 +8,8 @@
 // A baseline scan without restart markers is ONE bit string: where a code starts is only known once everything before
 // it has been decoded.  The decoder uses the self-synchronisation of Huffman codes (Klein & Wiseman 2003; Weissenberger &
 // Schmidt 2018): a decoder started at a wrong bit position falls in step with the true decoder after a few symbols.
-//   k_jd_unstuff_*_multi   drop the 0x00 after every 0xFF (count per 256-byte chunk, scan, compact) -> raw bit string
-//   k_jd_build_lut_multi   16-bit lookup tables (length, symbol) of the file's own Huffman tables
+//   k_jd_unstuff_*_multi   drop the 0x00 after every 0xFF (count per 64-byte chunk, scan, compact) -> raw bit string
+//   k_jd_build_lut_multi   first-level lookup tables (the next 11 bits -> what the symbol implies) of the file's own Huffman tables
 //   k_jd_sync_multi<0>     every thread decodes one 512-bit subsequence from a guessed state (block 0, coefficient 0) and
 //                    records the state (bit, block-in-MCU, coefficient) it crosses the subsequence's end with
 //   k_jd_sync_multi<1>     rounds: thread i re-decodes subsequence i from the end state of i-1 (only if that state changed);
@@ -17,11 +17,14 @@
 //                    starts from the true state).  Bit and coefficient position fall in step within tens of bits, the
 //                    block-in-MCU index (which decides luma vs. chroma tables) only after ~7 MCUs of a 4:2:0 file, so
 //                    a 4K frame takes 5-8 rounds at quality 75 and 21-24 at quality 95; a round is one lane decoding
-//                    512 bits (~25 us), whatever the number of subsequences: that product is the decoder's latency.
+//                    512 bits (~17 us), whatever the number of subsequences: that product is the decoder's latency.
+//                    A launch runs 4 rounds with the states in LDS and returns at once when the one before changed nothing.
 //   (scan of the blocks completed per subsequence -> index of the block each subsequence starts in)
 //   k_jd_write_multi       final decode from the true start states: DC differences and AC values into zeroed coefficient blocks
-//   (three masked scans turn DC differences into DC values per component)
-//   k_jd_idct_multi        one thread per block: dequantise, "islow" IDCT, +128, clamp, store cropped to the plane
+//   (one scan turns the DC differences into DC values, the three components side by side)
+//   k_jd_idct_multi        one thread per block: DC value, dequantise, "islow" IDCT, +128, clamp, store cropped to the plane
+// The decoding kernels read nothing from global memory inside their symbol loops: the workgroup's stretch of the bit string, the
+// first-level tables and the canonical form of the longer codes are in LDS (a wave waits for all its memory operations at once).
 // Restart intervals (DRI / RSTn) make the job easier, not harder: every interval is a byte-aligned bit string of its own whose
 // start state is known, so its first subsequence plays the role of subsequence 0, nothing is carried across an interval boundary,
 // and the block index and the DC predictors restart with it (segmented scans).  The host finds the markers while it looks for the
@@ -123,9 +126,10 @@ __device__ __forceinline__ void unstuff_copy_body(const uint8_t* src, uint32_t n
 constexpr uint32_t kFastBitsEarly = UHDR_JD_FASTBITS;   // == kFastBits (first-level table width), needed before its definition
 // ---- Huffman lookup tables -----------------------------------------------------------------------------------------
 // First-level tables, indexed by the next kFastBits bits of the stream; a workgroup that decodes copies them into LDS.
-// lut[x]: (code length << 8) | symbol, 0 when no code of at most kFastBits bits matches.
-// adv[x]: what the position-only passes need from a symbol, in one 16-bit entry: bits 8..12 = bits consumed (code + value bits,
-// <= 27), bits 0..6 = advance of the coefficient index (DC: 1; AC: run + 1, ZRL 16, EOB 64); 0x8000 when no such code matches.
+// lut[x]: the 32-bit entry of the final pass (coef_entry), 0 when no code of at most kFastBits bits matches.
+// adv[x]: what the position-only passes need from a symbol, in 16 bits: bits 8..13 = bits consumed (code + value bits, <= 27),
+// bits 0..6 = advance of the coefficient index (DC: 1; AC: run + 1, ZRL 16, EOB 64); 0x8000 when no such code matches.  The
+// upper 16 bits: the same for this symbol and the next one together, where both lie inside the pattern (0: no pair).
 // Longer codes (and "no code at all") are resolved from the canonical form of the table, also in LDS (LongCodes): a decoding loop
 // must not load from memory -- a wave waits for all its outstanding vector memory operations at once, coefficient stores included.
 __device__ __forceinline__ uint32_t adv_entry(uint32_t tb, uint32_t len, uint32_t sym) {
@@ -133,29 +137,53 @@ __device__ __forceinline__ uint32_t adv_entry(uint32_t tb, uint32_t len, uint32_
   const uint32_t dz = (tb & 1u) == 0u ? 1u : (vb != 0u ? r + 1u : (r == 15u ? 16u : 64u));
   return ((len + vb) << 8) | dz;
 }
-__device__ __forceinline__ void build_lut_body(const DecTables& t, uint16_t* lut, uint16_t* adv) {
+// What the final pass needs from a symbol: bits 0..4 code length, 5..8 value bits, 9..15 advance of the coefficient index, 16..19 run
+// of zeros in front of the coefficient, bit 20 = the symbol carries a coefficient, bit 21 = not a code (one bit consumed).
+constexpr uint32_t kNoCodeEntry = 1u | (1u << 21);
+__device__ __forceinline__ uint32_t coef_entry(uint32_t tb, uint32_t len, uint32_t sym) {
+  const uint32_t vb = sym & 15u, r = sym >> 4;
+  if ((tb & 1u) == 0u) return len | (vb << 5) | (1u << 9) | (1u << 20);              // DC: the difference, position 0
+  if (vb != 0u) return len | (vb << 5) | ((r + 1u) << 9) | (r << 16) | (1u << 20);   // AC: r zeros, then the value
+  return len | ((r == 15u ? 16u : 64u) << 9);                                        // ZRL / EOB (runs of 1..14 zeros without a value: as EOB)
+}
+// the code of at most `avail` bits at the top of the kFastBits-bit pattern x: (length << 8) | symbol, or 0
+__device__ __forceinline__ uint32_t short_code(const HuffSpec& h, uint32_t x, uint32_t avail) {
+#pragma unroll 1
+  for (uint32_t l = 1; l <= avail; ++l) {
+    const uint32_t code = x >> (kFastBitsEarly - l);
+    if (code >= h.first_code[l] && code - h.first_code[l] < h.count[l]) return (l << 8) | h.vals[h.first_val[l] + code - h.first_code[l]];
+  }
+  return 0u;
+}
+__device__ __forceinline__ void build_lut_body(const DecTables& t, uint32_t* lut, uint32_t* adv) {
   const uint32_t g = blockIdx.x * 256u + threadIdx.x;   // 4 tables x 2^kFastBits
   if (g >= (4u << kFastBitsEarly)) return;
   const uint32_t tb = g >> kFastBitsEarly, x = g & ((1u << kFastBitsEarly) - 1u);
   const HuffSpec& h = t.huff[tb];
-  uint16_t e = 0;
-  if (h.present) {
-#pragma unroll 1
-    for (uint32_t l = 1; l <= kFastBitsEarly; ++l) {
-      const uint32_t code = x >> (kFastBitsEarly - l);
-      if (code >= h.first_code[l] && code - h.first_code[l] < h.count[l]) {
-        e = (uint16_t)((l << 8) | h.vals[h.first_val[l] + code - h.first_code[l]]);
-        break;
+  const uint32_t e = h.present ? short_code(h, x, kFastBitsEarly) : 0u;
+  lut[g] = e != 0u ? coef_entry(tb, e >> 8, e & 0xFFu) : 0u;
+  uint32_t a = 0x8000u;
+  if (e != 0u) {
+    a = adv_entry(tb, e >> 8, e & 0xFFu);
+    // An AC symbol that does not end the block is followed by another code of the same table: when that one lies inside the
+    // pattern too, the upper half of the entry is the pair (bits and index advance of both); step_pos takes it when the first
+    // symbol neither fills the block nor crosses the subsequence's end.  Two symbols per table lookup where the codes are short.
+    const uint32_t bits1 = (a >> 8) & 31u, dz1 = a & 127u;
+    if ((tb & 1u) != 0u && dz1 < 64u && bits1 < kFastBitsEarly) {
+      const uint32_t e2 = short_code(h, (x << bits1) & ((1u << kFastBitsEarly) - 1u), kFastBitsEarly - bits1);
+      if (e2 != 0u) {
+        const uint32_t a2 = adv_entry(tb, e2 >> 8, e2 & 0xFFu);
+        const uint32_t bits = bits1 + ((a2 >> 8) & 31u);
+        // (a step may consume 32 bits at most: the window is refilled one word at a time)
+        if (bits <= 32u) a |= ((bits << 8) | (dz1 + (a2 & 127u))) << 16;   // advance <= 16 + 64: 7 bits
       }
     }
   }
-  lut[g] = e;
-  adv[g] = e != 0 ? (uint16_t)adv_entry(tb, e >> 8, e & 0xFFu) : (uint16_t)0x8000u;
+  adv[g] = a;
 }
 
 // ---- the sequential decoder one thread runs over a stretch of bits ------------------------------------------------------
 struct DState { uint32_t p; uint32_t cz; };   // bit position; (block-in-MCU << 8) | coefficient index
-__device__ __forceinline__ int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }   // T.81 F.2.2.1
 
 // A symbol costs two dependent memory reads (stream bits, then the code table); from L2 that is ~1000 cycles per symbol, and a
 // wave waits for the slowest of its lanes at every symbol (one s_waitcnt covers all outstanding loads).  So nothing in the
@@ -217,62 +245,47 @@ struct Reader {
   }
 };
 
-// One symbol.  MODE 0: advance only; MODE 1: also report the coefficient (position zpos, value val; has = true).
-// A bit pattern that is no code (only possible off-sync, or in a corrupt file) consumes one bit: any deterministic rule
-// will do for the synchronisation, and the final pass flags it.
+// One symbol of the final pass: the coefficient it carries (has: at zigzag position zpos of the current block, value val) and
+// the new state.  Everything the symbol implies sits in one 32-bit table entry (coef_entry), so the walk has no branches but the
+// rare long-code lookup and the window refill.  A bit pattern that is no code (only possible off-sync, or in a corrupt file)
+// consumes one bit -- any deterministic rule will do for the synchronisation -- and is reported (returns false), as is a run
+// that leaves the block.
 // gray: the job's field by value -- read through the job it would be loaded again after every coefficient store (the compiler
 // must assume the store hit it), and the wait for that load would sit out the store.
-template <int MODE>
-__device__ __forceinline__ bool step(const bool gray, const LongCodes& lc, const uint16_t (*s_lut)[1u << kFastBits], Reader& rd, DState& s,
-                                     bool& block_done, int& zpos, int& val, bool& has) {
+__device__ __forceinline__ bool step_coef(const bool gray, const LongCodes& lc, const uint32_t (*s_lut)[1u << kFastBits], Reader& rd, DState& s,
+                                          bool& block_done, uint32_t& zpos, int& val, bool& has) {
   const uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
-  const uint32_t comp_chroma = gray ? 0u : (c >= 4u ? 1u : 0u);
-  const uint32_t tb = 2u * comp_chroma + (z != 0u ? 1u : 0u);   // slots: 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma (no table in memory: a
-                                                                 // lane-indexed kernel-argument array is a ~500-cycle load per symbol)
+  const uint32_t tb = (gray ? 0u : (c >= 4u ? 2u : 0u)) + (z != 0u ? 1u : 0u);   // slots: 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma
   const uint32_t sh = s.p - rd.base;
   const uint64_t w = rd.win;
   const uint32_t peek = (uint32_t)(w >> (48u - sh)) & 0xFFFFu;
   uint32_t e = s_lut[tb][peek >> (16u - kFastBits)];
-  if (e == 0u) e = long_code(lc, tb, peek);
-  const uint32_t len = e >> 8, sym = e & 0xFFu;
-  block_done = false;
-  has = false;
-  bool ok = true;
-  if (len == 0u) { s.p += 1u; rd.advance_to(s.p); return false; }
-  uint32_t nz = z, vbits = 0;
-  if (z == 0u) {
-    vbits = sym & 15u;
-    nz = 1u;
-    if (MODE == 1) { zpos = 0; has = true; }
-  } else {
-    const uint32_t r = sym >> 4;
-    vbits = sym & 15u;
-    if (vbits == 0u) {
-      if (r == 15u) nz = z + 16u;
-      else nz = 64u;                       // EOB
-    } else {
-      nz = z + r;
-      if (MODE == 1) { zpos = (int)nz; has = nz < 64u; }
-      ok = nz < 64u;
-      nz += 1u;
-    }
+  if (e == 0u) {
+    const uint32_t ls = long_code(lc, tb, peek);
+    e = ls != 0u ? coef_entry(tb, ls >> 8, ls & 0xFFu) : kNoCodeEntry;
   }
-  if (MODE == 1 && has) {
-    const int raw = vbits ? (int)((w >> (64u - sh - len - vbits)) & ((1u << vbits) - 1u)) : 0;
-    val = vbits ? extend(raw, (int)vbits) : 0;
-  }
+  const uint32_t len = e & 31u, vbits = (e >> 5) & 15u, dz = (e >> 9) & 127u, run = (e >> 16) & 15u;
+  zpos = z + run;
+  has = ((e >> 20) & 1u) != 0u && zpos < 64u;
+  const bool ok = ((e >> 21) & 1u) == 0u && (((e >> 20) & 1u) == 0u || zpos < 64u);
+  const uint32_t raw = (uint32_t)(w >> (64u - sh - len - vbits)) & ((1u << vbits) - 1u);   // (sh + len + vbits <= 62)
+  val = raw < ((1u << vbits) >> 1) ? (int)raw - (int)(1u << vbits) + 1 : (int)raw;         // T.81 F.2.2.1; no value bits: 0
   s.p += len + vbits;
   rd.advance_to(s.p);
-  if (nz >= 64u) { block_done = true; nz = 0u; }
+  uint32_t nz = z + dz;
+  block_done = nz >= 64u;
+  nz = block_done ? 0u : nz;
   const uint32_t bpm = gray ? 1u : 6u;
   const uint32_t nc = block_done ? (c + 1u == bpm ? 0u : c + 1u) : c;
   s.cz = (nc << 8) | nz;
   return ok;
 }
 
-// The position-only form of step() for the synchronisation passes: no branches but the rare long-code lookup.
-__device__ __forceinline__ void step_pos(const bool gray, const LongCodes& lc, const uint16_t (*s_adv)[1u << kFastBits], Reader& rd, DState& s,
-                                         uint32_t& blocks) {
+// The position-only walk of the synchronisation passes: one symbol -- or two, when the table entry holds a pair and the first one
+// neither completes the block nor crosses the subsequence's end (the state a subsequence ends with is the one behind the first
+// symbol that crosses it).  No branches but the rare long-code lookup and the window refill.
+__device__ __forceinline__ void step_pos(const bool gray, const LongCodes& lc, const uint32_t (*s_adv)[1u << kFastBits], Reader& rd, DState& s,
+                                         const uint32_t end, uint32_t& blocks) {
   const uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
   const uint32_t tb = (gray ? 0u : (c >= 4u ? 2u : 0u)) + (z != 0u ? 1u : 0u);
   const uint32_t sh = s.p - rd.base;
@@ -282,7 +295,10 @@ __device__ __forceinline__ void step_pos(const bool gray, const LongCodes& lc, c
     const uint32_t e = long_code(lc, tb, peek);
     a = e != 0u ? adv_entry(tb, e >> 8, e & 0xFFu) : 0x0100u;   // no code: one bit consumed, index unchanged
   }
-  s.p += (a >> 8) & 31u;
+  const uint32_t pair = a >> 16;
+  const bool both = pair != 0u && z + (a & 127u) < 64u && s.p + ((a >> 8) & 63u) < end;
+  a = both ? pair : a;
+  s.p += (a >> 8) & 63u;     // (at most 32 bits: build_lut_body)
   rd.advance_to(s.p);
   uint32_t nz = z + (a & 127u);
   const bool done = nz >= 64u;
@@ -293,10 +309,11 @@ __device__ __forceinline__ void step_pos(const bool gray, const LongCodes& lc, c
   s.cz = (nc << 8) | nz;
 }
 // workgroup prologue: one of the two first-level tables -> LDS (16 bytes per lane and turn; ends with a barrier)
-__device__ __forceinline__ void load_fast_table(const uint16_t* table, uint16_t (*s_tab)[1u << kFastBits]) {
+template <typename T>
+__device__ __forceinline__ void load_fast_table(const T* table, T (*s_tab)[1u << kFastBits]) {
   const uint4* src = reinterpret_cast<const uint4*>(table);
   uint4* dst = reinterpret_cast<uint4*>(&s_tab[0][0]);
-  for (uint32_t g = threadIdx.x; g < (4u << kFastBits) / 8u; g += blockDim.x) dst[g] = src[g];
+  for (uint32_t g = threadIdx.x; g < (4u << kFastBits) * sizeof(T) / 16u; g += blockDim.x) dst[g] = src[g];
   __syncthreads();
 }
 
@@ -333,7 +350,7 @@ __device__ __forceinline__ uint32_t stage_bits(const DecJob& j, uint32_t i0, uin
 // One position-only decode of subsequence i from state s until its end is crossed; nb: blocks completed on the way.
 // (A corrupt state cannot come out of the rounds -- positions only grow, by at most one symbol past an end -- but a read outside
 // the staged words must be impossible, not unlikely: such a state decodes nothing and keeps its value.)
-__device__ __forceinline__ void decode_positions(const DecJob& j, const LongCodes& lc, const uint16_t (*s_adv)[1u << kFastBits], const uint32_t* s_bits,
+__device__ __forceinline__ void decode_positions(const DecJob& j, const LongCodes& lc, const uint32_t (*s_adv)[1u << kFastBits], const uint32_t* s_bits,
                                                  uint32_t w0, uint32_t i, DState& s, uint32_t& nb) {
   const uint32_t end = sub_end_bit(j, i);
   const bool gray = j.gray != 0;
@@ -341,14 +358,14 @@ __device__ __forceinline__ void decode_positions(const DecJob& j, const LongCode
   if ((s.p >> 5) >= w0 && (s.p >> 5) - w0 + 3u < kStageWords && end > s.p && end - s.p <= kSubBits + 32u) {
     Reader rd;
     rd.init(s_bits, w0, s.p);
-    while (s.p < end) step_pos(gray, lc, s_adv, rd, s, nb);
+    while (s.p < end) step_pos(gray, lc, s_adv, rd, s, end, nb);
   }
 }
 
 // The first pass: every subsequence from the guess (its own start, block 0, coefficient 0; the true state for the first one of the
 // scan or of a restart interval).  Records the state each crosses its end with; every start state counts as new (dirty).
 __device__ __forceinline__ void sync_first_body(const DecJob& j, const DecTables& tables, DState* next, uint8_t* dirty_out, uint32_t* nblocks) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_adv[4][1u << kFastBits];
+  __shared__ __attribute__((aligned(16))) uint32_t s_adv[4][1u << kFastBits];
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[kStageWords];
   __shared__ LongCodes s_long;
   const uint32_t i0 = blockIdx.x * 256u, i = i0 + threadIdx.x;
@@ -382,7 +399,7 @@ constexpr uint32_t kFirstLaunches = 2u * ((8u + 2u * kLocalRounds - 1u) / (2u * 
 constexpr uint32_t kMoreLaunches = 2u * ((16u + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
 __device__ __forceinline__ void sync_rounds_body(const DecJob& j, const DecTables& tables, const DState* prev, DState* next, const uint8_t* dirty_in,
                                                  uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_adv[4][1u << kFastBits];
+  __shared__ __attribute__((aligned(16))) uint32_t s_adv[4][1u << kFastBits];
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[kStageWords];
   __shared__ LongCodes s_long;
   __shared__ DState s_st[256];
@@ -440,7 +457,7 @@ __device__ __forceinline__ void sync_rounds_body(const DecJob& j, const DecTable
 }
 
 __device__ __forceinline__ void write_body(const DecJob& j, const DecTables& tables, const DState* st, const uint32_t* first_block, uint32_t* error) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_lut[4][1u << kFastBits];
+  __shared__ __attribute__((aligned(16))) uint32_t s_lut[4][1u << kFastBits];
   __shared__ __attribute__((aligned(16))) uint32_t s_bits[kStageWords];
   const uint32_t i0 = blockIdx.x * 256u, i = i0 + threadIdx.x;
   if (i0 >= j.nsub) return;
@@ -464,7 +481,8 @@ __device__ __forceinline__ void write_body(const DecJob& j, const DecTables& tab
     blk_end = (k + 1u) * j.restart_blocks < j.nblk ? (k + 1u) * j.restart_blocks : j.nblk;
   }
   bool bd, has;
-  int zp = 0, v = 0;
+  uint32_t zp = 0;
+  int v = 0;
   // The pointer comes out of a structure in memory, so the compiler would store through a FLAT instruction -- and those count as
   // LDS traffic too: the wait in front of the next symbol's table lookup would then sit out the scattered store of this one.
   // A global store is waited for by nothing in this loop (which is why the loop must not load from memory either).
@@ -473,22 +491,19 @@ __device__ __forceinline__ void write_body(const DecJob& j, const DecTables& tab
   const bool gray = j.gray != 0;
   bool bad = false;
   while (s.p < end && blk < blk_end) {   // (stops in front of the 1-bits that pad an interval to its byte boundary)
-    const bool ok = step<1>(gray, s_long, s_lut, rd, s, bd, zp, v, has);
+    const bool ok = step_coef(gray, s_long, s_lut, rd, s, bd, zp, v, has);
     bad = bad || !ok;
-    if (has) coef[(size_t)blk * 64u + (uint32_t)zp] = (int16_t)v;
+    if (has) coef[(size_t)blk * 64u + zp] = (int16_t)v;
     blk += bd;
   }
   if (bad || (sub_is_last(j, i) && (blk != blk_end || s.p > end))) *error = 1u;   // an interval (the scan) must end exactly after its last block
 }
 
 // ---- DC prediction: value = running sum of the differences of the same component ---------------------------------------
-struct DcPick {
-  const int16_t* coef;
-  int comp, gray;
-  __host__ __device__ int operator()(uint32_t b) const {
-    const int c = gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
-    return c == comp ? (int)coef[(size_t)b * 64u] : 0;
-  }
+// one running sum per component, scanned together: a block contributes its difference to its own component's sum
+struct Dc3 { int v[3]; };
+struct Dc3Sum {
+  __host__ __device__ Dc3 operator()(const Dc3& a, const Dc3& b) const { Dc3 r; r.v[0] = a.v[0] + b.v[0]; r.v[1] = a.v[1] + b.v[1]; r.v[2] = a.v[2] + b.v[2]; return r; }
 };
 struct BlkKey {   // restart interval a block belongs to: the DC predictors start from zero in each (T.81 F.1.1.5.1 / E.2.4)
   uint32_t per;
@@ -505,14 +520,6 @@ struct SegOf {   // which image element g of a concatenation belongs to; off: n 
     return (uint32_t)lo;
   }
 };
-
-__device__ __forceinline__ void dc_apply_body(const DecJob& j, const int* sum0, const int* sum1, const int* sum2) {
-  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-  if (b >= j.nblk) return;
-  const int c = j.gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
-  const int* s = c == 0 ? sum0 : (c == 1 ? sum1 : sum2);
-  j.coef[(size_t)b * 64u] = (int16_t)s[b];
-}
 
 // ---- dequantisation + IDCT -----------------------------------------------------------------------------------------
 __device__ __forceinline__ int dscale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -539,7 +546,7 @@ __device__ __forceinline__ void idct8(int (&d)[64], int base, int stride) {   //
   d[base + 3 * stride] = dscale(tmp13 + tmp0, sh); d[base + 4 * stride] = dscale(tmp13 - tmp0, sh);
 }
 
-__device__ __forceinline__ void idct_body(const DecJob& j) {
+__device__ __forceinline__ void idct_body(const DecJob& j, const Dc3* dc) {
   const uint32_t b = blockIdx.x * 128u + threadIdx.x;
   if (b >= j.nblk) return;
   int comp, br, bc;
@@ -552,6 +559,7 @@ __device__ __forceinline__ void idct_body(const DecJob& j) {
   }
   const DecPlane& pl = j.plane[comp];
   if (br * 8 >= pl.h || bc * 8 >= pl.w) return;      // a dummy block of the encoder: nothing of it is inside the image
+  const int dc_value = (int)(int16_t)dc[b].v[comp];  // the running sum of the component's differences (the coefficient array holds the difference)
   const uint16_t* q = j.quant[comp];                 // zigzag order
   constexpr uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -568,6 +576,7 @@ __device__ __forceinline__ void idct_body(const DecJob& j) {
       d[nat[8 * k + 2 * m + 1]] = (int)(int16_t)(w[m] >> 16) * (int)q[8 * k + 2 * m + 1];
     }
   }
+  d[0] = dc_value * (int)q[0];
 #pragma unroll
   for (int c = 0; c < 8; ++c) idct8<0>(d, c, 8);
 #pragma unroll
@@ -599,9 +608,9 @@ struct DecBatchJob {
   DecJob j;
   const uint8_t* src; uint32_t src_bytes; int rst;     // unstuffing: stuffed segment -> j.raw
   uint32_t* kept; const uint32_t* kept_off; uint8_t* raw_out;
-  DecTables tables; uint16_t* lut_out; uint16_t* adv_out;
+  DecTables tables; uint32_t* lut_out; uint32_t* adv_out;
   DState* st[2]; uint8_t* dirty[2]; uint32_t* nblocks; uint32_t* flags;
-  const uint32_t* first_block; const int* dc[3];
+  const uint32_t* first_block; const Dc3* dc;
   uint8_t* zero[3]; uint32_t zero_words[3];            // ranges k_jd_zero_multi clears (16-byte multiples)
 };
 struct SubKeyBatch {   // (image, restart interval) of subsequence g of the concatenated nblocks arrays
@@ -621,22 +630,23 @@ struct BlkKeyBatch {   // (image, restart interval) of block g of the concatenat
     return ((uint64_t)img << 32) | (rb ? (g - seg.off[img]) / rb : 0u);
   }
 };
-struct DcPickBatch {   // DcPick through the concatenation
+struct DcPickBatch {   // the DC difference of block g of the concatenation, in its component's slot
   const DecBatchJob* jobs;
   SegOf seg;
-  int comp;
-  __host__ __device__ int operator()(uint32_t g) const {
+  __host__ __device__ Dc3 operator()(uint32_t g) const {
     const uint32_t img = seg(g), b = g - seg.off[img];
     const DecJob& j = jobs[img].j;
     const int c = j.gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
-    return c == comp ? (int)j.coef[(size_t)b * 64u] : 0;
+    Dc3 r; r.v[0] = r.v[1] = r.v[2] = 0;
+    r.v[c] = (int)j.coef[(size_t)b * 64u];
+    return r;
   }
 };
 typedef hipcub::CountingInputIterator<uint32_t> CountIt;
 typedef hipcub::TransformInputIterator<uint32_t, SegOf, CountIt> SegKeyIt;
 typedef hipcub::TransformInputIterator<uint64_t, SubKeyBatch, CountIt> SubKeyIt;
 typedef hipcub::TransformInputIterator<uint64_t, BlkKeyBatch, CountIt> BlkKeyIt;
-typedef hipcub::TransformInputIterator<int, DcPickBatch, CountIt> DcPickIt;
+typedef hipcub::TransformInputIterator<Dc3, DcPickBatch, CountIt> DcPickIt;
 
 __global__ void __launch_bounds__(256) k_jd_zero_multi(const DecBatchJob* jobs) {
   const DecBatchJob& b = jobs[blockIdx.y];
@@ -670,8 +680,7 @@ __global__ void __launch_bounds__(256) k_jd_sync_multi(const DecBatchJob* jobs, 
   sync_rounds_body(b.j, b.tables, b.st[parity], b.st[parity ^ 1], b.dirty[parity], b.dirty[parity ^ 1], b.nblocks, ring + (round & 63u));
 }
 __global__ void __launch_bounds__(256) k_jd_write_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; write_body(b.j, b.tables, b.st[0], b.first_block, b.flags + 1); }
-__global__ void __launch_bounds__(256) k_jd_dc_apply_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; dc_apply_body(b.j, b.dc[0], b.dc[1], b.dc[2]); }
-__global__ void __launch_bounds__(128) k_jd_idct_multi(const DecBatchJob* jobs) { idct_body(jobs[blockIdx.y].j); }
+__global__ void __launch_bounds__(128) k_jd_idct_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; idct_body(b.j, b.dc); }
 
 size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -688,8 +697,8 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
   size_t o = 0;
   l->src = o; o += up(nbytes + 16);
   l->raw = o; o += up(nbytes + 64);
-  l->lut = o; o += up((size_t)(4u << kFastBits) * 2);   // the first-level tables
-  l->adv = o; o += up((size_t)(4u << kFastBits) * 2);
+  l->lut = o; o += up((size_t)(4u << kFastBits) * 4);   // the first-level tables
+  l->adv = o; o += up((size_t)(4u << kFastBits) * 4);
   l->st_a = o; o += up((size_t)l->nsub_max * sizeof(DState));
   l->st_b = o; o += up((size_t)l->nsub_max * sizeof(DState));
   l->dirty_a = o; o += up((size_t)l->nsub_max + 2);
@@ -706,7 +715,7 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
 
 // where the batch-level arrays sit inside the scratch buffer
 struct BatchLayout {
-  size_t jobs, flags, offs, kept, kept_off, nblocks, first_block, dc[3], tmp, tmp_bytes, total;
+  size_t jobs, flags, offs, kept, kept_off, nblocks, first_block, dc, tmp, tmp_bytes, total;
   uint32_t n_kept, n_sub, n_blk;
 };
 static BatchLayout batch_layout(int n, const DecLayout l[]) {
@@ -722,14 +731,14 @@ static BatchLayout batch_layout(int n, const DecLayout l[]) {
   B.kept_off = o; o += up((size_t)B.n_kept * 4);
   B.nblocks = o; o += up((size_t)B.n_sub * 4);
   B.first_block = o; o += up((size_t)B.n_sub * 4);
-  for (int c = 0; c < 3; ++c) { B.dc[c] = o; o += up((size_t)B.n_blk * 4 + 4); }
+  B.dc = o; o += up((size_t)B.n_blk * sizeof(Dc3) + 16);
   size_t t1 = 0, t2 = 0, t3 = 0;
   const SegOf seg{nullptr, n};
   CountIt cnt(0u);
   (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t1, SegKeyIt(cnt, seg), (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)B.n_kept);
   (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t2, SubKeyIt(cnt, SubKeyBatch{nullptr, seg}), (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)B.n_sub);
-  (void)hipcub::DeviceScan::InclusiveSumByKey(nullptr, t3, BlkKeyIt(cnt, BlkKeyBatch{nullptr, seg}), DcPickIt(cnt, DcPickBatch{nullptr, seg, 0}), (int*)nullptr,
-                                              (int)(B.n_blk ? B.n_blk : 1u));
+  (void)hipcub::DeviceScan::InclusiveScanByKey(nullptr, t3, BlkKeyIt(cnt, BlkKeyBatch{nullptr, seg}), DcPickIt(cnt, DcPickBatch{nullptr, seg}), (Dc3*)nullptr,
+                                               Dc3Sum(), (int)(B.n_blk ? B.n_blk : 1u));
   B.tmp_bytes = up(std::max(t1, std::max(t2, t3)) + 256);
   B.tmp = o; o += B.tmp_bytes;
   B.total = o;
@@ -770,7 +779,7 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   const size_t noffs = (size_t)3 * (n + 1);
   uint32_t* koff = offs; uint32_t* soff = koff + (n + 1); uint32_t* boff = soff + (n + 1);
   koff[0] = soff[0] = boff[0] = 0u;
-  uint32_t gu = 1, gsync = 1, gblk = 1, gidct = 1;
+  uint32_t gu = 1, gsync = 1, gidct = 1;
   for (int k = 0; k < n; ++k) {
     DecBatchJob& b = jobs[k];
     memset(&b, 0, sizeof(b));
@@ -781,13 +790,13 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     // the arrays the prefix sums run over are slices of batch-level concatenations (one segmented scan for all images)
     b.kept = reinterpret_cast<uint32_t*>(batch_ws + B.kept) + koff[k]; b.kept_off = reinterpret_cast<const uint32_t*>(batch_ws + B.kept_off) + koff[k];
     b.raw_out = w + L.raw;
-    b.tables = in.tables; b.lut_out = reinterpret_cast<uint16_t*>(w + L.lut); b.adv_out = reinterpret_cast<uint16_t*>(w + L.adv);
+    b.tables = in.tables; b.lut_out = reinterpret_cast<uint32_t*>(w + L.lut); b.adv_out = reinterpret_cast<uint32_t*>(w + L.adv);
     b.st[0] = reinterpret_cast<DState*>(w + L.st_a); b.st[1] = reinterpret_cast<DState*>(w + L.st_b);
     b.dirty[0] = w + L.dirty_a; b.dirty[1] = w + L.dirty_b;
     b.nblocks = reinterpret_cast<uint32_t*>(batch_ws + B.nblocks) + soff[k];
     b.flags = dflags + kFlagWords * (uint32_t)k;
     b.first_block = reinterpret_cast<const uint32_t*>(batch_ws + B.first_block) + soff[k];
-    for (int c = 0; c < 3; ++c) b.dc[c] = reinterpret_cast<const int*>(batch_ws + B.dc[c]) + boff[k];
+    b.dc = reinterpret_cast<const Dc3*>(batch_ws + B.dc) + boff[k];
     DecJob& j = b.j;
     j.raw = reinterpret_cast<const uint32_t*>(w + L.raw);
     j.lut = b.lut_out; j.adv = b.adv_out;
@@ -828,7 +837,6 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     boff[k + 1] = boff[k] + j.nblk;
     gu = std::max(gu, (L.nchunks + 255u) / 256u);
     gsync = std::max(gsync, (j.nsub + 255u) / 256u);
-    gblk = std::max(gblk, (j.nblk + 255u) / 256u);
     gidct = std::max(gidct, (j.nblk + 127u) / 128u);
   }
   JD_TRY(hipMemcpyAsync(djobs, jobs, (size_t)n * sizeof(DecBatchJob), hipMemcpyHostToDevice, s));
@@ -875,14 +883,11 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
                                                  reinterpret_cast<uint32_t*>(batch_ws + B.first_block), (int)soff[n], hipcub::Equality(), s));
   }
   hipLaunchKernelGGL(k_jd_write_multi, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs);
-  bool colour = false;
-  for (int k = 0; k < n; ++k) colour = colour || (!bad[k] && !jobs[k].j.gray);
-  for (int c = 0; c < (colour ? 3 : 1) && boff[n]; ++c) {   // DC differences -> DC values: per component, image and restart interval
+  if (boff[n]) {   // DC differences -> DC values: per component, image and restart interval
     size_t tmp = B.tmp_bytes;
-    JD_TRY(hipcub::DeviceScan::InclusiveSumByKey(stmp, tmp, BlkKeyIt(cnt0, BlkKeyBatch{djobs, bseg}), DcPickIt(cnt0, DcPickBatch{djobs, bseg, c}),
-                                                 reinterpret_cast<int*>(batch_ws + B.dc[c]), (int)boff[n], hipcub::Equality(), s));
+    JD_TRY(hipcub::DeviceScan::InclusiveScanByKey(stmp, tmp, BlkKeyIt(cnt0, BlkKeyBatch{djobs, bseg}), DcPickIt(cnt0, DcPickBatch{djobs, bseg}),
+                                                  reinterpret_cast<Dc3*>(batch_ws + B.dc), Dc3Sum(), (int)boff[n], hipcub::Equality(), s));
   }
-  hipLaunchKernelGGL(k_jd_dc_apply_multi, dim3(gblk, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_idct_multi, dim3(gidct, ny), dim3(128), 0, s, (const DecBatchJob*)djobs);
   JD_LAP("tail enqueued");
   JD_TRY(hipMemcpyAsync(flags.data(), dflags, flags.size() * 4, hipMemcpyDeviceToHost, s));

@@ -8,8 +8,9 @@
 // A baseline scan without restart markers is ONE bit string: where a code starts is only known once everything before
 // it has been decoded.  The decoder uses the self-synchronisation of Huffman codes (Klein & Wiseman 2003; Weissenberger &
 // Schmidt 2018): a decoder started at a wrong bit position falls in step with the true decoder after a few symbols.
-//   k_jd_unstuff_*_multi   drop the 0x00 after every 0xFF (count per 64-byte chunk, scan, compact) -> raw bit string
-//   k_jd_build_lut_multi   first-level lookup tables (the next 11 bits -> what the symbol implies) of the file's own Huffman tables
+//   k_jd_prepare_multi     per 64-byte chunk, the bytes that stay once the 0x00 after every 0xFF is dropped; first-level lookup tables (the
+//                    next 11 bits -> what the symbol implies) of the file's own Huffman tables; cleared flags and coefficients
+//   (scan) k_jd_unstuff_copy_multi   compact -> raw bit string
 //   k_jd_sync_multi<0>     every thread decodes one 512-bit subsequence from a guessed state (block 0, coefficient 0) and
 //                    records the state (bit, block-in-MCU, coefficient) it crosses the subsequence's end with
 //   k_jd_sync_multi<1>     rounds: thread i re-decodes subsequence i from the end state of i-1 (only if that state changed);
@@ -155,8 +156,8 @@ __device__ __forceinline__ uint32_t short_code(const HuffSpec& h, uint32_t x, ui
   }
   return 0u;
 }
-__device__ __forceinline__ void build_lut_body(const DecTables& t, uint32_t* lut, uint32_t* adv) {
-  const uint32_t g = blockIdx.x * 256u + threadIdx.x;   // 4 tables x 2^kFastBits
+__device__ __forceinline__ void build_lut_body(const DecTables& t, uint32_t* lut, uint32_t* adv, uint32_t block) {
+  const uint32_t g = block * 256u + threadIdx.x;   // 4 tables x 2^kFastBits
   if (g >= (4u << kFastBitsEarly)) return;
   const uint32_t tb = g >> kFastBitsEarly, x = g & ((1u << kFastBitsEarly) - 1u);
   const HuffSpec& h = t.huff[tb];
@@ -611,7 +612,7 @@ struct DecBatchJob {
   DecTables tables; uint32_t* lut_out; uint32_t* adv_out;
   DState* st[2]; uint8_t* dirty[2]; uint32_t* nblocks; uint32_t* flags;
   const uint32_t* first_block; const Dc3* dc;
-  uint8_t* zero[3]; uint32_t zero_words[3];            // ranges k_jd_zero_multi clears (16-byte multiples)
+  uint8_t* zero[3]; uint32_t zero_words[3];            // ranges k_jd_prepare_multi clears (16-byte multiples)
 };
 struct SubKeyBatch {   // (image, restart interval) of subsequence g of the concatenated nblocks arrays
   const DecBatchJob* jobs;
@@ -648,23 +649,29 @@ typedef hipcub::TransformInputIterator<uint64_t, SubKeyBatch, CountIt> SubKeyIt;
 typedef hipcub::TransformInputIterator<uint64_t, BlkKeyBatch, CountIt> BlkKeyIt;
 typedef hipcub::TransformInputIterator<Dc3, DcPickBatch, CountIt> DcPickIt;
 
-__global__ void __launch_bounds__(256) k_jd_zero_multi(const DecBatchJob* jobs) {
+// What depends on nothing but the uploaded jobs, in one launch (a launch and the gap behind it cost more than any of the three):
+// workgroups [0, gu) count the bytes each 64-byte chunk of the stuffed segment keeps, the next kLutBlocks build the first-level
+// tables, the last kZeroBlocks clear the flags, the buffer of the bit string and the coefficients.
+constexpr uint32_t kLutBlocks = (4u << kFastBits) / 256u, kZeroBlocks = 512u;
+__global__ void __launch_bounds__(256) k_jd_prepare_multi(const DecBatchJob* jobs, uint32_t gu) {
   const DecBatchJob& b = jobs[blockIdx.y];
+  if (blockIdx.x < gu) {
+    if (b.src_bytes == 0u) return;   // an image that failed on the host: it owns no slice of the batch arrays
+    if (blockIdx.x == 0u && threadIdx.x == 0u) b.kept[(b.src_bytes + kUnstuffChunk - 1u) / kUnstuffChunk] = 0u;   // the scan's last input
+    unstuff_count_body(b.src, b.src_bytes, b.kept, b.rst);
+  } else if (blockIdx.x < gu + kLutBlocks) {
+    build_lut_body(b.tables, b.lut_out, b.adv_out, blockIdx.x - gu);
+  } else {
+    const uint32_t first = (blockIdx.x - gu - kLutBlocks) * 256u + threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    uint4* p = reinterpret_cast<uint4*>(b.zero[k]);
-    const uint32_t n16 = b.zero_words[k];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = 0; k < 3; ++k) {
+      uint4* p = reinterpret_cast<uint4*>(b.zero[k]);
+      const uint32_t n16 = b.zero_words[k];
+      for (uint32_t i = first; i < n16; i += kZeroBlocks * 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
-__global__ void __launch_bounds__(256) k_jd_unstuff_count_multi(const DecBatchJob* jobs) {
-  const DecBatchJob& b = jobs[blockIdx.y];
-  if (b.src_bytes == 0u) return;   // an image that failed on the host: it owns no slice of the batch arrays
-  if (blockIdx.x == 0u && threadIdx.x == 0u) b.kept[(b.src_bytes + kUnstuffChunk - 1u) / kUnstuffChunk] = 0u;   // the scan's last input
-  unstuff_count_body(b.src, b.src_bytes, b.kept, b.rst);
-}
 __global__ void __launch_bounds__(256) k_jd_unstuff_copy_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; unstuff_copy_body(b.src, b.src_bytes, b.kept_off, b.raw_out, b.rst); }
-__global__ void __launch_bounds__(256) k_jd_build_lut_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; build_lut_body(b.tables, b.lut_out, b.adv_out); }
 // parity: which of the two state / dirty buffers is read (the other one is written).  round: number of the launch, 1, 2, ... --
 // words 64..127 of an image's flags are a ring of "launch r changed an end state".  A launch that follows one without a change has
 // nothing to do (both state buffers are equal by then) and returns at once, image by image: the host enqueues launches without
@@ -849,15 +856,13 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   keep.clear();
   const dim3 b256(256);
   const unsigned ny = (unsigned)n;
-  hipLaunchKernelGGL(k_jd_zero_multi, dim3(512, ny), b256, 0, s, (const DecBatchJob*)djobs);
-  hipLaunchKernelGGL(k_jd_unstuff_count_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
+  hipLaunchKernelGGL(k_jd_prepare_multi, dim3(gu + kLutBlocks + kZeroBlocks, ny), b256, 0, s, (const DecBatchJob*)djobs, gu);
   if (koff[n]) {
     size_t tmp = B.tmp_bytes;
     JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(stmp, tmp, SegKeyIt(cnt0, kseg), reinterpret_cast<const uint32_t*>(batch_ws + B.kept),
                                                  reinterpret_cast<uint32_t*>(batch_ws + B.kept_off), (int)koff[n], hipcub::Equality(), s));
   }
   hipLaunchKernelGGL(k_jd_unstuff_copy_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
-  hipLaunchKernelGGL(k_jd_build_lut_multi, dim3((4u << kFastBits) / 256u, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_sync_multi<0>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, 0u);
   JD_LAP("enqueued through sync<0>");
   std::vector<uint32_t> flags((size_t)n * kFlagWords, 0u);

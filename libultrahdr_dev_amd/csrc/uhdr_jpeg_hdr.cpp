@@ -6,6 +6,10 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+#define UHDR_JD_HAVE_AVX2_WALK 1
+#endif
 
 #include "uhdr_jpeg.h"
 
@@ -19,7 +23,48 @@ static unsigned rd16(const uint8_t* p) { return ((unsigned)p[0] << 8) | p[1]; }
 // (mispredicted: the positions are random) costs more than the search, so 16 bytes at a time are classified without one and the
 // zeros counted in byte lanes; only a real marker (RSTn, or the one that ends the segment) leaves the loop.  Returns the position of
 // the next marker's 0xFF at or behind `e`, or of the first byte the loop did not look at, with `stuffed` advanced up to there.
+#if defined(UHDR_JD_HAVE_AVX2_WALK)
+// the same walk, 32 bytes at a time, where the processor has AVX2 (decided at run time)
+__attribute__((target("avx2"))) static size_t skip_to_marker_avx2(const uint8_t* p, size_t e, size_t n, uint32_t* stuffed) {
+  const __m256i ff = _mm256_set1_epi8((char)0xFF), zero = _mm256_setzero_si256();
+  __m256i acc = zero;
+  unsigned pending = 0;
+  auto flush = [&]() __attribute__((target("avx2"))) {
+    const __m256i sad = _mm256_sad_epu8(acc, zero);
+    const __m128i lo = _mm256_castsi256_si128(sad), hi = _mm256_extracti128_si256(sad, 1);
+    const __m128i sum = _mm_add_epi64(lo, hi);
+    *stuffed += (uint32_t)_mm_cvtsi128_si32(sum) + (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(sum, 8));
+    acc = zero;
+    pending = 0;
+  };
+  while (e + 33 <= n) {
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + e));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + e + 1));
+    const __m256i is_ff = _mm256_cmpeq_epi8(a, ff);
+    const __m256i z = _mm256_cmpeq_epi8(b, zero);
+    const __m256i st = _mm256_and_si256(is_ff, z);
+    const unsigned mk = (unsigned)_mm256_movemask_epi8(_mm256_andnot_si256(_mm256_or_si256(z, _mm256_cmpeq_epi8(b, ff)), is_ff));
+    if (mk != 0u) {
+      const unsigned m = (unsigned)__builtin_ctz(mk);
+      flush();
+      *stuffed += (uint32_t)__builtin_popcount((unsigned)_mm256_movemask_epi8(st) & (uint32_t)((1ull << m) - 1ull));
+      return e + m;
+    }
+    acc = _mm256_sub_epi8(acc, st);   // a set lane is 0xFF = -1
+    if (++pending == 255u) flush();
+    e += 32;
+  }
+  flush();
+  return e;
+}
+#endif
+
 static size_t skip_to_marker(const uint8_t* p, size_t e, size_t n, uint32_t* stuffed) {
+#if defined(UHDR_JD_HAVE_AVX2_WALK)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) e = skip_to_marker_avx2(p, e, n, stuffed);
+  if (e + 1 < n && p[e] == 0xFF && p[e + 1] != 0x00 && p[e + 1] != 0xFF) return e;   // at a marker
+#endif
 #if defined(__SSE2__)
   const __m128i ff = _mm_set1_epi8((char)0xFF), zero = _mm_setzero_si128();
   __m128i acc = zero;

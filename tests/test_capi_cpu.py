@@ -168,3 +168,32 @@ def test_graft_entry_build_runs():
         sys.path.insert(0, root)
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_jpeg_header_refuses_a_huffman_table_that_is_no_prefix_code(api, orc):
+    """parse_header sees the untrusted file before the device does (no GPU needed to refuse it): a DHT whose counts put more codes
+    on a length than its bits hold is JERR_BAD_HUFF_TABLE in libjpeg (jdhuff.c, jpeg_make_d_derived_tbl) and UNKNOWN_ERROR here --
+    the canonical long-code lookup of the device decoder relies on the tables being prefix codes"""
+    lib = api.load()
+    rng = np.random.default_rng(5)
+    w, h = 64, 48
+    y = rng.integers(0, 256, w * h, dtype=np.uint8)
+    uv = rng.integers(0, 256, w * h // 2, dtype=np.uint8)
+    good = bytearray(orc.jpeg_encode("orc", y, uv, w, h, 90))
+    out = np.zeros(w * h * 3 // 2, np.uint8)
+    desc = api.Image()
+
+    def decode(data):
+        buf = np.frombuffer(bytes(data), np.uint8)
+        return lib.uhdr_hip_jpeg_decode(C.c_void_p(buf.ctypes.data), buf.size, C.c_void_p(out.ctypes.data), out.size, C.byref(desc), api.MEM_HOST, None)
+
+    assert orc.jpeg_decode("lj", bytes(good))[0] > 0
+    at = bytes(good).index(b"\xff\xc4")      # first DHT: marker, length, Tc/Th, 16 counts, symbols
+    counts = at + 5
+    bad = bytearray(good)
+    donor = max(range(16), key=lambda k: bad[counts + k])
+    assert bad[counts + donor] >= 3 and donor != 0
+    bad[counts + donor] -= 3                 # same number of symbols (the segment stays well-formed) ...
+    bad[counts + 0] += 3                     # ... but three 1-bit codes
+    assert orc.jpeg_decode("lj", bytes(bad))[0] < 0, "libjpeg accepts the table"
+    assert decode(bad) == api.UNKNOWN_ERROR

@@ -188,9 +188,9 @@ struct DState { uint32_t p; uint32_t cz; };   // bit position; (block-in-MCU << 
 
 // A symbol costs two dependent memory reads (stream bits, then the code table); from L2 that is ~1000 cycles per symbol, and a
 // wave waits for the slowest of its lanes at every symbol (one s_waitcnt covers all outstanding loads).  So nothing in the
-// symbol loop touches global memory but the rare code longer than kFastBits: a workgroup first copies the stretch of the bit
-// string its 256 subsequences cover into LDS (stage_bits), the bit window lives in registers (64 bits, refilled one word at a
-// time from there), and the first kFastBits bits of every code are looked up in LDS.
+// symbol loop touches global memory: a workgroup first copies the stretch of the bit string its 256 subsequences cover into LDS
+// (stage_bits), the bit window lives in registers (64 bits, refilled one word at a time from there), the first kFastBits bits of
+// every code are looked up in LDS, and so are the longer codes (LongCodes).
 constexpr uint32_t kFastBits = kFastBitsEarly;
 // The codes of more than kFastBits bits, in canonical form (T.81 Annex C): a code of length l is the l-bit number in
 // [first_code[l], first_code[l] + count[l]); with lim[l] = that upper bound shifted to 16 bits, the lengths' ranges follow one another,
@@ -210,8 +210,7 @@ __device__ __forceinline__ void load_long_codes(const DecTables& t, LongCodes& l
     lc.lim[tb][k] = h.present ? ((uint32_t)h.first_code[l] + (uint32_t)h.count[l]) << (16u - l) : 0u;
     lc.off[tb][k] = (int32_t)h.first_val[l] - (int32_t)h.first_code[l];
   }
-  for (uint32_t q = g; q < 4u * 64u; q += blockDim.x)
-    reinterpret_cast<uint32_t*>(&lc.vals[0][0])[q] = reinterpret_cast<const uint32_t*>(t.huff[q >> 6].vals)[q & 63u];
+  for (uint32_t q = g; q < 4u * 256u; q += blockDim.x) lc.vals[q >> 8][q & 255u] = t.huff[q >> 8].vals[q & 255u];
 }
 // (length << 8) | symbol of the code of more than kFastBits bits in front of `peek`, 0 if there is none
 __device__ __forceinline__ uint32_t long_code(const LongCodes& lc, uint32_t tb, uint32_t peek) {

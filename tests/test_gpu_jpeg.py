@@ -265,3 +265,17 @@ def test_decoder_survives_corrupted_files(hip, orc):
         assert rc == 0 and np.array_equal(got, orc.jpeg_decode("orc", good)[1])
     print("corrupted-file outcomes by status:", outcomes)
     assert outcomes.get(0, 0) > 0 and outcomes.get(hip.UNKNOWN_ERROR, 0) > 0
+
+
+def test_random_files_decode_like_libjpeg(hip, orc, tmp_path):
+    """400 random files (oracle encoder and Pillow / libjpeg-turbo: standard and optimised tables, restart intervals from one MCU to
+    thousands, 2x2 to 2400x1400, qualities 1-100, noise / smooth / flat content, colour and single-plane): the device decoder's
+    planes equal libjpeg's in device and in host memory.  `python tests/stress_jpeg_dec.py 20000 11` is the long form of this test
+    (40 000 identical decodes on an MI355X after the decoder's synchronisation passes were rewritten)."""
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        pytest.skip("Pillow not usable here")
+    from tests import stress_jpeg_dec
+    decoded, mismatches = stress_jpeg_dec.run(400, 3, dump_dir=str(tmp_path))
+    assert mismatches == 0 and decoded == 800

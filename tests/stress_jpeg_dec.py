@@ -1,6 +1,6 @@
 """GPU: randomized hunt for device-decoder bugs.  Files from the oracle encoder and from Pillow / libjpeg-turbo (optimised tables,
 restart intervals of every size) over random sizes, qualities and content; every one decoded on the device (device and host output)
-and by the image's libjpeg through the oracle's harness: the planes must be identical.  usage: python tests/stress_jpeg_dec.py [cases] [seed]; tests/test_gpu_jpeg.py runs 400 cases"""
+and by the image's libjpeg through the oracle's harness: the planes must be identical.  usage: python tests/stress_jpeg_dec.py [cases] [seed] [damage]; tests/test_gpu_jpeg.py runs 400 cases"""
 import ctypes as C
 import io, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +10,9 @@ from PIL import Image
 from libultrahdr_dev_amd import api
 from oracle import oracle as orc
 
-def run(cases, seed, dump_dir="gpurun_out"):
-    """-> (identical decodes, mismatches)"""
+def run(cases, seed, dump_dir="gpurun_out", damage=False):
+    """-> (identical decodes, mismatches); damage: every file also with bytes of its scan flipped, cut or doubled -- those must
+    come back with a status (their planes are not compared: libjpeg conceals what it can, this decoder refuses)"""
     lib = api.init(0)
     rng = np.random.RandomState(seed)
 
@@ -86,6 +87,21 @@ def run(cases, seed, dump_dir="gpurun_out"):
             im.save(b, "JPEG", **kw)
             data = b.getvalue()
             tag = "pil %s" % kw
+        if damage:
+            d = bytearray(data)
+            sos = d.find(b"\xff\xda")
+            for _ in range(rng.randint(1, 6)):
+                at = rng.randint(sos + 12, max(sos + 13, len(d) - 2))
+                k = rng.randint(0, 4)
+                if k == 0: d[at] = rng.randint(0, 256)
+                elif k == 1: d[at] = 0xFF
+                elif k == 2: del d[at:at + rng.randint(1, 40)]
+                else: d[at:at] = bytes(rng.randint(0, 256, rng.randint(1, 9)).astype(np.uint8))
+            for device in (True, False):
+                rc, got = gpu_decode(bytes(d), device)
+                if rc not in (0, api.UNKNOWN_ERROR, api.ERROR_UNSUPPORTED_FEATURE, api.ERROR_RESOLUTION_MISMATCH):
+                    bad += 1
+                    print("DAMAGED case %d: rc %d" % (it, rc), flush=True)
         st, want, dw, dh, g = orc.jpeg_decode("lj", data)
         for device in (True, False):
             rc, got = gpu_decode(data, device)
@@ -104,5 +120,5 @@ def run(cases, seed, dump_dir="gpurun_out"):
 
 
 if __name__ == "__main__":
-    _, mismatches = run(int(sys.argv[1]) if len(sys.argv) > 1 else 500, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    _, mismatches = run(int(sys.argv[1]) if len(sys.argv) > 1 else 500, int(sys.argv[2]) if len(sys.argv) > 2 else 1, damage="damage" in sys.argv[3:])
     sys.exit(1 if mismatches else 0)

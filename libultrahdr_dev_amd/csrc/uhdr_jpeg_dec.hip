@@ -129,10 +129,12 @@ constexpr uint32_t kFastBitsEarly = UHDR_JD_FASTBITS;   // == kFastBits (first-l
 // First-level tables, indexed by the next kFastBits bits of the stream; a workgroup that decodes copies them into LDS.
 // lut[x]: the 32-bit entry of the final pass (coef_entry), 0 when no code of at most kFastBits bits matches.
 // adv[x]: what the position-only passes need from a symbol, in 16 bits: bits 8..13 = bits consumed (code + value bits, <= 27),
-// bits 0..6 = advance of the coefficient index (DC: 1; AC: run + 1, ZRL 16, EOB 64); 0x8000 when no such code matches.  The
-// upper 16 bits: the same for this symbol and the next one together, where both lie inside the pattern (0: no pair).
+// bits 0..6 = advance of the coefficient index (DC: 1; AC: run + 1, ZRL 16, EOB 64); kLongEntry when no such code matches.  The
+// upper 16 bits: the same for this symbol and the next one together, where both lie inside the pattern (0: no pair; their
+// top bit is never set: at most 32 bits per pair).
 // Longer codes (and "no code at all") are resolved from the canonical form of the table, also in LDS (LongCodes): a decoding loop
 // must not load from memory -- a wave waits for all its outstanding vector memory operations at once, coefficient stores included.
+constexpr uint32_t kLongEntry = 0x80000000u;   // first-level entry of the position-only tables: look among the longer codes
 __device__ __forceinline__ uint32_t adv_entry(uint32_t tb, uint32_t len, uint32_t sym) {
   const uint32_t vb = sym & 15u, r = sym >> 4;
   const uint32_t dz = (tb & 1u) == 0u ? 1u : (vb != 0u ? r + 1u : (r == 15u ? 16u : 64u));
@@ -163,11 +165,11 @@ __device__ __forceinline__ void build_lut_body(const DecTables& t, uint32_t* lut
   const HuffSpec& h = t.huff[tb];
   const uint32_t e = h.present ? short_code(h, x, kFastBitsEarly) : 0u;
   lut[g] = e != 0u ? coef_entry(tb, e >> 8, e & 0xFFu) : 0u;
-  uint32_t a = 0x8000u;
+  uint32_t a = kLongEntry;
   if (e != 0u) {
     a = adv_entry(tb, e >> 8, e & 0xFFu);
     // An AC symbol that does not end the block is followed by another code of the same table: when that one lies inside the
-    // pattern too, the upper half of the entry is the pair (bits and index advance of both); step_pos takes it when the first
+    // pattern too, the upper half of the entry is the pair (bits and index advance of both); decode_positions takes it when the first
     // symbol neither fills the block nor crosses the subsequence's end.  Two symbols per table lookup where the codes are short.
     const uint32_t bits1 = (a >> 8) & 31u, dz1 = a & 127u;
     if ((tb & 1u) != 0u && dz1 < 64u && bits1 < kFastBitsEarly) {
@@ -281,33 +283,6 @@ __device__ __forceinline__ bool step_coef(const bool gray, const LongCodes& lc, 
   return ok;
 }
 
-// The position-only walk of the synchronisation passes: one symbol -- or two, when the table entry holds a pair and the first one
-// neither completes the block nor crosses the subsequence's end (the state a subsequence ends with is the one behind the first
-// symbol that crosses it).  No branches but the rare long-code lookup and the window refill.
-__device__ __forceinline__ void step_pos(const bool gray, const LongCodes& lc, const uint32_t (*s_adv)[1u << kFastBits], Reader& rd, DState& s,
-                                         const uint32_t end, uint32_t& blocks) {
-  const uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
-  const uint32_t tb = (gray ? 0u : (c >= 4u ? 2u : 0u)) + (z != 0u ? 1u : 0u);
-  const uint32_t sh = s.p - rd.base;
-  const uint32_t peek = (uint32_t)(rd.win >> (48u - sh)) & 0xFFFFu;
-  uint32_t a = s_adv[tb][peek >> (16u - kFastBits)];
-  if (a & 0x8000u) {
-    const uint32_t e = long_code(lc, tb, peek);
-    a = e != 0u ? adv_entry(tb, e >> 8, e & 0xFFu) : 0x0100u;   // no code: one bit consumed, index unchanged
-  }
-  const uint32_t pair = a >> 16;
-  const bool both = pair != 0u && z + (a & 127u) < 64u && s.p + ((a >> 8) & 63u) < end;
-  a = both ? pair : a;
-  s.p += (a >> 8) & 63u;     // (at most 32 bits: build_lut_body)
-  rd.advance_to(s.p);
-  uint32_t nz = z + (a & 127u);
-  const bool done = nz >= 64u;
-  nz = done ? 0u : nz;
-  const uint32_t bpm = gray ? 1u : 6u;
-  const uint32_t nc = done ? (c + 1u == bpm ? 0u : c + 1u) : c;
-  blocks += done ? 1u : 0u;
-  s.cz = (nc << 8) | nz;
-}
 // workgroup prologue: one of the two first-level tables -> LDS (16 bytes per lane and turn; ends with a barrier)
 template <typename T>
 __device__ __forceinline__ void load_fast_table(const T* table, T (*s_tab)[1u << kFastBits]) {
@@ -350,16 +325,55 @@ __device__ __forceinline__ uint32_t stage_bits(const DecJob& j, uint32_t i0, uin
 // One position-only decode of subsequence i from state s until its end is crossed; nb: blocks completed on the way.
 // (A corrupt state cannot come out of the rounds -- positions only grow, by at most one symbol past an end -- but a read outside
 // the staged words must be impossible, not unlikely: such a state decodes nothing and keeps its value.)
+// A step takes one symbol -- or two, when the table entry holds a pair and the first symbol neither completes the block nor crosses
+// the subsequence's end (the state a subsequence ends with is the one behind the first symbol that crosses it).  The loop is the
+// decoder's latency (one lane, one wave per SIMD: every instruction is waited for), so its state is kept in the form the next
+// step needs: bits left to the end instead of a position, the shift that brings the next 16 bits of the window down instead of
+// the window's base, block-in-MCU and coefficient index apart, the LDS address of the next word.  No branches but the rare
+// long-code lookup and the window refill.
 __device__ __forceinline__ void decode_positions(const DecJob& j, const LongCodes& lc, const uint32_t (*s_adv)[1u << kFastBits], const uint32_t* s_bits,
                                                  uint32_t w0, uint32_t i, DState& s, uint32_t& nb) {
   const uint32_t end = sub_end_bit(j, i);
   const bool gray = j.gray != 0;
   nb = 0;
-  if ((s.p >> 5) >= w0 && (s.p >> 5) - w0 + 3u < kStageWords && end > s.p && end - s.p <= kSubBits + 32u) {
-    Reader rd;
-    rd.init(s_bits, w0, s.p);
-    while (s.p < end) step_pos(gray, lc, s_adv, rd, s, end, nb);
-  }
+  if (!((s.p >> 5) >= w0 && (s.p >> 5) - w0 + 3u < kStageWords && end > s.p && end - s.p <= kSubBits + 32u)) return;
+  const uint32_t* next_word = s_bits + ((s.p >> 5) - w0);
+  uint64_t win = ((uint64_t)__builtin_bswap32(next_word[0]) << 32) | (uint64_t)__builtin_bswap32(next_word[1]);   // bits [base, base + 64), MSB first
+  uint32_t nextw = next_word[2];                       // bits [base + 64, base + 96), still in memory byte order
+  next_word += 3;
+  int32_t down = 48 - (int32_t)(s.p & 31u);            // win >> down: the next 16 bits of the stream in bits 15..0; 17 <= down <= 48
+  int32_t left = (int32_t)(end - s.p);                 // > 0 while the subsequence's end has not been crossed
+  uint32_t c = s.cz >> 8, z = s.cz & 0xFFu;
+  const uint32_t bpm = gray ? 1u : 6u, chroma_at = gray ? 0xFFu : 4u;
+  const char* tables = reinterpret_cast<const char*>(&s_adv[0][0]);
+  do {
+    const uint32_t tb = (c >= chroma_at ? 2u : 0u) + (z != 0u ? 1u : 0u);
+    const uint32_t x = (uint32_t)(win >> (uint32_t)down);
+    uint32_t a = *reinterpret_cast<const uint32_t*>(tables + ((tb << (kFastBits + 2u)) | ((x >> (14u - kFastBits)) & ((1u << (kFastBits + 2u)) - 4u))));
+    if ((int32_t)a < 0) {                              // kLongEntry: no code of at most kFastBits bits
+      const uint32_t e = long_code(lc, tb, x & 0xFFFFu);
+      a = e != 0u ? adv_entry(tb, e >> 8, e & 0xFFu) : 0x0100u;   // no code: one bit consumed, index unchanged
+    }
+    const uint32_t pair = a >> 16;
+    const bool both = pair != 0u && z + (a & 127u) < 64u && (int32_t)((a >> 8) & 63u) < left;
+    a = both ? pair : a;
+    const uint32_t bits = (a >> 8) & 63u;              // (at most 32: build_lut_body)
+    left -= (int32_t)bits;
+    down -= (int32_t)bits;
+    if (down < 17) {                                  // the window's first word is used up
+      win = (win << 32) | (uint64_t)__builtin_bswap32(nextw);
+      down += 32;
+      nextw = *next_word++;
+    }
+    z += a & 127u;
+    const bool done = z >= 64u;
+    z = done ? 0u : z;
+    const uint32_t cn = c + 1u == bpm ? 0u : c + 1u;
+    c = done ? cn : c;
+    nb += done ? 1u : 0u;
+  } while (left > 0);
+  s.p = end - (uint32_t)left;
+  s.cz = (c << 8) | z;
 }
 
 // The first pass: every subsequence from the guess (its own start, block 0, coefficient 0; the true state for the first one of the

@@ -422,8 +422,10 @@ __device__ __forceinline__ void sync_first_body(const DecJob& j, const DecTables
 #endif
 constexpr uint32_t kLocalRounds = UHDR_JD_LOCAL_ROUNDS;
 // launches the host enqueues before it looks at the ring: a quality-75 4K file needs 5-8 rounds, a quality-95 one 21-24
-constexpr uint32_t kFirstLaunches = 2u * ((8u + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
-constexpr uint32_t kMoreLaunches = 2u * ((16u + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
+// (counted in rounds of 512-bit subsequences; shorter subsequences need proportionally more)
+constexpr uint32_t kRoundScale = 512u / kSubBits > 0u ? 512u / kSubBits : 1u;
+constexpr uint32_t kFirstLaunches = 2u * ((8u * kRoundScale + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
+constexpr uint32_t kMoreLaunches = 2u * ((16u * kRoundScale + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
 __device__ __forceinline__ void sync_rounds_body(const DecJob& j, const DecTables& tables, const DState* prev, DState* next, const uint8_t* dirty_in,
                                                  uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {
   __shared__ __attribute__((aligned(16))) uint32_t s_adv[4][1u << kFastBits];

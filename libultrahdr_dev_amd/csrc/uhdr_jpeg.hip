@@ -5,9 +5,9 @@
 // jpegr.cpp:294-297) -> the byte stream libjpeg writes in raw-data mode with default tables, quality scaling with
 // force_baseline and the ISLOW DCT.  The whole encoder runs on the device; the host only builds the ~600-byte header:
 //
-//   k_jpeg_fdct_quant   one thread per 8x8 block (in entropy-coding order, dummy edge blocks included): level shift,
-//                       13-bit fixed-point FDCT, quantisation by rounded division -> 64 int16 in zigzag order
-//   k_jpeg_count_bits   one thread per block: DC difference + run/size symbols -> number of bits
+//   k_jpeg_fdct_quant_count   one thread per 8x8 block (in entropy-coding order, dummy edge blocks included): level shift,
+//                       13-bit fixed-point FDCT, quantisation by rounded division -> 64 int16 in zigzag order; and, from the same
+//                       registers, DC difference + run/size symbols -> the block's number of bits
 //   (device-wide exclusive scan of the bit counts -> bit offset of every block)
 //   k_jpeg_emit         one thread per block: codes written MSB-first at the block's bit offset (whole words stored,
 //                       the two boundary words OR-ed atomically); the last block pads the final byte with ones
@@ -241,15 +241,8 @@ __device__ __forceinline__ int quantise(int v, int q, uint32_t m) {
   return v < 0 ? -t : t;
 }
 
-__global__ void __launch_bounds__(128) k_jpeg_fdct_quant(const Job j) {
-  const uint32_t i = blockIdx.x * 128u + threadIdx.x;
-  if (i >= j.nblk) return;
-  const BlockRef b = locate(j, i);
-  const Plane& p = j.plane[b.comp];
-  const uint16_t* q = b.comp == 0 ? j.q_lum : j.q_chr;   // zigzag order
-  const uint32_t* qm = b.comp == 0 ? j.m_lum : j.m_chr;
-  int16_t* out = j.coef + (size_t)i * 64u;
-  int d[64];
+// the 64 level-shifted samples of block b (of its source block for a dummy), with the helper's padding rules
+__device__ __forceinline__ void load_samples(const Plane& p, const BlockRef& b, int (&d)[64]) {
   const int r0 = b.br * 8, c0 = b.bc * 8;
   const bool inside = r0 + 8 <= p.h && (c0 + 8 <= p.w || !p.pad_cols);
   if (inside && p.aligned4) {
@@ -268,48 +261,15 @@ __global__ void __launch_bounds__(128) k_jpeg_fdct_quant(const Job j) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) d[r * 8 + c] = sample(p, r0 + r, c0 + c) - 128;
   }
-  if (b.dummy) {  // zero AC, DC of the source block; the islow DC is the plain sum of the 64 level-shifted samples
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) s += d[k];
-    uint4* o = reinterpret_cast<uint4*>(out);
-#pragma unroll
-    for (int k = 1; k < 8; ++k) o[k] = make_uint4(0u, 0u, 0u, 0u);
-    o[0] = make_uint4((uint32_t)(uint16_t)(int16_t)quantise(s, q[0], qm[0]), 0u, 0u, 0u);
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) fdct8<0>(d, r * 8, 1);
-#pragma unroll
-  for (int c = 0; c < 8; ++c) fdct8<1>(d, c, 8);
-  constexpr uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                               41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-  uint32_t packed[32];
-#pragma unroll
-  for (int k = 0; k < 64; k += 2) {
-    const int a = quantise(d[nat[k]], q[k], qm[k]), c = quantise(d[nat[k + 1]], q[k + 1], qm[k + 1]);
-    packed[k >> 1] = (uint32_t)(uint16_t)(int16_t)a | ((uint32_t)(uint16_t)(int16_t)c << 16);
-  }
-  uint4* o = reinterpret_cast<uint4*>(out);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = make_uint4(packed[4 * k], packed[4 * k + 1], packed[4 * k + 2], packed[4 * k + 3]);
 }
 
 // ---- entropy coding ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int nbits_of(int a) { return a == 0 ? 0 : 32 - __builtin_clz((unsigned)a); }
 
-// walks one block's symbols (jchuff.c encode_one_block); SINK::put(code, size) receives MSB-first bit strings
+// walks one block's symbols (jchuff.c encode_one_block); SINK::put(code, size) receives MSB-first bit strings.
+// c: the block's 64 quantised coefficients in zigzag order (registers: every index is a compile-time constant)
 template <typename SINK>
-__device__ __forceinline__ void walk_block(const int16_t* __restrict__ zz, int pred, int tbl_dc, int tbl_ac, SINK& s) {
-  int16_t c[64];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {   // 128 B per block, every index below is a compile-time constant (registers, no scratch)
-    const uint4 v = reinterpret_cast<const uint4*>(zz)[k];
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { c[8 * k + 2 * m] = (int16_t)(w[m] & 0xffffu); c[8 * k + 2 * m + 1] = (int16_t)(w[m] >> 16); }
-  }
+__device__ __forceinline__ void walk_coefs(const int16_t (&c)[64], int pred, int tbl_dc, int tbl_ac, SINK& s) {
   int temp = (int)c[0] - pred, temp2 = temp;
   if (temp < 0) { temp = -temp; temp2--; }
   int nb = nbits_of(temp);
@@ -331,6 +291,18 @@ __device__ __forceinline__ void walk_block(const int16_t* __restrict__ zz, int p
   }
   if (r > 0) { h = c_huff[tbl_ac][0]; s.put(h & 0xffffu, (int)(h >> 16)); }
 }
+template <typename SINK>
+__device__ __forceinline__ void walk_block(const int16_t* __restrict__ zz, int pred, int tbl_dc, int tbl_ac, SINK& s) {
+  int16_t c[64];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {   // 128 B per block
+    const uint4 v = reinterpret_cast<const uint4*>(zz)[k];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { c[8 * k + 2 * m] = (int16_t)(w[m] & 0xffffu); c[8 * k + 2 * m + 1] = (int16_t)(w[m] >> 16); }
+  }
+  walk_coefs(c, pred, tbl_dc, tbl_ac, s);
+}
 
 struct CountSink {
   uint32_t bits = 0;
@@ -343,13 +315,62 @@ __device__ __forceinline__ int pred_of(const Job& j, uint32_t i) {
 }
 __device__ __forceinline__ int comp_of(const Job& j, uint32_t i) { return j.gray ? 0 : ((i % 6u) < 4u ? 0 : 1); }
 
-__global__ void __launch_bounds__(128) k_jpeg_count_bits(const Job j) {
+// One thread per 8x8 block: forward DCT, quantisation, the block's 64 coefficients to memory (zigzag order) -- and, while they are
+// in registers, the number of bits its Huffman code takes (the prefix sum of those is where k_jpeg_emit writes).  The DC code needs
+// the quantised DC of the component's previous block, which another thread computes: the islow DC is the plain sum of the 64
+// level-shifted samples (pass 1 scales the row sums by 4, pass 2 descales by 4: exact), so it is had from that block's 64 bytes.
+__global__ void __launch_bounds__(128) k_jpeg_fdct_quant_count(const Job j) {
   const uint32_t i = blockIdx.x * 128u + threadIdx.x;
+  if (i == 0u) j.bits[j.nblk] = 0u;   // the scan's last input: its last output is then the total number of bits
   if (i >= j.nblk) return;
+  const BlockRef b = locate(j, i);
+  const Plane& p = j.plane[b.comp];
+  const uint16_t* q = b.comp == 0 ? j.q_lum : j.q_chr;   // zigzag order
+  const uint32_t* qm = b.comp == 0 ? j.m_lum : j.m_chr;
+  int16_t* out = j.coef + (size_t)i * 64u;
+  int d[64];
+  load_samples(p, b, d);
+  int16_t c[64];
+  if (b.dummy) {  // zero AC, DC of the source block
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) s += d[k];
+#pragma unroll
+    for (int k = 1; k < 64; ++k) c[k] = 0;
+    c[0] = (int16_t)quantise(s, q[0], qm[0]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fdct8<0>(d, r * 8, 1);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) fdct8<1>(d, cc, 8);
+    constexpr uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+#pragma unroll
+    for (int k = 0; k < 64; ++k) c[k] = (int16_t)quantise(d[nat[k]], q[k], qm[k]);
+  }
+  uint4* o = reinterpret_cast<uint4*>(out);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t w[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) w[m] = (uint32_t)(uint16_t)c[8 * k + 2 * m] | ((uint32_t)(uint16_t)c[8 * k + 2 * m + 1] << 16);
+    o[k] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  int pred = 0;
+  const uint32_t pi = dc_predecessor(j, i);
+  if (pi != 0xFFFFFFFFu) {
+    int e[64];
+    load_samples(p, locate(j, pi), e);   // (the same component, so the same plane and quantiser)
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) s += e[k];
+    pred = (int)(int16_t)quantise(s, q[0], qm[0]);
+  }
   const int chroma = comp_of(j, i);
-  CountSink s;
-  walk_block(j.coef + (size_t)i * 64u, pred_of(j, i), 2 * chroma, 2 * chroma + 1, s);
-  j.bits[i] = s.bits;
+  CountSink cs;
+  walk_coefs(c, pred, 2 * chroma, 2 * chroma + 1, cs);
+  j.bits[i] = cs.bits;
 }
 
 // MSB-first writer into a zero-initialised word buffer that other threads write next to: whole words are stored, the first
@@ -512,20 +533,18 @@ hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint6
   uint64_t* totals = reinterpret_cast<uint64_t*>(ws + l.totals);
   hipError_t e;
   if ((e = hipMemsetAsync(j.stream, 0, l.stream_bytes, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(j.bits + j.nblk, 0, 4, s)) != hipSuccess) return e;   // (bits has room: rounded up to 256 B)
   const dim3 gb((j.nblk + 127u) / 128u), bb(128);
-  hipLaunchKernelGGL(k_jpeg_fdct_quant, gb, bb, 0, s, j);
-  hipLaunchKernelGGL(k_jpeg_count_bits, gb, bb, 0, s, j);
+  hipLaunchKernelGGL(k_jpeg_fdct_quant_count, gb, bb, 0, s, j);
   size_t tmp = l.scan_tmp_bytes;
   // nblk + 1 items: the last output is the total number of bits
   if ((e = scan_bits(ws + l.scan_tmp, tmp, j.bits, j.bit_off, j.nblk + 1u, s)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(totals, j.bit_off + j.nblk, 8, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+  const uint64_t* total_bits = j.bit_off + j.nblk;
   hipLaunchKernelGGL(k_jpeg_emit, gb, bb, 0, s, j);
   const dim3 gc((j.max_chunks + 255u) / 256u), bc(256);
-  hipLaunchKernelGGL(k_jpeg_stuff_count, gc, bc, 0, s, j, totals);
+  hipLaunchKernelGGL(k_jpeg_stuff_count, gc, bc, 0, s, j, total_bits);
   tmp = l.scan_tmp_bytes;
   if ((e = hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, j.ff_count, j.ff_off, (int)j.max_chunks, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_jpeg_stuff_copy, gc, bc, 0, s, j, totals, out, out_cap, header_len, totals + 1);
+  hipLaunchKernelGGL(k_jpeg_stuff_copy, gc, bc, 0, s, j, total_bits, out, out_cap, header_len, totals + 1);
   return hipGetLastError();
 }
 

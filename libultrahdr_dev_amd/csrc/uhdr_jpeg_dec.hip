@@ -10,7 +10,7 @@
 // Schmidt 2018): a decoder started at a wrong bit position falls in step with the true decoder after a few symbols.
 //   k_jd_prepare_multi     per 64-byte chunk, the bytes that stay once the 0x00 after every 0xFF is dropped; first-level lookup tables (the
 //                    next 11 bits -> what the symbol implies) of the file's own Huffman tables; cleared flags and coefficients
-//   (scan) k_jd_unstuff_copy_multi   compact -> raw bit string
+//   k_jd_unstuff_copy_multi   compact -> raw bit string (offsets: the workgroups' totals summed, a block scan inside)
 //   k_jd_sync_multi<0>     every thread decodes one 512-bit subsequence from a guessed state (block 0, coefficient 0) and
 //                    records the state (bit, block-in-MCU, coefficient) it crosses the subsequence's end with
 //   k_jd_sync_multi<1>     rounds: thread i re-decodes subsequence i from the end state of i-1 (only if that state changed);
@@ -61,34 +61,52 @@ __device__ __forceinline__ bool dropped_byte(const uint8_t* src, uint32_t n, uin
   if (prev == 0xFF && (v == 0 || (rst && (v & 0xF8) == 0xD0))) return true;
   return rst && v == 0xFF && at + 1u < n && (src[at + 1u] & 0xF8) == 0xD0;
 }
-__device__ __forceinline__ void unstuff_count_body(const uint8_t* src, uint32_t n, uint32_t* kept, int rst) {
+// kept[t]: bytes chunk t keeps; kept_blk[g]: bytes the 256 chunks of workgroup g keep.  The compaction needs the number of
+// bytes kept in front of every chunk: inside a workgroup that is a block scan of 256 counts, across workgroups a sum of at most a
+// few hundred totals, which every workgroup of the copy forms for itself -- no device-wide scan between the two kernels.
+__device__ __forceinline__ void unstuff_count_body(const uint8_t* src, uint32_t n, uint32_t* kept, uint32_t* kept_blk, int rst) {
+  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
+  __shared__ typename Reduce::TempStorage s_tmp;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t b0 = t * kUnstuffChunk;
-  if (b0 >= n) return;
-  const uint32_t len = n - b0 < kUnstuffChunk ? n - b0 : kUnstuffChunk;
+  if (blockIdx.x * 256u * kUnstuffChunk >= n) return;   // (uniform: a workgroup behind the end of this image's segment owns no total)
   uint32_t k = 0;
-  uint8_t prev = b0 ? src[b0 - 1] : 0;
-  for (uint32_t i = 0; i < len; ++i) {
-    const uint8_t v = src[b0 + i];
-    k += !dropped_byte(src, n, b0 + i, v, prev, rst);
-    prev = v;
+  if (b0 < n) {
+    const uint32_t len = n - b0 < kUnstuffChunk ? n - b0 : kUnstuffChunk;
+    uint8_t prev = b0 ? src[b0 - 1] : 0;
+    for (uint32_t i = 0; i < len; ++i) {
+      const uint8_t v = src[b0 + i];
+      k += !dropped_byte(src, n, b0 + i, v, prev, rst);
+      prev = v;
+    }
+    kept[t] = k;
   }
-  kept[t] = k;
+  const uint32_t total = Reduce(s_tmp).Sum(k);
+  if (threadIdx.x == 0u) kept_blk[blockIdx.x] = total;
 }
 // a workgroup compacts its 16 KiB into LDS and writes the run out as aligned dwords (its start in `dst` is arbitrary)
-__device__ __forceinline__ void unstuff_copy_body(const uint8_t* src, uint32_t n, const uint32_t* off, uint8_t* dst, int rst) {
+__device__ __forceinline__ void unstuff_copy_body(const uint8_t* src, uint32_t n, const uint32_t* kept, const uint32_t* kept_blk, uint8_t* dst, int rst) {
+  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
+  typedef hipcub::BlockScan<uint32_t, 256> Scan;
+  __shared__ union { typename Reduce::TempStorage reduce; typename Scan::TempStorage scan; } s_tmp;
   __shared__ uint8_t s_buf[256 * kUnstuffChunk + 8];
-  __shared__ uint32_t s_len;
+  __shared__ uint32_t s_len, s_base;
   const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
   const uint32_t blk_b0 = first * kUnstuffChunk;
   if (blk_b0 >= n) return;
-  const uint32_t base = off[first];
+  uint32_t before = 0;
+  for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 256u) before += kept_blk[g];
+  before = Reduce(s_tmp.reduce).Sum(before);
+  if (threadIdx.x == 0u) s_base = before;
+  __syncthreads();
+  const uint32_t base = s_base;
   const uint32_t b0 = t * kUnstuffChunk;
   if (threadIdx.x == 0) s_len = 0u;
+  uint32_t lo = 0;
+  Scan(s_tmp.scan).ExclusiveSum(b0 < n ? kept[t] : 0u, lo);
   __syncthreads();
   if (b0 < n) {
     const uint32_t len = n - b0 < kUnstuffChunk ? n - b0 : kUnstuffChunk;
-    uint32_t lo = off[t] - base;
     uint8_t prev = b0 ? src[b0 - 1] : 0;
     const uint4* q = reinterpret_cast<const uint4*>(src + b0);     // src is 256-byte aligned, chunks are 64 bytes
 #pragma unroll
@@ -636,7 +654,7 @@ __device__ __forceinline__ void idct_body(const DecJob& j, const Dc3* dc) {
 struct DecBatchJob {
   DecJob j;
   const uint8_t* src; uint32_t src_bytes; int rst;     // unstuffing: stuffed segment -> j.raw
-  uint32_t* kept; const uint32_t* kept_off; uint8_t* raw_out;
+  uint32_t* kept; uint32_t* kept_blk; uint8_t* raw_out;
   DecTables tables; uint32_t* lut_out; uint32_t* adv_out;
   DState* st[2]; uint8_t* dirty[2]; uint32_t* nblocks; uint32_t* flags;
   const uint32_t* first_block; const Dc3* dc;
@@ -672,7 +690,6 @@ struct DcPickBatch {   // the DC difference of block g of the concatenation, in 
   }
 };
 typedef hipcub::CountingInputIterator<uint32_t> CountIt;
-typedef hipcub::TransformInputIterator<uint32_t, SegOf, CountIt> SegKeyIt;
 typedef hipcub::TransformInputIterator<uint64_t, SubKeyBatch, CountIt> SubKeyIt;
 typedef hipcub::TransformInputIterator<uint64_t, BlkKeyBatch, CountIt> BlkKeyIt;
 typedef hipcub::TransformInputIterator<Dc3, DcPickBatch, CountIt> DcPickIt;
@@ -685,8 +702,7 @@ __global__ void __launch_bounds__(256) k_jd_prepare_multi(const DecBatchJob* job
   const DecBatchJob& b = jobs[blockIdx.y];
   if (blockIdx.x < gu) {
     if (b.src_bytes == 0u) return;   // an image that failed on the host: it owns no slice of the batch arrays
-    if (blockIdx.x == 0u && threadIdx.x == 0u) b.kept[(b.src_bytes + kUnstuffChunk - 1u) / kUnstuffChunk] = 0u;   // the scan's last input
-    unstuff_count_body(b.src, b.src_bytes, b.kept, b.rst);
+    unstuff_count_body(b.src, b.src_bytes, b.kept, b.kept_blk, b.rst);
   } else if (blockIdx.x < gu + kLutBlocks) {
     build_lut_body(b.tables, b.lut_out, b.adv_out, blockIdx.x - gu);
   } else {
@@ -699,7 +715,7 @@ __global__ void __launch_bounds__(256) k_jd_prepare_multi(const DecBatchJob* job
     }
   }
 }
-__global__ void __launch_bounds__(256) k_jd_unstuff_copy_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; unstuff_copy_body(b.src, b.src_bytes, b.kept_off, b.raw_out, b.rst); }
+__global__ void __launch_bounds__(256) k_jd_unstuff_copy_multi(const DecBatchJob* jobs) { const DecBatchJob& b = jobs[blockIdx.y]; unstuff_copy_body(b.src, b.src_bytes, b.kept, b.kept_blk, b.raw_out, b.rst); }
 // parity: which of the two state / dirty buffers is read (the other one is written).  round: number of the launch, 1, 2, ... --
 // words 64..127 of an image's flags are a ring of "launch r changed an end state".  A launch that follows one without a change has
 // nothing to do (both state buffers are equal by then) and returns at once, image by image: the host enqueues launches without
@@ -750,7 +766,7 @@ size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l) {
 
 // where the batch-level arrays sit inside the scratch buffer
 struct BatchLayout {
-  size_t jobs, flags, offs, kept, kept_off, nblocks, first_block, dc, tmp, tmp_bytes, total;
+  size_t jobs, flags, offs, kept, kept_blk, nblocks, first_block, dc, tmp, tmp_bytes, total;
   uint32_t n_kept, n_sub, n_blk;
 };
 static BatchLayout batch_layout(int n, const DecLayout l[]) {
@@ -763,18 +779,17 @@ static BatchLayout batch_layout(int n, const DecLayout l[]) {
   B.flags = o; o += up((size_t)n * kFlagWords * 4);
   B.offs = o; o += up((size_t)3 * (n + 1) * 4);
   B.kept = o; o += up((size_t)B.n_kept * 4);
-  B.kept_off = o; o += up((size_t)B.n_kept * 4);
+  B.kept_blk = o; o += up(((size_t)B.n_kept / 256u + (size_t)n + 1u) * 4);
   B.nblocks = o; o += up((size_t)B.n_sub * 4);
   B.first_block = o; o += up((size_t)B.n_sub * 4);
   B.dc = o; o += up((size_t)B.n_blk * sizeof(Dc3) + 16);
-  size_t t1 = 0, t2 = 0, t3 = 0;
+  size_t t2 = 0, t3 = 0;
   const SegOf seg{nullptr, n};
   CountIt cnt(0u);
-  (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t1, SegKeyIt(cnt, seg), (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)B.n_kept);
   (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t2, SubKeyIt(cnt, SubKeyBatch{nullptr, seg}), (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)B.n_sub);
   (void)hipcub::DeviceScan::InclusiveScanByKey(nullptr, t3, BlkKeyIt(cnt, BlkKeyBatch{nullptr, seg}), DcPickIt(cnt, DcPickBatch{nullptr, seg}), (Dc3*)nullptr,
                                                Dc3Sum(), (int)(B.n_blk ? B.n_blk : 1u));
-  B.tmp_bytes = up(std::max(t1, std::max(t2, t3)) + 256);
+  B.tmp_bytes = up(std::max(t2, t3) + 256);
   B.tmp = o; o += B.tmp_bytes;
   B.total = o;
   return B;
@@ -823,7 +838,7 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     uint8_t* w = ws[k];
     b.src = w + L.src; b.src_bytes = (uint32_t)in.scan_bytes; b.rst = in.restart_interval != 0 ? 1 : 0;
     // the arrays the prefix sums run over are slices of batch-level concatenations (one segmented scan for all images)
-    b.kept = reinterpret_cast<uint32_t*>(batch_ws + B.kept) + koff[k]; b.kept_off = reinterpret_cast<const uint32_t*>(batch_ws + B.kept_off) + koff[k];
+    b.kept = reinterpret_cast<uint32_t*>(batch_ws + B.kept) + koff[k]; b.kept_blk = reinterpret_cast<uint32_t*>(batch_ws + B.kept_blk) + koff[k] / 256u + (uint32_t)k;
     b.raw_out = w + L.raw;
     b.tables = in.tables; b.lut_out = reinterpret_cast<uint32_t*>(w + L.lut); b.adv_out = reinterpret_cast<uint32_t*>(w + L.adv);
     b.st[0] = reinterpret_cast<DState*>(w + L.st_a); b.st[1] = reinterpret_cast<DState*>(w + L.st_b);
@@ -878,18 +893,13 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   JD_TRY(hipMemcpyAsync(doffs, offs, noffs * 4, hipMemcpyHostToDevice, s));
   if (!keep.empty()) JD_TRY(hipStreamSynchronize(s));   // restart tables are in pageable host memory
   JD_LAP("jobs assembled + uploaded");
-  const SegOf kseg{doffs, n}, sseg{doffs + (n + 1), n}, bseg{doffs + 2 * (n + 1), n};
+  const SegOf sseg{doffs + (n + 1), n}, bseg{doffs + 2 * (n + 1), n};
   const CountIt cnt0(0u);
   uint8_t* stmp = batch_ws + B.tmp;
   keep.clear();
   const dim3 b256(256);
   const unsigned ny = (unsigned)n;
   hipLaunchKernelGGL(k_jd_prepare_multi, dim3(gu + kLutBlocks + kZeroBlocks, ny), b256, 0, s, (const DecBatchJob*)djobs, gu);
-  if (koff[n]) {
-    size_t tmp = B.tmp_bytes;
-    JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(stmp, tmp, SegKeyIt(cnt0, kseg), reinterpret_cast<const uint32_t*>(batch_ws + B.kept),
-                                                 reinterpret_cast<uint32_t*>(batch_ws + B.kept_off), (int)koff[n], hipcub::Equality(), s));
-  }
   hipLaunchKernelGGL(k_jd_unstuff_copy_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_sync_multi<0>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, 0u);
   JD_LAP("enqueued through sync<0>");

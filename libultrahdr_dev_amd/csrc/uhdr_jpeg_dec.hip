@@ -439,10 +439,12 @@ __device__ __forceinline__ void sync_first_body(const DecJob& j, const DecTables
 #define UHDR_JD_LOCAL_ROUNDS 4
 #endif
 constexpr uint32_t kLocalRounds = UHDR_JD_LOCAL_ROUNDS;
-// launches the host enqueues before it looks at the ring: a quality-75 4K file needs 5-8 rounds, a quality-95 one 21-24
+// launches the host enqueues before it looks at the ring (a quality-75 4K file needs 5-8 rounds, a quality-95 one 21-24)
 // (counted in rounds of 512-bit subsequences; shorter subsequences need proportionally more)
 constexpr uint32_t kRoundScale = 512u / kSubBits > 0u ? 512u / kSubBits : 1u;
-constexpr uint32_t kFirstLaunches = 2u * ((8u * kRoundScale + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
+// (A look at the ring leaves the device idle for ~35 us -- copy, host wake-up, next launch -- and a launch that returns at once
+// costs ~7: so the first batch covers what a quality-95 file needs, and a file that needs a third of it pays four empty launches.)
+constexpr uint32_t kFirstLaunches = 2u * ((24u * kRoundScale + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
 constexpr uint32_t kMoreLaunches = 2u * ((16u * kRoundScale + 2u * kLocalRounds - 1u) / (2u * kLocalRounds));
 __device__ __forceinline__ void sync_rounds_body(const DecJob& j, const DecTables& tables, const DState* prev, DState* next, const uint8_t* dirty_in,
                                                  uint8_t* dirty_out, uint32_t* nblocks, uint32_t* changed) {

@@ -707,16 +707,45 @@ struct JpegrFile {
   uhdr_hip_metadata_t md;
   int gamut = UHDR_HIP_CG_UNSPECIFIED;
 };
+// The image that starts at `begin`, found through its header: the header parser's walk over the (only) scan of a baseline file
+// ends at EOI, and that is where the image ends.  Anything else -- more scans, other markers behind the scan, a header this decoder
+// does not read -- is left to the container's own marker walk (jpegr::find_images), which then walks the scan a second time.
+bool image_by_header(const uint8_t* file, size_t n, size_t begin, jpeg::DecInfo* info, size_t* len) {
+  if (begin + 4 > n || jpeg::parse_header(file + begin, n - begin, info) != 0) return false;
+  const size_t e = begin + info->scan_offset + info->scan_bytes;
+  if (e + 2 > n || file[e] != 0xFF || file[e + 1] != 0xD9) return false;
+  *len = e + 2 - begin;
+  return true;
+}
+
 int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bool want_metadata, JpegrFile* f) {
   const uint8_t* file = static_cast<const uint8_t*>(jpegr);
-  jpegr::Range img[2];
-  const int found = jpegr::find_images(file, jpegr_size, img);                                          // :823-876
-  if (found == 0) return UHDR_HIP_ERROR_NO_IMAGES_FOUND;
-  if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
   const bool sdr = output_format == UHDR_HIP_OUTPUT_SDR;   // the gain map is neither decompressed nor (unless asked for) read (:728, :754)
+  jpegr::Range img[2];
+  bool by_header = false;   // both ranges and both headers in one walk per image (the file the reference's encoder writes)
+  if (file != nullptr && jpegr_size >= 4 && file[0] == 0xFF && file[1] == 0xD8 && image_by_header(file, jpegr_size, 0, &f->info[0], &img[0].len)) {
+    img[0].begin = 0;
+    size_t pos = img[0].len;
+    while (pos + 1 < jpegr_size) {   // the next SOI, as find_images looks for it
+      const void* q = memchr(file + pos, 0xFF, jpegr_size - 1 - pos);
+      if (q == nullptr) break;
+      pos = (size_t)(static_cast<const uint8_t*>(q) - file);
+      if (file[pos + 1] == 0xD8) {
+        by_header = image_by_header(file, jpegr_size, pos, &f->info[1], &img[1].len);
+        img[1].begin = pos;
+        break;
+      }
+      pos++;
+    }
+  }
+  if (!by_header) {
+    const int found = jpegr::find_images(file, jpegr_size, img);                                        // :823-876
+    if (found == 0) return UHDR_HIP_ERROR_NO_IMAGES_FOUND;
+    if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
+  }
   for (int k = 0; k < (sdr ? 1 : 2); ++k) {   // the headers, parsed once (jpeg_read_header of either decompressImage call, :690-694 / :731-733)
     f->jpg[k] = file + img[k].begin; f->len[k] = img[k].len;
-    const int prc = jpeg::parse_header(f->jpg[k], f->len[k], &f->info[k]);
+    const int prc = by_header ? 0 : jpeg::parse_header(f->jpg[k], f->len[k], &f->info[k]);
     if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
     if (prc != 0 || f->info[k].w > 8192 || f->info[k].h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;
   }

@@ -95,6 +95,9 @@ struct DecJob {
 };
 // 0 ok, -1 malformed, -2 outside what this decoder (or the reference: sampling) supports
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info);
+// the walk over an entropy-coded segment on its own (the container scan uses it): position of the 0xFF of the first marker at or
+// behind `e` that is neither a stuffed zero, a fill byte nor an RSTn; n if there is none
+size_t skip_entropy_coded(const uint8_t* p, size_t e, size_t n);
 size_t dec_workspace_bytes(const DecInfo& info, DecLayout* l);
 // n images on one stream with one launch per decoder step for all of them (blockIdx.y = image); batch_ws: device scratch of
 // dec_batch_scratch_bytes(n, layouts)

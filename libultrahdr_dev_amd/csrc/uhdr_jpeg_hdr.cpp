@@ -98,6 +98,20 @@ static size_t skip_to_marker(const uint8_t* p, size_t e, size_t n, uint32_t* stu
   return e;
 }
 
+// position of the 0xFF of the first marker at or behind `e` that is neither a stuffed zero, a fill byte nor an RSTn; n if there is none
+size_t skip_entropy_coded(const uint8_t* p, size_t e, size_t n) {
+  uint32_t stuffed = 0;
+  for (;;) {
+    e = skip_to_marker(p, e, n, &stuffed);
+    while (e + 1 < n && p[e] != 0xFF) ++e;
+    if (e + 1 >= n) return n;
+    const uint8_t b = p[e + 1];
+    if (b == 0x00 || (b & 0xF8) == 0xD0) { e += 2; continue; }
+    if (b == 0xFF) { e += 1; continue; }
+    return e;
+  }
+}
+
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
   if (jpg == nullptr || n < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return -1;
   *info = DecInfo();

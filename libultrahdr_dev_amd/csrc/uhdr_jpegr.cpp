@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/uhdr_hip.h"
+#include "uhdr_jpeg.h"
 #include "uhdr_jpegr.h"
 
 namespace uhdr {
@@ -39,15 +40,8 @@ size_t walk_image(const uint8_t* d, size_t n, size_t pos) {
     if (len < 2 || pos + 2 + len > n) return 0;
     pos += 2 + len;
     if (m == 0xDA) {   // entropy-coded segment: up to the next marker that is neither a stuffed zero, a fill byte nor RSTn
-      for (;;) {
-        const void* f = pos + 1 < n ? memchr(d + pos, 0xFF, n - 1 - pos) : nullptr;
-        if (f == nullptr) return 0;
-        pos = (size_t)(static_cast<const uint8_t*>(f) - d);
-        const unsigned k = d[pos + 1];
-        if (k == 0x00 || (k >= 0xD0 && k <= 0xD7)) { pos += 2; continue; }
-        if (k == 0xFF) { pos += 1; continue; }
-        break;
-      }
+      pos = jpeg::skip_entropy_coded(d, pos, n);
+      if (pos + 1 >= n) return 0;
     }
   }
 }

@@ -4,14 +4,16 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=/tmp/trace_jd
 rm -rf $OUT; mkdir -p $OUT $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/a -- python3 $R/scripts/time_jpeg_dec.py > $OUT/a.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/a -- python3 $R/scripts/${TRACE_SCRIPT:-time_jpeg_dec.py} > $OUT/a.log 2>&1
 python3 - $OUT $R/gpurun_out/trace_jpeg_dec.txt <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/a/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "k_jd_prepare_multi" in r["Kernel_Name"]]
 # decodes 4..13 are the 10 timed q95 decodes; take the 8th
-a, b = starts[10], starts[11]
+import os
+k = int(os.environ.get("TRACE_DECODE", "10"))
+a, b = starts[k], starts[k + 1]
 out = open(sys.argv[2], "w")
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0
 for r in rows[a:b]:

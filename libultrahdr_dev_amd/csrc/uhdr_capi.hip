@@ -49,6 +49,9 @@ struct DeviceState {
   // uhdr_hip_jpegr_decode[_batch]: per-file decoder workspaces and planes
   std::vector<void*> pool;
   std::vector<size_t> pool_bytes;
+  // encodeJPEGR: the gain-map JPEG is compressed on a stream of its own, next to the SDR image's conversion and compression
+  hipStream_t aux = nullptr;
+  hipEvent_t map_ready = nullptr;
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
 std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
@@ -490,6 +493,8 @@ int uhdr_hip_shutdown(void) {
     for (void* q : kv.second.pool) if (q) (void)hipFree(q);
     for (int i = 0; i < 14; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
+    if (kv.second.map_ready) (void)hipEventDestroy(kv.second.map_ready);
+    if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
   }
   g_dev.clear();
   if (prev >= 0) (void)hipSetDevice(prev);
@@ -1106,8 +1111,7 @@ int jpeg_enqueue_device(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, 
   uint8_t* ws = static_cast<uint8_t*>(c.st->stage[ws_slot]);
   memcpy(dst.data(), header.data(), header.size());   // host memory: no copy to enqueue
   *total = 0;
-  HIP_TRY(jpeg::encode_async(j, l, ws, dst.data(), dst.size(), header.size(), c.s()));
-  HIP_TRY(hipMemcpyAsync(total, ws + l.totals + 8, 8, hipMemcpyDeviceToHost, c.s()));
+  HIP_TRY(jpeg::encode_async(j, l, ws, dst.data(), dst.size(), header.size(), c.s(), total));   // (the size goes where the bytes go: page-locked host memory)
   pend->dst = &dst; pend->total = total; pend->img = img; pend->q = q;
   pend->has_icc = icc != nullptr;
   if (icc) pend->icc = *icc;
@@ -1129,8 +1133,19 @@ int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, HostBytes& 
   g.chroma_data = nullptr; g.chroma_stride = 0; g.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
   jpeg.resize(map.width * map.height + 65536);
   if (!c.host()) {   // enqueued; *n == kPendingSize until resolve_gainmap_jpeg() (or finish_from_planes) has synchronised
+    // On a stream of its own behind the kernel that wrote the map: nothing the caller's stream does next (the SDR image's BT.601
+    // re-encode and compression) depends on it, and its ~12 small launches fit next to those (g_jpegr_mu held: one call at a time).
+    if (c.st->aux == nullptr) {
+      HIP_TRY(hipStreamCreateWithFlags(&c.st->aux, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c.st->map_ready, hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamSynchronize(c.st->aux));   // (idle unless an earlier call left on an error path)
+    HIP_TRY(hipEventRecord(c.st->map_ready, c.s()));
+    HIP_TRY(hipStreamWaitEvent(c.st->aux, c.st->map_ready, 0));
+    EncodeCtx side = c;
+    side.stream = c.st->aux;
     *n = kPendingSize;
-    return jpeg_enqueue_device(c, g, 85, nullptr, jpeg, 13, pinned_totals(), &pending_gainmap()) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
+    return jpeg_enqueue_device(side, g, 85, nullptr, jpeg, 13, pinned_totals(), &pending_gainmap()) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
   }
   return jpeg_to_host(c, g, 85, nullptr, jpeg, n) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
 }
@@ -1150,15 +1165,44 @@ int make_gainmap_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& yuv, const uhd
   return gainmap_to_jpeg(c, map, jpeg, n);
 }
 
+// the 3x3 of JpegR::convertYuv for a pair of different encodings (jpegr.cpp:1134-1197)
+const float* yuv_matrix(int src_encoding, int dest_encoding) {
+  switch (src_encoding) {
+    case UHDR_HIP_CG_BT709: return dest_encoding == UHDR_HIP_CG_P3 ? kYuv709To601 : kYuv709To2100;
+    case UHDR_HIP_CG_P3: return dest_encoding == UHDR_HIP_CG_BT709 ? kYuv601To709 : kYuv601To2100;
+    default: return dest_encoding == UHDR_HIP_CG_BT709 ? kYuv2100To709 : kYuv2100To601;
+  }
+}
+// convertYuv of `src` into the planes of `dst` (device memory, same size): the private copy API-1 converts is written by the
+// conversion itself instead of by three plane copies in front of it
+int convert_yuv_into(const uhdr_hip_image_t& src, const uhdr_hip_image_t& dst, const float* m, hipStream_t s) {
+  CvtImage t;
+  t.y = static_cast<uint8_t*>(dst.data);
+  t.u = static_cast<uint8_t*>(dst.chroma_data);
+  t.v = t.u + dst.chroma_stride * (dst.height / 2);
+  t.y_stride = (uint32_t)dst.luma_stride; t.c_stride = (uint32_t)dst.chroma_stride;
+  t.width = (uint32_t)dst.width; t.height = (uint32_t)dst.height;
+  for (int i = 0; i < 9; ++i) t.m[i] = m[i];
+  t.sy = static_cast<const uint8_t*>(src.data);
+  t.su = static_cast<const uint8_t*>(src.chroma_data);
+  t.sv = t.su + src.chroma_stride * (src.height / 2);
+  t.sy_stride = (uint32_t)src.luma_stride; t.sc_stride = (uint32_t)src.chroma_stride;
+  const bool aligned = t.width % 8u == 0 && al(t.y, 8) && t.y_stride % 8u == 0 && al(t.u, 4) && al(t.v, 4) && t.c_stride % 4u == 0 &&
+                       al(t.sy, 8) && t.sy_stride % 8u == 0 && al(t.su, 4) && al(t.sv, 4) && t.sc_stride % 4u == 0;
+  HIP_TRY(launch_convert_yuv(t, aligned, s));
+  return UHDR_HIP_NO_ERROR;
+}
+
 // the tail API-0 and API-1 share (jpegr.cpp:210-247 / :294-380): ICC for the SDR gamut, BT.601 re-encode unless P3, JPEG at `quality`,
 // appendGainMap.  `enc` must be private to the call when it is not P3 (it is converted in place).
 int finish_from_planes(const EncodeCtx& c, uhdr_hip_image_t enc, int quality, const void* exif, size_t exif_size,
                        const HostBytes& gm_jpeg, size_t gm_n, const uhdr_hip_metadata_t& md, void* out, size_t out_capacity,
-                       size_t* out_size) {   // gm_n may be kPendingSize: the gain-map JPEG is still being written (device callers)
+                       size_t* out_size, bool converted = false) {   // gm_n may be kPendingSize: the gain-map JPEG is still being written (device callers)
   std::vector<uint8_t> icc;
   if (!jpegr::icc_profile_srgb_transfer(enc.colorGamut, icc)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
   int rc;
-  if (enc.colorGamut != UHDR_HIP_CG_P3 && (rc = uhdr_hip_convert_yuv(&enc, enc.colorGamut, UHDR_HIP_CG_P3, c.mem_space, c.stream)) != UHDR_HIP_NO_ERROR)
+  if (!converted && enc.colorGamut != UHDR_HIP_CG_P3 &&
+      (rc = uhdr_hip_convert_yuv(&enc, enc.colorGamut, UHDR_HIP_CG_P3, c.mem_space, c.stream)) != UHDR_HIP_NO_ERROR)
     return rc;
   static thread_local HostBytes sdr_jpeg;
   sdr_jpeg.resize(enc.width * enc.height + 65536);
@@ -1167,6 +1211,7 @@ int finish_from_planes(const EncodeCtx& c, uhdr_hip_image_t enc, int quality, co
     PendingJpeg sdr;
     if (jpeg_enqueue_device(c, enc, quality, &icc, sdr_jpeg, 12, pinned_totals() + 1, &sdr) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
     HIP_TRY(hipStreamSynchronize(c.s()));
+    if (gm_n == kPendingSize) HIP_TRY(hipStreamSynchronize(c.st->aux));
     if (gm_n == kPendingSize && jpeg_collect(c, pending_gainmap(), &gm_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
     if (jpeg_collect(c, sdr, &sdr_n) != UHDR_HIP_NO_ERROR) return UHDR_HIP_ERROR_ENCODE_ERROR;
   } else if (jpeg_to_host(c, enc, quality, &icc, sdr_jpeg, &sdr_n) != UHDR_HIP_NO_ERROR) {
@@ -1179,7 +1224,7 @@ int finish_from_planes(const EncodeCtx& c, uhdr_hip_image_t enc, int quality, co
 // for the callers that need the gain-map JPEG at once (API-2 / API-3 / API-x): wait for it
 int resolve_gainmap_jpeg(const EncodeCtx& c, size_t* n) {
   if (*n != kPendingSize) return UHDR_HIP_NO_ERROR;
-  HIP_TRY(hipStreamSynchronize(c.s()));
+  HIP_TRY(hipStreamSynchronize(c.st->aux));
   return jpeg_collect(c, pending_gainmap(), n) == UHDR_HIP_NO_ERROR ? UHDR_HIP_NO_ERROR : UHDR_HIP_ERROR_ENCODE_ERROR;
 }
 
@@ -1249,6 +1294,7 @@ int uhdr_hip_jpegr_encode_api1(const uhdr_hip_image_t* p010_in, const uhdr_hip_i
   // :297-358: unless the SDR image is P3 (= BT.601 encoding) already, a copy with 16-aligned strides, zero padded, is what gets converted
   uhdr_hip_image_t enc = yuv;
   std::vector<uint8_t> host_601;
+  bool converted = false;
   if (yuv.colorGamut != UHDR_HIP_CG_P3) {
     const size_t ls = (w + 15) / 16 * 16, cs = ls >> 1, total = ls * h * 3 / 2;
     enc.luma_stride = ls; enc.chroma_stride = cs;
@@ -1264,15 +1310,17 @@ int uhdr_hip_jpegr_encode_api1(const uhdr_hip_image_t* p010_in, const uhdr_hip_i
     } else {
       if ((rc = stage_reserve(c.st, 8, total + 64)) != 0) return rc;
       uint8_t* d = static_cast<uint8_t*>(c.st->stage[8]);
-      HIP_TRY(hipMemsetAsync(d, 0, total, c.s()));
-      HIP_TRY(hipMemcpy2DAsync(d, ls, yuv.data, yuv.luma_stride, w, h, hipMemcpyDeviceToDevice, c.s()));
-      HIP_TRY(hipMemcpy2DAsync(d + ls * h, cs, src_u, yuv.chroma_stride, w / 2, h / 2, hipMemcpyDeviceToDevice, c.s()));
-      HIP_TRY(hipMemcpy2DAsync(d + ls * h + cs * h / 2, cs, src_v, yuv.chroma_stride, w / 2, h / 2, hipMemcpyDeviceToDevice, c.s()));
+      if (ls != w) HIP_TRY(hipMemsetAsync(d, 0, total, c.s()));   // the padding columns (a width of whole 16-column batches has none)
       enc.data = d;
+      enc.chroma_data = d + ls * h;
+      // the copy is written by the conversion (the same arithmetic on the same samples as a copy followed by the in-place form)
+      if (!valid_gamut(yuv.colorGamut)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+      if ((rc = convert_yuv_into(yuv, enc, yuv_matrix(yuv.colorGamut, UHDR_HIP_CG_P3), c.s())) != UHDR_HIP_NO_ERROR) return rc;
+      converted = true;
     }
     enc.chroma_data = static_cast<uint8_t*>(enc.data) + ls * h;
   }
-  return finish_from_planes(c, enc, quality, exif, exif_size, gm_jpeg, gm_n, md, out, out_capacity, out_size);
+  return finish_from_planes(c, enc, quality, exif, exif_size, gm_jpeg, gm_n, md, out, out_capacity, out_size, converted);
 }
 
 // JpegR::encodeJPEGR API-4 (jpegr.cpp:502-560): host bytes only, nothing runs on the device
@@ -1738,6 +1786,7 @@ int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_enc
     t.y_stride = (uint32_t)d.luma_stride; t.c_stride = (uint32_t)d.chroma_stride;
     t.width = (uint32_t)d.width; t.height = (uint32_t)d.height;
     for (int i = 0; i < 9; ++i) t.m[i] = m[i];
+    t.sy = t.y; t.su = t.u; t.sv = t.v; t.sy_stride = t.y_stride; t.sc_stride = t.c_stride;   // in place
     const bool aligned = t.width % 8u == 0 && al(t.y, 8) && t.y_stride % 8u == 0 && al(t.u, 4) && al(t.v, 4) &&
                          t.c_stride % 4u == 0;
     HIP_TRY(launch_convert_yuv(t, aligned, s));

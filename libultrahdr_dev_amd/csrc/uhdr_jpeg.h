@@ -43,7 +43,9 @@ void build_header(int w, int h, bool gray, int quality, const void* icc, size_t 
 size_t workspace_bytes(uint32_t nblk, Layout* l);
 // enqueues the whole encoder; the JPEG (without the header, which the caller places at out[0, header_len)) lands at
 // out + header_len, its total size (header included) in the uint64 at ws + l.totals + 8
-hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint64_t out_cap, uint64_t header_len, hipStream_t s);
+// out_size: where the kernel that appends EOI reports the file's size (device-accessible; nullptr: word [1] of the workspace's totals)
+hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint64_t out_cap, uint64_t header_len, hipStream_t s,
+                        uint64_t* out_size = nullptr);
 
 // ---- decoder (uhdr_jpeg_dec.hip) -------------------------------------------------------------------------------------
 struct HuffSpec {            // one DHT table in canonical form (T.81 Annex C)

@@ -522,7 +522,7 @@ size_t workspace_bytes(uint32_t nblk, Layout* l) {
   return o;
 }
 
-hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint64_t out_cap, uint64_t header_len, hipStream_t s) {
+hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint64_t out_cap, uint64_t header_len, hipStream_t s, uint64_t* out_size) {
   j.coef = reinterpret_cast<int16_t*>(ws + l.coef);
   j.bits = reinterpret_cast<uint32_t*>(ws + l.bits);
   j.bit_off = reinterpret_cast<uint64_t*>(ws + l.bit_off);
@@ -544,7 +544,7 @@ hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint6
   hipLaunchKernelGGL(k_jpeg_stuff_count, gc, bc, 0, s, j, total_bits);
   tmp = l.scan_tmp_bytes;
   if ((e = hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, j.ff_count, j.ff_off, (int)j.max_chunks, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_jpeg_stuff_copy, gc, bc, 0, s, j, total_bits, out, out_cap, header_len, totals + 1);
+  hipLaunchKernelGGL(k_jpeg_stuff_copy, gc, bc, 0, s, j, total_bits, out, out_cap, header_len, out_size != nullptr ? out_size : totals + 1);
   return hipGetLastError();
 }
 

@@ -96,11 +96,15 @@ struct ToneImage {
   uint32_t width, height;
 };
 struct CvtImage {
-  uint8_t* y;
+  uint8_t* y;   // where the converted planes go ...
   uint8_t* u;
   uint8_t* v;
   uint32_t y_stride, c_stride, width, height;
   float m[9];
+  const uint8_t* sy;   // ... and where the samples come from: the same planes (JpegR::convertYuv works in place), or the caller's
+  const uint8_t* su;   // image when the conversion is also the private copy encodeJPEGR API-1 takes first (jpegr.cpp:297-358)
+  const uint8_t* sv;
+  uint32_t sy_stride, sc_stride;
 };
 
 // ---- editorhelper effects (crop / mirror / rotate / resize): byte gathers over planes ---------------

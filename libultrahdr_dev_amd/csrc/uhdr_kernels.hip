@@ -1328,13 +1328,17 @@ __global__ void __launch_bounds__(256) k_convert_yuv(const CvtImage t) {
   uint8_t* y1 = y0 + t.y_stride;
   uint8_t* ur = t.u + (size_t)cyr * t.c_stride;
   uint8_t* vr = t.v + (size_t)cyr * t.c_stride;
+  const uint8_t* sy0 = t.sy + (size_t)(2u * cyr) * t.sy_stride;
+  const uint8_t* sy1 = sy0 + t.sy_stride;
+  const uint8_t* sur = t.su + (size_t)cyr * t.sc_stride;
+  const uint8_t* svr = t.sv + (size_t)cyr * t.sc_stride;
   if (ALIGNED) {  // 4 chroma samples = 8 luma columns per thread; cw % 4 == 0
     const uint32_t cx = i * 4u;
     if (cx >= cw) return;
-    uint2 a = *reinterpret_cast<const uint2*>(y0 + 2u * cx);
-    uint2 bq = *reinterpret_cast<const uint2*>(y1 + 2u * cx);
-    uint32_t uw = *reinterpret_cast<const uint32_t*>(ur + cx);
-    uint32_t vw = *reinterpret_cast<const uint32_t*>(vr + cx);
+    uint2 a = *reinterpret_cast<const uint2*>(sy0 + 2u * cx);
+    uint2 bq = *reinterpret_cast<const uint2*>(sy1 + 2u * cx);
+    uint32_t uw = *reinterpret_cast<const uint32_t*>(sur + cx);
+    uint32_t vw = *reinterpret_cast<const uint32_t*>(svr + cx);
     const uint32_t top[2] = {a.x, a.y}, bot[2] = {bq.x, bq.y};
     uint32_t otop[2] = {0u, 0u}, obot[2] = {0u, 0u}, ou = 0u, ov = 0u;
 #pragma unroll
@@ -1354,8 +1358,8 @@ __global__ void __launch_bounds__(256) k_convert_yuv(const CvtImage t) {
     *reinterpret_cast<uint32_t*>(vr + cx) = ov;
   } else {
     if (i >= cw) return;
-    uint32_t yb[4] = {y0[2u * i], y0[2u * i + 1u], y1[2u * i], y1[2u * i + 1u]};
-    uint32_t ub = ur[i], vb = vr[i];
+    uint32_t yb[4] = {sy0[2u * i], sy0[2u * i + 1u], sy1[2u * i], sy1[2u * i + 1u]};
+    uint32_t ub = sur[i], vb = svr[i];
     cvt_block(t.m, yb, ub, vb);
     y0[2u * i] = (uint8_t)yb[0]; y0[2u * i + 1u] = (uint8_t)yb[1];
     y1[2u * i] = (uint8_t)yb[2]; y1[2u * i + 1u] = (uint8_t)yb[3];

@@ -28,11 +28,11 @@ struct Job {
   uint64_t* bit_off;       // nblk + 1 (exclusive scan; [nblk] = total)
   uint32_t* stream;        // packed entropy-coded bits before byte stuffing, big-endian words
   uint32_t* ff_count;      // per 64-byte chunk of the stream
-  uint32_t* ff_off;
+  uint32_t* ff_blk;
   uint32_t max_chunks;
 };
 struct Layout {
-  size_t coef, bits, bit_off, stream, stream_bytes, ff_count, ff_off, totals, scan_tmp, scan_tmp_bytes;
+  size_t coef, bits, bit_off, stream, stream_bytes, ff_count, ff_blk, totals, scan_tmp, scan_tmp_bytes;
   uint32_t max_chunks;
 };
 

@@ -11,8 +11,7 @@
 //   (device-wide exclusive scan of the bit counts -> bit offset of every block)
 //   k_jpeg_emit         one thread per block: codes written MSB-first at the block's bit offset (whole words stored,
 //                       the two boundary words OR-ed atomically); the last block pads the final byte with ones
-//   k_jpeg_stuff_count  one thread per 64 bytes of the packed stream: number of 0xFF bytes
-//   (scan)
+//   k_jpeg_stuff_count  one thread per 64 bytes of the packed stream: number of 0xFF bytes (and per workgroup)
 //   k_jpeg_stuff_copy   one thread per 64 bytes: copy to the output with 0x00 stuffed after every 0xFF, EOI at the end
 //
 // Byte-exact against libjpeg for every size, stride regime and quality tested (tests/test_gpu_jpeg.py against
@@ -423,18 +422,25 @@ __global__ void __launch_bounds__(128) k_jpeg_emit(const Job j) {
 
 // ---- byte stuffing -------------------------------------------------------------------------------------------------
 constexpr uint32_t kChunk = 64;
+// ff_count[t]: 0xFF bytes in chunk t; ff_blk[g]: in the 256 chunks of workgroup g.  The copy needs the number of stuffed zeros in
+// front of every chunk: inside a workgroup a block scan of 256 counts, across workgroups the sum of the totals in front, which
+// every workgroup of the copy forms for itself (a 4K frame has ~100 of them) -- no device-wide scan between the two kernels.
 __global__ void __launch_bounds__(256) k_jpeg_stuff_count(const Job j, const uint64_t* total_bits) {
+  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
+  __shared__ typename Reduce::TempStorage s_tmp;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint64_t nbytes = (*total_bits + 7u) >> 3;
   const uint64_t b0 = (uint64_t)t * kChunk;
-  if (t >= j.max_chunks) return;
+  if ((uint64_t)blockIdx.x * 256u * kChunk >= nbytes) return;   // uniform per workgroup: behind the end of the stream
   uint32_t n = 0;
-  if (b0 < nbytes) {
+  if (t < j.max_chunks && b0 < nbytes) {
     const uint8_t* p = reinterpret_cast<const uint8_t*>(j.stream) + b0;
     const uint32_t len = (uint32_t)(nbytes - b0 < kChunk ? nbytes - b0 : kChunk);
     for (uint32_t k = 0; k < len; ++k) n += p[k] == 0xFFu;
+    j.ff_count[t] = n;
   }
-  j.ff_count[t] = n;
+  const uint32_t total = Reduce(s_tmp).Sum(n);
+  if (threadIdx.x == 0u) j.ff_blk[blockIdx.x] = total;
 }
 // One workgroup = 256 chunks = 16 KiB of the packed stream.  Every thread expands its chunk into LDS (0x00 after each
 // 0xFF), then the workgroup writes the expanded run to the output as aligned dwords: the run's start in the output is
@@ -442,19 +448,28 @@ __global__ void __launch_bounds__(256) k_jpeg_stuff_count(const Job j, const uin
 // stores over 256 cache lines per instruction (28 us per 4K frame measured; this form: see DESIGN.md).
 __global__ void __launch_bounds__(256) k_jpeg_stuff_copy(const Job j, const uint64_t* total_bits, uint8_t* out, uint64_t out_cap,
                                                          uint64_t header_len, uint64_t* out_size) {
+  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
+  typedef hipcub::BlockScan<uint32_t, 256> Scan;
+  __shared__ union { typename Reduce::TempStorage reduce; typename Scan::TempStorage scan; } s_tmp;
   __shared__ uint8_t s_buf[256 * kChunk * 2 + 8];
-  __shared__ uint32_t s_len;
+  __shared__ uint32_t s_len, s_base;
   const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
   const uint64_t nbytes = (*total_bits + 7u) >> 3;
   const uint64_t blk_b0 = (uint64_t)first * kChunk;
   if (blk_b0 >= nbytes) return;                       // uniform per workgroup
-  const uint32_t base_ff = j.ff_off[first];
-  const uint64_t b0 = (uint64_t)t * kChunk;
-  if (threadIdx.x == 0) s_len = 0u;
+  uint32_t before = 0;
+  for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 256u) before += j.ff_blk[g];
+  before = Reduce(s_tmp.reduce).Sum(before);
+  if (threadIdx.x == 0) { s_len = 0u; s_base = before; }
   __syncthreads();
-  if (t < j.max_chunks && b0 < nbytes) {
+  const uint32_t base_ff = s_base;
+  const uint64_t b0 = (uint64_t)t * kChunk;
+  const bool mine = t < j.max_chunks && b0 < nbytes;
+  uint32_t ff_before = 0;
+  Scan(s_tmp.scan).ExclusiveSum(mine ? j.ff_count[t] : 0u, ff_before);
+  if (mine) {
     const uint32_t len = (uint32_t)(nbytes - b0 < kChunk ? nbytes - b0 : kChunk);
-    uint32_t lo = (uint32_t)(b0 - blk_b0) + (j.ff_off[t] - base_ff);
+    uint32_t lo = (uint32_t)(b0 - blk_b0) + ff_before;
     const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(j.stream) + b0);
 #pragma unroll
     for (uint32_t q = 0; q < kChunk / 16u; ++q) {
@@ -512,12 +527,11 @@ size_t workspace_bytes(uint32_t nblk, Layout* l) {
   l->stream = o; o += l->stream_bytes;
   l->max_chunks = (uint32_t)(l->stream_bytes / kChunk);
   l->ff_count = o; o += up((size_t)l->max_chunks * 4);
-  l->ff_off = o; o += up((size_t)(l->max_chunks + 1) * 4);
+  l->ff_blk = o; o += up((size_t)(l->max_chunks / 256u + 2) * 4);
   l->totals = o; o += 256;   // [0] total bits (uint64), [1] output size (uint64)
-  size_t t1 = 0, t2 = 0;
+  size_t t1 = 0;
   (void)scan_bits(nullptr, t1, nullptr, nullptr, nblk + 1, nullptr);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)(l->max_chunks + 1));
-  l->scan_tmp_bytes = up((t1 > t2 ? t1 : t2) + 256);
+  l->scan_tmp_bytes = up(t1 + 256);
   l->scan_tmp = o; o += l->scan_tmp_bytes;
   return o;
 }
@@ -528,7 +542,7 @@ hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint6
   j.bit_off = reinterpret_cast<uint64_t*>(ws + l.bit_off);
   j.stream = reinterpret_cast<uint32_t*>(ws + l.stream);
   j.ff_count = reinterpret_cast<uint32_t*>(ws + l.ff_count);
-  j.ff_off = reinterpret_cast<uint32_t*>(ws + l.ff_off);
+  j.ff_blk = reinterpret_cast<uint32_t*>(ws + l.ff_blk);
   j.max_chunks = l.max_chunks;
   uint64_t* totals = reinterpret_cast<uint64_t*>(ws + l.totals);
   hipError_t e;
@@ -542,8 +556,6 @@ hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint6
   hipLaunchKernelGGL(k_jpeg_emit, gb, bb, 0, s, j);
   const dim3 gc((j.max_chunks + 255u) / 256u), bc(256);
   hipLaunchKernelGGL(k_jpeg_stuff_count, gc, bc, 0, s, j, total_bits);
-  tmp = l.scan_tmp_bytes;
-  if ((e = hipcub::DeviceScan::ExclusiveSum(ws + l.scan_tmp, tmp, j.ff_count, j.ff_off, (int)j.max_chunks, s)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_jpeg_stuff_copy, gc, bc, 0, s, j, total_bits, out, out_cap, header_len, out_size != nullptr ? out_size : totals + 1);
   return hipGetLastError();
 }

@@ -777,9 +777,10 @@ static BatchLayout batch_layout(int n, const DecLayout l[]) {
   B.n_kept = B.n_sub = B.n_blk = 0;
   for (int k = 0; k < n; ++k) { B.n_kept += l[k].nchunks + 1u; B.n_sub += l[k].nsub_max + 1u; B.n_blk += l[k].nblk; }
   size_t o = 0;
-  B.jobs = o; o += up((size_t)n * sizeof(DecBatchJob));
+  B.jobs = o; o += (size_t)n * sizeof(DecBatchJob);        // the jobs and, right behind them, the three offset tables: one upload
+  B.offs = o; o += up((size_t)3 * (n + 1) * 4 + 256);
+  o = up(o);
   B.flags = o; o += up((size_t)n * kFlagWords * 4);
-  B.offs = o; o += up((size_t)3 * (n + 1) * 4);
   B.kept = o; o += up((size_t)B.n_kept * 4);
   B.kept_blk = o; o += up(((size_t)B.n_kept / 256u + (size_t)n + 1u) * 4);
   B.nblocks = o; o += up((size_t)B.n_sub * 4);
@@ -891,8 +892,7 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     gsync = std::max(gsync, (j.nsub + 255u) / 256u);
     gidct = std::max(gidct, (j.nblk + 127u) / 128u);
   }
-  JD_TRY(hipMemcpyAsync(djobs, jobs, (size_t)n * sizeof(DecBatchJob), hipMemcpyHostToDevice, s));
-  JD_TRY(hipMemcpyAsync(doffs, offs, noffs * 4, hipMemcpyHostToDevice, s));
+  JD_TRY(hipMemcpyAsync(djobs, jobs, (size_t)n * sizeof(DecBatchJob) + noffs * 4, hipMemcpyHostToDevice, s));   // jobs + offset tables (adjacent on both sides)
   if (!keep.empty()) JD_TRY(hipStreamSynchronize(s));   // restart tables are in pageable host memory
   JD_LAP("jobs assembled + uploaded");
   const SegOf sseg{doffs + (n + 1), n}, bseg{doffs + 2 * (n + 1), n};

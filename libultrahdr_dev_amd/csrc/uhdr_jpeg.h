@@ -25,14 +25,15 @@ struct Job {
   // workspace (device)
   int16_t* coef;           // nblk x 64, zigzag order
   uint32_t* bits;          // nblk (+1 zero)
-  uint64_t* bit_off;       // nblk + 1 (exclusive scan; [nblk] = total)
+  uint32_t* bits_blk;      // per workgroup of 128 blocks: their bits
+  uint64_t* total_bits;    // the stream's length in bits (written by k_jpeg_emit)
   uint32_t* stream;        // packed entropy-coded bits before byte stuffing, big-endian words
   uint32_t* ff_count;      // per 64-byte chunk of the stream
   uint32_t* ff_blk;
   uint32_t max_chunks;
 };
 struct Layout {
-  size_t coef, bits, bit_off, stream, stream_bytes, ff_count, ff_blk, totals, scan_tmp, scan_tmp_bytes;
+  size_t coef, bits, bits_blk, stream, stream_bytes, ff_count, ff_blk, totals, scan_tmp, scan_tmp_bytes;
   uint32_t max_chunks;
 };
 

@@ -8,8 +8,8 @@
 //   k_jpeg_fdct_quant_count   one thread per 8x8 block (in entropy-coding order, dummy edge blocks included): level shift,
 //                       13-bit fixed-point FDCT, quantisation by rounded division -> 64 int16 in zigzag order; and, from the same
 //                       registers, DC difference + run/size symbols -> the block's number of bits
-//   (device-wide exclusive scan of the bit counts -> bit offset of every block)
-//   k_jpeg_emit         one thread per block: codes written MSB-first at the block's bit offset (whole words stored,
+//   k_jpeg_emit         one thread per block: its bit offset (the totals of the workgroups in front + a block scan), then its
+//                       codes written MSB-first there (whole words stored,
 //                       the two boundary words OR-ed atomically); the last block pads the final byte with ones
 //   k_jpeg_stuff_count  one thread per 64 bytes of the packed stream: number of 0xFF bytes (and per workgroup)
 //   k_jpeg_stuff_copy   one thread per 64 bytes: copy to the output with 0x00 stuffed after every 0xFF, EOI at the end
@@ -318,10 +318,21 @@ __device__ __forceinline__ int comp_of(const Job& j, uint32_t i) { return j.gray
 // in registers, the number of bits its Huffman code takes (the prefix sum of those is where k_jpeg_emit writes).  The DC code needs
 // the quantised DC of the component's previous block, which another thread computes: the islow DC is the plain sum of the 64
 // level-shifted samples (pass 1 scales the row sums by 4, pass 2 descales by 4: exact), so it is had from that block's 64 bytes.
+__device__ __forceinline__ uint32_t fdct_quant_count_block(const Job& j, const uint32_t i);
 __global__ void __launch_bounds__(128) k_jpeg_fdct_quant_count(const Job j) {
   const uint32_t i = blockIdx.x * 128u + threadIdx.x;
-  if (i == 0u) j.bits[j.nblk] = 0u;   // the scan's last input: its last output is then the total number of bits
-  if (i >= j.nblk) return;
+  typedef hipcub::BlockReduce<uint32_t, 128> Reduce;
+  __shared__ typename Reduce::TempStorage s_tmp;
+  uint32_t my_bits = 0;
+  if (i < j.nblk) my_bits = fdct_quant_count_block(j, i);
+  // bits_blk[g]: the bits of workgroup g's 128 blocks.  k_jpeg_emit needs the bit offset of every block: inside a workgroup a block
+  // scan, across workgroups the sum of the totals in front (a 4K frame has 1519), formed by every workgroup of the emit for itself
+  const uint32_t total = Reduce(s_tmp).Sum(my_bits);
+  if (threadIdx.x == 0u) j.bits_blk[blockIdx.x] = total;
+}
+
+// the work of one thread of k_jpeg_fdct_quant_count: block i's coefficients to memory, its number of bits returned
+__device__ __forceinline__ uint32_t fdct_quant_count_block(const Job& j, const uint32_t i) {
   const BlockRef b = locate(j, i);
   const Plane& p = j.plane[b.comp];
   const uint16_t* q = b.comp == 0 ? j.q_lum : j.q_chr;   // zigzag order
@@ -370,6 +381,7 @@ __global__ void __launch_bounds__(128) k_jpeg_fdct_quant_count(const Job j) {
   CountSink cs;
   walk_coefs(c, pred, 2 * chroma, 2 * chroma + 1, cs);
   j.bits[i] = cs.bits;
+  return cs.bits;
 }
 
 // MSB-first writer into a zero-initialised word buffer that other threads write next to: whole words are stored, the first
@@ -401,9 +413,22 @@ struct EmitSink {
 };
 
 __global__ void __launch_bounds__(128) k_jpeg_emit(const Job j) {
+  typedef hipcub::BlockReduce<uint64_t, 128> Reduce;
+  typedef hipcub::BlockScan<uint64_t, 128> Scan;
+  __shared__ union { typename Reduce::TempStorage reduce; typename Scan::TempStorage scan; } s_tmp;
+  __shared__ uint64_t s_base;
   const uint32_t i = blockIdx.x * 128u + threadIdx.x;
+  uint64_t before = 0;
+  for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 128u) before += j.bits_blk[g];
+  before = Reduce(s_tmp.reduce).Sum(before);
+  if (threadIdx.x == 0u) s_base = before;
+  __syncthreads();
+  const uint64_t my_bits = i < j.nblk ? j.bits[i] : 0u;
+  uint64_t in_front = 0;
+  Scan(s_tmp.scan).ExclusiveSum(my_bits, in_front);
   if (i >= j.nblk) return;
-  const uint64_t off = j.bit_off[i];
+  const uint64_t off = s_base + in_front;
+  if (i == j.nblk - 1u) *j.total_bits = off + my_bits;   // read by the stuffing kernels behind this one
   EmitSink s;
   s.words = j.stream;
   s.acc = 0;
@@ -413,7 +438,7 @@ __global__ void __launch_bounds__(128) k_jpeg_emit(const Job j) {
   const int chroma = comp_of(j, i);
   walk_block(j.coef + (size_t)i * 64u, pred_of(j, i), 2 * chroma, 2 * chroma + 1, s);
   if (i == j.nblk - 1u) {      // jchuff.c flush_bits: fill the last byte with ones
-    const uint64_t end = off + j.bits[i];
+    const uint64_t end = off + my_bits;
     const int pad = (int)((8u - (uint32_t)(end & 7u)) & 7u);
     if (pad) s.put((1u << pad) - 1u, pad);
   }
@@ -507,21 +532,12 @@ __global__ void __launch_bounds__(256) k_jpeg_stuff_copy(const Job j, const uint
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
-// widening scan input: bit counts are uint32, offsets uint64 (an 8K frame at quality 100 can exceed 2^32 bits)
-struct WidenU32 {
-  __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
-};
-static hipError_t scan_bits(void* tmp, size_t& tmp_bytes, const uint32_t* bits, uint64_t* off, uint32_t n, hipStream_t s) {
-  hipcub::TransformInputIterator<uint64_t, WidenU32, const uint32_t*> in(bits, WidenU32());
-  return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, off, (int)n, s);
-}
-
 size_t workspace_bytes(uint32_t nblk, Layout* l) {
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   size_t o = 0;
   l->coef = o; o += up((size_t)nblk * 128);
   l->bits = o; o += up((size_t)(nblk + 1) * 4);
-  l->bit_off = o; o += up((size_t)(nblk + 1) * 8);
+  l->bits_blk = o; o += up((size_t)(nblk / 128u + 2) * 4);
   // worst case per block: 20 bits of DC + 63 x 26 bits of AC = 1658 bits
   l->stream_bytes = up((size_t)nblk * 208 + 64);
   l->stream = o; o += l->stream_bytes;
@@ -529,17 +545,15 @@ size_t workspace_bytes(uint32_t nblk, Layout* l) {
   l->ff_count = o; o += up((size_t)l->max_chunks * 4);
   l->ff_blk = o; o += up((size_t)(l->max_chunks / 256u + 2) * 4);
   l->totals = o; o += 256;   // [0] total bits (uint64), [1] output size (uint64)
-  size_t t1 = 0;
-  (void)scan_bits(nullptr, t1, nullptr, nullptr, nblk + 1, nullptr);
-  l->scan_tmp_bytes = up(t1 + 256);
-  l->scan_tmp = o; o += l->scan_tmp_bytes;
+  l->scan_tmp_bytes = 0;
+  l->scan_tmp = o;
   return o;
 }
 
 hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint64_t out_cap, uint64_t header_len, hipStream_t s, uint64_t* out_size) {
   j.coef = reinterpret_cast<int16_t*>(ws + l.coef);
   j.bits = reinterpret_cast<uint32_t*>(ws + l.bits);
-  j.bit_off = reinterpret_cast<uint64_t*>(ws + l.bit_off);
+  j.bits_blk = reinterpret_cast<uint32_t*>(ws + l.bits_blk);
   j.stream = reinterpret_cast<uint32_t*>(ws + l.stream);
   j.ff_count = reinterpret_cast<uint32_t*>(ws + l.ff_count);
   j.ff_blk = reinterpret_cast<uint32_t*>(ws + l.ff_blk);
@@ -549,10 +563,8 @@ hipError_t encode_async(Job j, const Layout& l, uint8_t* ws, uint8_t* out, uint6
   if ((e = hipMemsetAsync(j.stream, 0, l.stream_bytes, s)) != hipSuccess) return e;
   const dim3 gb((j.nblk + 127u) / 128u), bb(128);
   hipLaunchKernelGGL(k_jpeg_fdct_quant_count, gb, bb, 0, s, j);
-  size_t tmp = l.scan_tmp_bytes;
-  // nblk + 1 items: the last output is the total number of bits
-  if ((e = scan_bits(ws + l.scan_tmp, tmp, j.bits, j.bit_off, j.nblk + 1u, s)) != hipSuccess) return e;
-  const uint64_t* total_bits = j.bit_off + j.nblk;
+  const uint64_t* total_bits = totals;   // written by the last thread of k_jpeg_emit
+  j.total_bits = totals;
   hipLaunchKernelGGL(k_jpeg_emit, gb, bb, 0, s, j);
   const dim3 gc((j.max_chunks + 255u) / 256u), bc(256);
   hipLaunchKernelGGL(k_jpeg_stuff_count, gc, bc, 0, s, j, total_bits);

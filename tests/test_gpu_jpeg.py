@@ -279,3 +279,32 @@ def test_random_files_decode_like_libjpeg(hip, orc, tmp_path):
     from tests import stress_jpeg_dec
     decoded, mismatches = stress_jpeg_dec.run(400, 3, dump_dir=str(tmp_path), damage=True)   # (each file also damaged: a status, never a fault)
     assert mismatches == 0 and decoded == 800
+
+
+def test_random_images_encode_like_libjpeg(hip, orc):
+    """250 random images (2x2 to 1500x900, tight / aligned / padded / odd strides, qualities 1-100, noise / smooth / extreme / flat
+    content, colour and single-plane, device and host memory): the device encoder's bytes equal the CPU restatement's (which
+    tests/test_jpeg_oracle.py pins to libjpeg).  Written when the bit counts moved into the DCT kernel and the two prefix sums into
+    the kernels that consume them."""
+    lib = hip.load()
+    import os
+    rng = np.random.RandomState(int(os.environ.get("UHDR_ENC_SWEEP_SEED", "21")))
+    kinds = ["smooth", "noise", "extreme", "flat"]
+    for it in range(int(os.environ.get("UHDR_ENC_SWEEP", "250"))):   # (UHDR_ENC_SWEEP=8000 is the long form: no mismatch)
+        big = rng.rand() < 0.06
+        w = 2 * rng.randint(1, 750 if big else 100)
+        h = 2 * rng.randint(1, 450 if big else 80)
+        kind = kinds[rng.randint(0, 4)]
+        y, u, v = _content(kind, w, h, rng)
+        aw, acw = (w + 15) // 16 * 16, (w // 2 + 7) // 8 * 8
+        ls, cs = [(w, w // 2), (aw, acw), (aw + 16, acw + 8), (w + 2, w // 2 + 1)][rng.randint(0, 4)]
+        yb, ub = _planes(y, u, v, ls, cs, rng)
+        q = int(rng.choice([rng.randint(1, 101), 95, 100, 85, 50]))
+        device = bool(rng.randint(0, 2))
+        if rng.rand() < 0.25:
+            rc, n, got = _gpu_encode(lib, hip, yb, None, w, h, q, ls, 0, device)
+            want = orc.jpeg_encode("orc", yb, None, w, h, q, ls)
+        else:
+            rc, n, got = _gpu_encode(lib, hip, yb, ub, w, h, q, ls, cs, device)
+            want = orc.jpeg_encode("orc", yb, ub, w, h, q, ls, cs)
+        assert rc == 0 and n == len(want) and got == want, (it, kind, w, h, ls, cs, q, device, n, len(want))

@@ -1,0 +1,10 @@
+#!/bin/bash
+# The long forms of the randomized GPU tests (run on the GPU box from the repo root; ~4 minutes):
+#   decoder: 20000 random files (oracle encoder + libjpeg-turbo through Pillow, restart intervals, optimised tables) against libjpeg,
+#            then 6000 more each also as a damaged copy (statuses only, never a fault)
+#   encoder: 8000 random images against the CPU restatement of libjpeg
+# Last run (round 1, final build): 40 000 + 12 000 identical decodes, 0 mismatches; 8000 identical encodes.
+set -e
+python tests/stress_jpeg_dec.py 20000 11
+python tests/stress_jpeg_dec.py 6000 23 damage
+UHDR_ENC_SWEEP=8000 UHDR_ENC_SWEEP_SEED=5 python -m pytest tests/test_gpu_jpeg.py -x -q -k random_images

@@ -143,6 +143,19 @@ int main(int argc, char** argv) {
         }
       }
       v.push_back(0xFF); v.push_back(0xD9);
+      {   // the walk the container scan uses (RSTn skipped whether or not a DRI was seen), against the same walk byte by byte
+        size_t e = hdr.scan_offset;
+        for (;;) {
+          while (e + 1 < v.size() && v[e] != 0xFF) ++e;
+          if (e + 1 >= v.size()) { e = v.size(); break; }
+          const uint8_t b = v[e + 1];
+          if (b == 0x00 || (b & 0xF8) == 0xD0) { e += 2; continue; }
+          if (b == 0xFF) { e += 1; continue; }
+          break;
+        }
+        const size_t got = jpeg::skip_entropy_coded(v.data(), hdr.scan_offset, v.size());
+        if (got != e) { fprintf(stderr, "skip_entropy_coded: %zu, byte walk %zu\n", got, e); abort(); }
+      }
       jpeg::DecInfo info;
       const int prc = jpeg::parse_header(v.data(), v.size(), &info);
       size_t sb = 0; uint32_t rb = 0; std::vector<uint32_t> st;

@@ -186,14 +186,16 @@ __device__ __forceinline__ void build_lut_body(const DecTables& t, uint32_t* lut
   uint32_t a = kLongEntry;
   if (e != 0u) {
     a = adv_entry(tb, e >> 8, e & 0xFFu);
-    // An AC symbol that does not end the block is followed by another code of the same table: when that one lies inside the
-    // pattern too, the upper half of the entry is the pair (bits and index advance of both); decode_positions takes it when the first
-    // symbol neither fills the block nor crosses the subsequence's end.  Two symbols per table lookup where the codes are short.
+    // A symbol that does not end the block is followed by an AC code of the same component -- the same table behind an AC symbol,
+    // the AC table next to it behind a DC difference: when that code lies inside the pattern too, the upper half of the entry is the
+    // pair (bits and index advance of both); decode_positions takes it when the first symbol neither fills the block nor crosses the
+    // subsequence's end.  Two symbols per table lookup where the codes are short; a block of a flat area (DC difference, EOB) is one.
     const uint32_t bits1 = (a >> 8) & 31u, dz1 = a & 127u;
-    if ((tb & 1u) != 0u && dz1 < 64u && bits1 < kFastBitsEarly) {
-      const uint32_t e2 = short_code(h, (x << bits1) & ((1u << kFastBitsEarly) - 1u), kFastBitsEarly - bits1);
+    const uint32_t tb2 = tb | 1u;
+    if (dz1 < 64u && bits1 < kFastBitsEarly && t.huff[tb2].present) {
+      const uint32_t e2 = short_code(t.huff[tb2], (x << bits1) & ((1u << kFastBitsEarly) - 1u), kFastBitsEarly - bits1);
       if (e2 != 0u) {
-        const uint32_t a2 = adv_entry(tb, e2 >> 8, e2 & 0xFFu);
+        const uint32_t a2 = adv_entry(tb2, e2 >> 8, e2 & 0xFFu);
         const uint32_t bits = bits1 + ((a2 >> 8) & 31u);
         // (a step may consume 32 bits at most: the window is refilled one word at a time)
         if (bits <= 32u) a |= ((bits << 8) | (dz1 + (a2 & 127u))) << 16;   // advance <= 16 + 64: 7 bits

@@ -279,6 +279,91 @@ bool gen_aligned(const GenImage& g, uint32_t w, uint32_t h) {
          al(g.y, 8) && g.y_stride % 8u == 0 && al(g.u, 4) && al(v, 4) && g.c_stride % 4u == 0 && al(g.map, 2);
 }
 
+// ---- FAST apply's line-segment tables (uhdr_kernels.h, k_apply_s4) ---------------------------------
+// An entry is the chord of the function over its cell, lowered by half its largest deviation, as (c0, c1): f ~ c0 + c1 * argument.
+template <class F>
+void chord(F f, double lo, double hi, double* c0, double* c1) {
+  *c1 = (f(hi) - f(lo)) / (hi - lo);
+  *c0 = f(lo) - *c1 * lo;
+  double dev = 0.0;
+  for (int k = 1; k < 32; ++k) { const double x = lo + (hi - lo) * k / 32.0; const double d = f(x) - (*c0 + *c1 * x); if (std::fabs(d) > std::fabs(dev)) dev = d; }
+  *c0 += 0.5 * dev;
+}
+// Stage 1: T(c) = srgbInvOetf(c)^g (gainmapmath.cpp:149-155).  Cell j holds the arguments whose half-precision conversion, rounded
+// toward zero, has the bits j << 3 | 0..7: e = j >> 7, m = j & 127: [2^(e-15) (1 + m/128), 2^(e-15) (1 + (m+1)/128)) for e >= 1, the
+// subnormal slots [m, m+1) 2^-21 for e = 0 (no input of the kernel other than 0 falls below 2^-17: (y + k dv) / 255).
+void f16_cell(uint32_t j, double* lo, double* hi) {
+  const uint32_t e = j >> 7, m = j & 127u;
+  if (e == 0) { *lo = std::ldexp((double)m, -21); *hi = std::ldexp((double)(m + 1u), -21); return; }
+  *lo = std::ldexp(1.0 + m / 128.0, (int)e - 15);
+  *hi = std::ldexp(1.0 + (m + 1u) / 128.0, (int)e - 15);
+}
+// ... and for g < 1 the arguments whose own bits 30..19 are j: e = j >> 4, m = j & 15: [2^(e-127) (1 + m/16), 2^(e-127) (1 + (m+1)/16))
+// for e >= 1, the subnormal slots [m, m+1) 2^-130 for e = 0.
+void f32_cell16(uint32_t j, double* lo, double* hi) {
+  const uint32_t e = j >> 4, m = j & 15u;
+  if (e == 0) { *lo = std::ldexp((double)m, -130); *hi = std::ldexp((double)(m + 1u), -130); return; }
+  *lo = std::ldexp(1.0 + m / 16.0, (int)e - 127);
+  *hi = std::ldexp(1.0 + (m + 1u) / 16.0, (int)e - 127);
+}
+void build_stage1(double g, float* out) {
+  const double thr = (double)0.04045f;
+  auto eotf = [&](double x) { return x <= thr ? x / (double)12.92f : std::pow((x + (double)0.055f) / (double)1.055f, 2.4); };
+  auto f = [&](double x) { return g == 1.0 ? eotf(x) : std::pow(eotf(x), g); };
+  const uint32_t cells = (g == 1.0 ? kTabS1Bytes : kTabS1PowBytes) / 8u;
+  for (uint32_t j = 0; j < cells; ++j) {
+    double lo, hi, c0, c1;
+    if (g == 1.0) f16_cell(j, &lo, &hi); else f32_cell16(j, &lo, &hi);
+    if (g == 1.0 && hi <= thr) { c0 = 0.0; c1 = 1.0 / (double)12.92f; }
+    else if (lo >= 1.0) { c0 = 1.0; c1 = 0.0; }
+    else if (j == 0) { c0 = 0.0; c1 = f(hi) / hi; }   // T(0) = 0 exactly
+    else chord(f, lo, hi, &c0, &c1);
+    out[2 * j] = (float)c0; out[2 * j + 1] = (float)c1;
+  }
+}
+// Stage 2: the 10-bit code (colorToRgba1010102, gainmapmath.cpp:722-727: truncation of OETF * 1023) as a function of
+// s = 2 + 2u, cell k = [2 + k/64, 2 + (k+1)/64), cell 128 = s >= 4 (u = 1, nothing above it is reached).  The entry evaluates
+// to -(2 + code 2^-22); the kernel's fma rounds toward zero, i.e. truncates the code, and the bits of the result are
+// 0xC0000000 | code.  c0 must then be a whole number of half codes (an ulp of [1, 2) is 2^-23), so its fraction is moved into the
+// slope: that tilts the line by < 0.002 codes over a cell (the argument stays within 1/256 of the cell's middle, relatively).
+// A line never evaluates below 0 (the result would leave the [2, 4) binade): cell 0 passes through (2, 0) exactly.
+template <class F>
+void build_stage2(F code_of_u, float* out) {
+  for (uint32_t k = 0; k < kTabS2Cells; ++k) {
+    const double lo = 2.0 + k / 64.0, hi = 2.0 + (k + 1u) / 64.0;
+    auto f = [&](double s) { return code_of_u(std::min(1.0, 0.5 * (s - 2.0))); };
+    float c0f = -2.0f, c1f = 0.0f;                       // a cell whose codes all truncate to 0
+    if (k == kTabS2Cells - 1u) c0f = (float)(-2.0 - std::ldexp(1023.0, -22));
+    else if (f(hi) >= 0.99) {
+      double c0, c1;
+      chord(f, lo, hi, &c0, &c1);
+      c0 += 1.0 / 256.0;                                 // margin: the line stays above 0 after the steps below
+      // -2 - n 2^-22 must be a float: n a whole number of codes when the magnitude is in [2, 4), of half codes when in [1, 2)
+      const double n = c0 < 0.0 ? std::nearbyint(2.0 * c0) / 2.0 : std::nearbyint(c0);
+      c1 += (c0 - n) / (0.5 * (lo + hi));
+      c0f = (float)(-2.0 - std::ldexp(n, -22));
+      c1f = (float)(-std::ldexp(c1, -22));
+      auto at = [&](double s) { return -(((double)c1f * s + (double)c0f) + 2.0) * 4194304.0; };
+      for (int it = 0; it < 4096 && at(lo) < 0.0; ++it) c1f = std::nextafter(c1f, -INFINITY);
+      if (at(lo) < 0.0) { c0f = -2.0f; c1f = 0.0f; }
+    }
+    out[2 * k] = c0f; out[2 * k + 1] = c1f;
+  }
+}
+void build_line_tables(std::vector<float>& tab) {
+  tab.assign(kLutBufferFloats - kTabS1Lin, 0.0f);
+  const double m1 = (double)(2610.0f / 16384.0f), m2 = (double)(2523.0f / 4096.0f * 128.0f);
+  const double k1 = (double)(3424.0f / 4096.0f), k2 = (double)(2413.0f / 4096.0f * 32.0f), k3 = (double)(2392.0f / 4096.0f * 32.0f);
+  build_stage1(1.0, tab.data() + (kTabS1Lin - kTabS1Lin));
+  build_stage1(0.5, tab.data() + (kTabS1Hlg - kTabS1Lin));
+  build_stage1(m1, tab.data() + (kTabS1Pq - kTabS1Lin));
+  // HLG OETF (gainmapmath.cpp:257-267) of x = u^2; PQ OETF (:305-314) of x = u^(1/m1), i.e. of p = u directly
+  auto hlg = [](double u) { const double x = u * u; return 1023.0 * (x <= 1.0 / 12.0 ? std::sqrt(3.0) * u : (double)0.17883277f * std::log(12.0 * x - (double)0.28466892f) + (double)0.55991073f); };
+  auto pq = [&](double p) { return p <= 0.0 ? 0.0 : 1023.0 * std::pow((k1 + k2 * p) / (1.0 + k3 * p), m2); };
+  build_stage2(hlg, tab.data() + (kTabS2Hlg - kTabS1Lin));
+  build_stage2(pq, tab.data() + (kTabS2Pq - kTabS1Lin));
+}
+
 // ---- apply ---------------------------------------------------------------------------------------
 // checks of ultrahdr.cpp:364-406 in order
 int validate_apply(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* map, const uhdr_hip_metadata_t* md,
@@ -319,16 +404,20 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
   c.idw = idw;
   c.lut = nullptr;
   c.lut_boost_factor = c.display_boost > 0 ? c.display_boost / md.maxContentBoost : 1.0f;  // gainmapmath.h:162
-  // FAST scale-4 kernel: factor/display_boost = 2^(gain*A + B); weights pre-multiplied by A (k_apply_s4)
+  // FAST scale-4 kernel: factor/display_boost = 2^(gain*A + B); weights pre-multiplied by A / 255 (k_apply_s4)
   const double ratio = (double)c.display_boost / (double)md.maxContentBoost;
   c.fast.A = (float)((c.log2_max_d - c.log2_min_d) * ratio);
   c.fast.B = (float)(c.log2_min_d * ratio - std::log2((double)c.display_boost));
+  c.fast.A255 = (float)((c.log2_max_d - c.log2_min_d) * ratio / 255.0);
   std::vector<float> t;
   build_idw_tables(4, t);
   for (int oy = 0; oy < 4; ++oy)
     for (int pr = 0; pr < 2; ++pr)
-      for (int k = 0; k < 4; ++k)
-        for (int j = 0; j < 2; ++j) c.fast.wA[oy][pr][k][j] = t[oy * 16 + (2 * pr + j) * 4 + k] * c.fast.A;
+      for (int k = 1; k < 4; ++k)
+        for (int j = 0; j < 2; ++j)
+          c.fast.wD[oy][pr][k - 1][j] = (float)((double)t[oy * 16 + (2 * pr + j) * 4 + k] * (c.log2_max_d - c.log2_min_d) * ratio / 255.0);
+  c.tab = nullptr;
+  c.cells_per_thread = 8;
   return c;
 }
 AppImage app_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map, void* dst) {
@@ -459,20 +548,9 @@ int uhdr_hip_init(int device) {
     HIP_TRY(hipMalloc(&st.lut, sizeof(float) * kLutBufferFloats));
     HIP_TRY(launch_build_luts(st.lut, nullptr));
     {
-      // FAST apply's sRGB EOTF (gainmapmath.cpp:149-155) as line segments: cell j holds the x with round(x * 32767) >> 3 == j,
-      // i.e. [(8j - 0.5) / 32767, (8j + 7.5) / 32767); the chord, lowered by half its largest deviation (the function is convex
-      // on a cell but for the one holding the junction), evaluated as c0 + c1 * x
-      std::vector<float> line(2 * kSrgbLineCells);
-      auto f = [](double x) { return x <= (double)0.04045f ? x / (double)12.92f : std::pow((x + (double)0.055f) / (double)1.055f, 2.4); };
-      for (uint32_t j = 0; j < kSrgbLineCells; ++j) {
-        const double lo = std::max(0.0, (8.0 * j - 0.5) / 32767.0), hi = std::min(1.0, (8.0 * j + 7.5) / 32767.0);
-        const double c1 = (f(hi) - f(lo)) / (hi - lo);
-        double c0 = f(lo) - c1 * lo, dev = 0.0;
-        for (int k = 1; k < 16; ++k) { const double x = lo + (hi - lo) * k / 16.0; const double d = f(x) - (c0 + c1 * x); if (std::fabs(d) > std::fabs(dev)) dev = d; }
-        c0 += 0.5 * dev;
-        line[2 * j] = (float)c0; line[2 * j + 1] = (float)c1;
-      }
-      HIP_TRY(hipMemcpy(st.lut + kSrgbLine, line.data(), line.size() * sizeof(float), hipMemcpyHostToDevice));
+      std::vector<float> tab;
+      build_line_tables(tab);
+      HIP_TRY(hipMemcpy(st.lut + kTabS1Lin, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(jpeg::upload_tables());
@@ -1618,7 +1696,7 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
     if ((rc = idw_for_scale(st, scale, &idw)) != UHDR_HIP_NO_ERROR) return rc;
     AppConsts c = apply_consts(y0, m0, *metadata, max_display_boost, idw);
     c.lut = apply_mode == UHDR_HIP_APPLY_LUT ? st->lut : nullptr;
-    c.srgb_line = st->lut + kSrgbLine;
+    c.tab = st->lut;
     AppBatch b;
     int m = 0;
     bool fast = true;

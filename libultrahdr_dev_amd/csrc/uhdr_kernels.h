@@ -12,9 +12,28 @@ constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4
 constexpr uint32_t kLutSrgbInvN = 1024, kLutHlgInvN = 4096, kLutPqInvN = 4096, kLutHlgN = 65536, kLutPqN = 65536;
 constexpr uint32_t kLutSrgbInv = 0, kLutHlgInv = kLutSrgbInv + kLutSrgbInvN, kLutPqInv = kLutHlgInv + kLutHlgInvN,
                    kLutHlg = kLutPqInv + kLutPqInvN, kLutPq = kLutHlg + kLutHlgN, kLutTotal = kLutPq + kLutPqN;
-// FAST apply only (not one of the reference's tables): the sRGB EOTF as 4096 line segments (c0, c1), cell = round(x * 32767) >> 3,
-// appended to the LUT buffer by uhdr_hip_init (see k_apply_s4)
-constexpr uint32_t kSrgbLineCells = 4096, kSrgbLine = kLutTotal, kLutBufferFloats = kLutTotal + 2 * kSrgbLineCells;
+// FAST apply only (not the reference's tables): transfer functions as line segments (c0, c1), 8 bytes per cell (k_apply_s4).
+// A channel is  code = OETF(EOTF_sRGB(c) * F) * 1023  with F = 2^E the gain factor.  Both OETFs are smooth, nearly linear
+// functions of a POWER of their argument -- HLG of u = sqrt(x) (exactly linear below its junction), PQ of u = x^m1 (a rational
+// function) -- so the path is  u = T(c) * 2^(g E),  T = EOTF^g  (g = 1/2 for HLG, m1 for PQ, 1 for the linear formats):
+//   stage 1  T(c):     cell = the float's own exponent and top 4 mantissa bits (16 cells per octave: the sRGB toe makes T
+//                      singular at 0, cells that follow the exponent hold a power law to a constant relative error, 6e-5 here);
+//                      `(bits >> 16) & 0x7FF8` -- one SDWA v_and -- is the byte offset of the entry as it stands.  Every octave
+//                      from the subnormals up to 1.0 has its cells (16 KiB), the pixels use the top few: 1-2 entries per bank.
+//                      For g = 1 (linear output formats, calls whose values may pass 1.0) 16 cells per octave are too coarse:
+//                      that table takes its cell from the HALF-PRECISION bit pattern of c (bits 14..3: 128 cells per octave).
+//   stage 2  code(u):  129 UNIFORM cells over 2 + 2u in [2, 4] -- the cell is byte 2 of the float itself -- each entry
+//                      replicated into 32 lane slots in LDS (cell * 256 + (lane & 31) * 8): no bank conflicts whatever the data.
+//                      The entry evaluates to -(2 + n 2^-22), n the integer code (the kernel rounds toward zero), whose bits are
+//                      0xC0000000 | n: red as it stands (alpha included), green and blue after a shift that drops the upper bits.
+// Appended to the LUT buffer by uhdr_hip_init; byte sizes are multiples of 16.
+constexpr uint32_t kTabS1Bytes = 0x3C00 + 16;                    // g = 1, half-precision cells up to 1.0
+constexpr uint32_t kTabS1PowBytes = 127u * 128u + 16u;           // g < 1, float cells up to 1.0 (exponent 127, mantissa 0)
+constexpr uint32_t kTabS2Cells = 129, kTabS2Floats = 260;        // 129 x (c0, c1), padded
+constexpr uint32_t kTabS2LdsBytes = kTabS2Cells * 256u;          // replicated
+constexpr uint32_t kTabS1Lin = kLutTotal, kTabS1Hlg = kTabS1Lin + kTabS1Bytes / 4, kTabS1Pq = kTabS1Hlg + kTabS1PowBytes / 4,
+                   kTabS2Hlg = kTabS1Pq + kTabS1PowBytes / 4, kTabS2Pq = kTabS2Hlg + kTabS2Floats,
+                   kLutBufferFloats = kTabS2Pq + kTabS2Floats;
 constexpr uint32_t kGainLutN = 1024;  // kGainFactorNumEntries, gainmapmath.h:149-150
 
 // ---- generate ----------------------------------------------------------------------------------
@@ -58,18 +77,20 @@ struct GenBatch {
 };
 
 // ---- apply -------------------------------------------------------------------------------------
-// constants of the FAST scale-4 kernel (see k_apply_s4): wA[oy][pair][k] = (w_k(ox=2*pair), w_k(ox=2*pair+1)) * A
+// constants of the FAST scale-4 kernel (see k_apply_s4): wD[oy][pair][k-2] = (w_k(ox=2*pair), w_k(ox=2*pair+1)) * A / 255
+// E = B + A255 * m1 + sum_{k=2..4} (m_k - m1) * wD[.][.][k-2][.]   (m: the four map bytes as floats; the weights of a cell sum to 1)
 struct AppFast {
-  float A, B;
-  float wA[4][2][4][2];
+  float A, B, A255;
+  float wD[4][2][3][2];
 };
 struct AppConsts {
   uint32_t width, height, map_w, map_h, scale;
+  uint32_t cells_per_thread;      // k_apply_s4: map cells a thread walks (set by launch_apply from the size of the launch)
   float display_boost, inv_display_boost, max_boost, inv_max_boost;
   double log2_min_d, log2_max_d;  // log2((double)minContentBoost), log2((double)maxContentBoost)
   const float* idw;               // device: 4 tables (std, NR, NB, C) of scale*scale*4 floats
   const float* lut;               // device LUT buffer (LUT mode only)
-  const float* srgb_line;         // device: kSrgbLineCells x (c0, c1), FAST scale-4 kernel
+  const float* tab;               // device: the LUT buffer (line-segment tables at kTabS1* / kTabS2*), FAST scale-4 kernel
   float lut_boost_factor;         // GainLUT(metadata, displayBoost): displayBoost > 0 ? displayBoost / max : 1 (gainmapmath.h:162)
   AppFast fast;
 };

@@ -781,48 +781,94 @@ __device__ __forceinline__ f2 srgb_eotf2(f2 e) {
   return pk_fma(x * x, t, lin);
 }
 
-// The same two values from the line-segment table in LDS (AppConsts::srgb_line): the EOTF's log2 + exp2 per value is half of
-// this kernel's special-function issue, and the LDS pipe is otherwise idle.  v_cvt_pknorm_i16_f32 turns BOTH clamped inputs into
-// round(x * 32767) in one issue slot; bits 14..3 of each half are the cell and, as they stand, the byte offset of its (c0, c1)
-// pair: one v_and each (the upper half through SDWA's WORD_1 select), one ds_read_b64 and one fma per value.
-// |error| <= 2e-8 absolute (cell width 2^-12, f'' <= 2.3): below the f32 rounding of the result.
-#ifndef UHDR_APPLY_SRGB_LDS
-#define UHDR_APPLY_SRGB_LDS 1
-#endif
-#ifndef UHDR_APPLY_CELLS
-#define UHDR_APPLY_CELLS (UHDR_APPLY_SRGB_LDS ? 8 : 1)
-#endif
-__device__ __forceinline__ f2 srgb_eotf2_lds(f2 e, const char* lut) {
-  typedef short s2 __attribute__((ext_vector_type(2)));
-  const s2 q = __builtin_amdgcn_cvt_pknorm_i16(e.x, e.y);
+// ---- transfer functions as line segments in LDS ---------------------------------------------------
+// Both transfer functions of a channel -- the sRGB EOTF in front of the gain, the HLG / PQ OETF behind it -- cost 13 (PQ: 22)
+// special-function evaluations per pixel on the VALU; they are read from line-segment tables in LDS instead (the LDS pipe is
+// otherwise idle in this kernel).  What bounds a table in LDS is not its size but bank conflicts: 32 lanes reading 32 random
+// 8-byte entries take 3-4 cycles instead of 1, and six such gathers per pixel made the LDS the bottleneck (PMC: 2/3 of its
+// cycles were conflicts).  So the path is arranged for ONE conflicting gather per value (uhdr_kernels.h has the arithmetic):
+//   stage 1: T(c) = EOTF(c)^g.  Cell = bits 14..3 of the half-precision bit pattern of c: v_cvt_pkrtz_f16_f32 converts two
+//     values in one issue slot, one v_and each (the upper half through SDWA's WORD_1 select) gives the byte offset of the
+//     8-byte (c0, c1) entry as it stands; one ds_read_b64, one fma.  Shared table, 15 KiB, conflicts as they come.
+//   u = T * 2^(g E) is formed as s = 2 + 2u by one packed fma; s lies in [2, 4], so byte 2 of its bit pattern IS the number of
+//     its 1/128-wide cell: v_perm_b32 puts that byte next to the lane's slot number -- the address of a private copy of the
+//     entry (cell * 256 + (lane & 31) * 8).  32 lanes, 32 different bank pairs: no conflict whatever the pixels hold.
+//   stage 2: the fma on that entry yields -(2 + code 2^-22) rounded toward zero (the kernel runs in that rounding mode), whose
+//     bits are 0xC0000000 | code: the pixel is two v_lshl_or_b32 of the three results.
+// Errors: stage 1 <= 2e-6 relative; stage 2 <= 0.05 codes next to the HLG junction, <= 0.01 elsewhere and for PQ
+// (tests/test_gpu_apply_tables.py measures both for every float).
+// byte offset of the cell of one value (diagnostics; the kernel converts two at a time)
+__device__ __forceinline__ uint32_t tab_offset(float x) {
+  typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+  const h2 q = __builtin_amdgcn_cvt_pkrtz(x, 0.0f);
+  return __builtin_bit_cast(uint32_t, q) & 0x7FF8u;
+}
+// stage-1 tables for g < 1: the byte offset of a value's cell is its own bits 30..19, in place: one SDWA v_and
+__device__ __forceinline__ uint32_t pow_offset(float x) {
+  uint32_t off;
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(0x7FF8u), "v"(x));
+  return off;
+}
+__device__ __forceinline__ void pow_pair(f2 x, const char* lut, float2& a, float2& b) {
+  a = *reinterpret_cast<const float2*>(lut + pow_offset(x.x));
+  b = *reinterpret_cast<const float2*>(lut + pow_offset(x.y));
+}
+template <uint32_t BASE>
+__device__ __forceinline__ void tab_pair(f2 x, const char* lut, float2& a, float2& b) {
+  typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+  const h2 q = __builtin_amdgcn_cvt_pkrtz(x.x, x.y);
   const uint32_t d = __builtin_bit_cast(uint32_t, q);
   uint32_t hi_off;
   asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(hi_off) : "v"(0x7FF8u), "v"(d));
-  const float2 a = *reinterpret_cast<const float2*>(lut + (d & 0x7FF8u));
-  const float2 b = *reinterpret_cast<const float2*>(lut + hi_off);
-  // two plain fmas on purpose (asm: the vectoriser would re-pack them behind three v_movs that shuffle the operands into pairs)
+  a = *reinterpret_cast<const float2*>(lut + BASE + (d & 0x7FF8u));
+  b = *reinterpret_cast<const float2*>(lut + BASE + hi_off);
+}
+// c0 + c1 * x for both values.  Two plain fmas on purpose (asm: the vectoriser would re-pack them behind three v_movs that shuffle
+// the operands into pairs)
+template <uint32_t BASE>
+__device__ __forceinline__ f2 tab_eval2(f2 x, const char* lut) {
+  float2 a, b;
+  tab_pair<BASE>(x, lut, a, b);
   f2 o;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.x) : "v"(a.y), "v"(e.x), "v"(a.x));
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.y) : "v"(b.y), "v"(e.y), "v"(b.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.x) : "v"(a.y), "v"(x.x), "v"(a.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.y) : "v"(b.y), "v"(x.y), "v"(b.x));
+  return o;
+}
+// stage 2 on s = 2 + 2u (both values): the lane's private copy of the cell's entry sits at byte2(s) * 256 + slot8
+__device__ __forceinline__ uint32_t s2_address(float s, uint32_t slot8) {
+  return __builtin_amdgcn_perm(__float_as_uint(s), slot8, 0x0C0C0600u);   // {0, 0, s.byte2, slot8.byte0}
+}
+__device__ __forceinline__ f2 code_eval2(f2 s, uint32_t slot8, const char* lut) {   // lut: the stage-2 table
+  const float2 a = *reinterpret_cast<const float2*>(lut + s2_address(s.x, slot8));
+  const float2 b = *reinterpret_cast<const float2*>(lut + s2_address(s.y, slot8));
+  f2 o;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.x) : "v"(a.y), "v"(s.x), "v"(a.x));
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o.y) : "v"(b.y), "v"(s.y), "v"(b.x));
   return o;
 }
 
-// OETF of two linear values, scaled to 10-bit code units where the format is 10 bit.  UNBOUNDED: the inputs
-// may exceed 1.0 (max_display_boost < maxContentBoost), so max(e, j) - j cannot be had from a [0,1] clamp and
-// the HLG junction is selected per lane instead.
-template <int FMT, bool UNBOUNDED>
+// LDS layout of the kernel for an output format: the replicated stage-2 table (HLG / PQ output of a call whose values stay within
+// [0, 1]), then the stage-1 table
+template <int FMT, bool MASK> struct ApplyTab {
+  static constexpr bool kOetf = !MASK && (FMT == 2 || FMT == 3);
+  static constexpr uint32_t kS1Bytes = kOetf ? kTabS1PowBytes : kTabS1Bytes;   // at LDS offset 0: its cell offsets are addresses
+  static constexpr uint32_t kS2Base = kS1Bytes;
+  static constexpr uint32_t kS2Bytes = kOetf ? kTabS2LdsBytes : 0u;
+  static constexpr uint32_t kBytes = kS1Bytes + kS2Bytes;
+  static constexpr uint32_t kS1Float = !kOetf ? kTabS1Lin : FMT == 3 ? kTabS1Hlg : kTabS1Pq;
+  static constexpr uint32_t kS2Float = FMT == 3 ? kTabS2Hlg : kTabS2Pq;
+};
+
+// OETF of two linear values, scaled to 10-bit code units where the format is 10 bit: the special-function forms, used where the
+// values may exceed 1.0 (max_display_boost < maxContentBoost: the tables end at 1.0, and the HLG junction is selected per lane
+// because max(e, j) - j cannot be had from a [0,1] clamp) and for the two linear formats.
+template <int FMT>
 __device__ __forceinline__ f2 oetf2_scaled(f2 e) {
-  if (FMT == 3 && UNBOUNDED) {
+  if (FMT == 3) {  // HLG (gainmapmath.cpp:259-265): sqrt(3e) | a ln(12e-b)+c, times 1023
     const f2 lo = sqrt_2(e * splat(3.0f * 1023.0f * 1023.0f));
     const f2 hi = pk_fma(log2_2(pk_fma(e, splat(12.0f), splat(-UHDR_HLG_B))),
                          splat(UHDR_HLG_A * 0.693147180559945f * 1023.0f), splat(UHDR_HLG_C * 1023.0f));
     return sel_le(e, 1.0f / 12.0f, lo, hi);
-  } else if (FMT == 3) {  // HLG (gainmapmath.cpp:259-265): sqrt(3e) | a ln(12e-b)+c, times 1023
-    constexpr float K = 1023.0f;
-    const f2 d = pk_add_sat(e, splat(-1.0f / 12.0f));                                  // max(e, 1/12) - 1/12
-    const f2 arg = pk_fma(d, splat(12.0f), splat(1.0f - UHDR_HLG_B));
-    const f2 hi = pk_fma(log2_2(arg), splat(UHDR_HLG_A * 0.693147180559945f * K), splat(UHDR_HLG_C * K - 0.5f * K));
-    return pk_fma(sqrt_2(pk_mul_sat(e, splat(12.0f))), splat(0.5f * K), hi);           // K sqrt(3 min(e, 1/12)) + hi
   } else if (FMT == 2) {  // PQ (gainmapmath.cpp:309-312): ((c1 + c2 e^m1) / (1 + c3 e^m1))^m2, times 1023
     // e == 0: log2 -> -inf, e^m1 -> 0, result c1^m2 * 1023 = 7e-4, which truncates to the reference's 0
     const f2 p = exp2_2(log2_2(e) * splat(UHDR_PQ_M1));
@@ -834,42 +880,28 @@ __device__ __forceinline__ f2 oetf2_scaled(f2 e) {
   return e;
 }
 
-// HLG OETF of lin * factor for bounded inputs, without forming the product: min(12 e, 1) = sat(lin * 12F) and
-// max(e, 1/12) - 1/12 = sat(lin * F - 1/12) are one packed op each
-__device__ __forceinline__ f2 hlg_oetf2_of_product(f2 lin, f2 factor, f2 factor12) {
-  constexpr float K = 1023.0f;
-  const f2 d = pk_fma_sat(lin, factor, splat(-1.0f / 12.0f));
-  const f2 arg = pk_fma(d, splat(12.0f), splat(1.0f - UHDR_HLG_B));
-  const f2 hi = pk_fma(log2_2(arg), splat(UHDR_HLG_A * 0.693147180559945f * K), splat(UHDR_HLG_C * K - 0.5f * K));
-  return pk_fma(sqrt_2(pk_mul_sat(lin, factor12)), splat(0.5f * K), hi);
-}
-
 struct PairOut { f2 r, g, b; };
 
 // two horizontally adjacent pixels sharing one chroma sample.  yraw: the two luma bytes as floats; crv2 / ngs2 / cbu2: the chroma
-// terms of this and the neighbouring pair, of which half HI is ours
-template <int FMT, bool UNBOUNDED, int HI>
-__device__ __forceinline__ PairOut apply_pair(f2 yraw, f2 crv2, f2 ngs2, f2 cbu2, f2 E, const char* lut) {
+// terms of this and the neighbouring pair, of which half HI is ours.  E: log2 of applyGain's factor / displayBoost -- times g, plus
+// 1, where a stage-2 table follows (launch_apply scales the constants).  With a stage-2 table the results are the bit patterns
+// 0xC0000000 | code (as floats).
+template <int FMT, bool MASK, int HI>
+__device__ __forceinline__ PairOut apply_pair(f2 yraw, f2 crv2, f2 ngs2, f2 cbu2, f2 E, uint32_t slot8, const char* lut) {
+  typedef ApplyTab<FMT, MASK> T;
   // p3YuvToRgb (gainmapmath.cpp:198-202): y / 255 + chroma term in one packed fma, the clamp rides on it
   const f2 r = pk_fma_sat_bc<HI>(yraw, splat(k255), crv2);
   const f2 g = pk_fma_sat_bc<HI>(yraw, splat(k255), ngs2);
   const f2 b = pk_fma_sat_bc<HI>(yraw, splat(k255), cbu2);
-  const f2 factor = exp2_2(E);  // applyGain's 2^(logBoost*displayBoost/max) / displayBoost
-#if UHDR_APPLY_SRGB_LDS
-  const f2 lr = srgb_eotf2_lds(r, lut), lg = srgb_eotf2_lds(g, lut), lb = srgb_eotf2_lds(b, lut);
-#else
-  const f2 lr = srgb_eotf2(r), lg = srgb_eotf2(g), lb = srgb_eotf2(b);
-#endif
+  const f2 factor = exp2_2(E);  // applyGain's 2^(logBoost*displayBoost/max) / displayBoost  [^g, doubled]
+  const f2 lr = tab_eval2<0>(r, lut), lg = tab_eval2<0>(g, lut), lb = tab_eval2<0>(b, lut);
   PairOut o;
-  if (FMT == 3 && !UNBOUNDED) {
-    const f2 factor12 = factor * splat(12.0f);
-    o.r = hlg_oetf2_of_product(lr, factor, factor12);
-    o.g = hlg_oetf2_of_product(lg, factor, factor12);
-    o.b = hlg_oetf2_of_product(lb, factor, factor12);
+  if (T::kOetf) {   // (not reached: HLG / PQ output within [0, 1] runs apply_cell_piped)
+    o.r = lr; o.g = lg; o.b = lb;
   } else {
-    o.r = oetf2_scaled<FMT, UNBOUNDED>(lr * factor);
-    o.g = oetf2_scaled<FMT, UNBOUNDED>(lg * factor);
-    o.b = oetf2_scaled<FMT, UNBOUNDED>(lb * factor);
+    o.r = oetf2_scaled<FMT>(lr * factor);
+    o.g = oetf2_scaled<FMT>(lg * factor);
+    o.b = oetf2_scaled<FMT>(lb * factor);
   }
   return o;
 }
@@ -886,48 +918,69 @@ __device__ __forceinline__ uint32_t pack10_scaled(float r, float g, float b) {
   asm("v_lshl_or_b32 %0, %1, 20, %2" : "=v"(t) : "v"(bi), "v"(t));
   return t | 0xC0000000u;
 }
+// the same from three OETF-table results: red's bits are 0xC0000000 | code (alpha included); the shifts push the upper bits of
+// green and blue out of the word
+__device__ __forceinline__ uint32_t pack10_bits(float r, float g, float b) {
+  uint32_t t;
+  asm("v_lshl_or_b32 %0, %1, 10, %2" : "=v"(t) : "v"(__float_as_uint(g)), "v"(__float_as_uint(r)));
+  asm("v_lshl_or_b32 %0, %1, 20, %2" : "=v"(t) : "v"(__float_as_uint(b)), "v"(t));
+  return t;
+}
+
+// one float of byte k of a word: v_cvt_f32_ubyte<k>
+template <int K>
+__device__ __forceinline__ float cvt_byte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
 
 template <int FMT, bool INTERIOR, bool MASK>
 __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
                                            const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
-                                           float e1, float e2, float e3, float e4, int tbl, const char* lut) {
+                                           float m1, float m2, float m3, float m4, int tbl, uint32_t slot8, const char* lut) {
   // chroma terms of the cell's 2x2 samples, one packed register per row of two: kCr * (V - 128) / 255 etc. as one fma each on the
   // byte values (constants pre-multiplied; within an ulp of the reference's two-step rounding, which FAST mode does not promise)
   constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
   f2 crv2[2], ngs2[2], cbu2[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    const f2 uf = (f2){(float)(uu[r] & 0xffu), (float)((uu[r] >> 8) & 0xffu)};
-    const f2 vf = (f2){(float)(vv[r] & 0xffu), (float)((vv[r] >> 8) & 0xffu)};
+    const f2 uf = (f2){cvt_byte<0>(uu[r]), cvt_byte<1>(uu[r])};
+    const f2 vf = (f2){cvt_byte<0>(vv[r]), cvt_byte<1>(vv[r])};
     crv2[r] = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
     cbu2[r] = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
     ngs2[r] = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
   }
+  // sampleMap (gainmapmath.cpp:705-719) folded into the exponent: the weights of a position sum to 1, so
+  // E = B + A/255 m1 + sum_k (m_k - m1) w_k A/255: three packed fmas per pixel pair
+  const float base = __builtin_fmaf(m1, c.fast.A255, c.fast.B);
+  const float d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
   const float* wt = c_idw4 + tbl * 64;  // border cells only: per-lane table (gainmapmath.cpp:710-716)
 #pragma unroll
   for (int oy = 0; oy < 4; ++oy) {
     PairOut po[2];
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-      f2 w0, w1, w2, w3;
+      f2 w1, w2, w3;
       if (INTERIOR) {
-        w0 = (f2){c.fast.wA[oy][pr][0][0], c.fast.wA[oy][pr][0][1]}; w1 = (f2){c.fast.wA[oy][pr][1][0], c.fast.wA[oy][pr][1][1]};
-        w2 = (f2){c.fast.wA[oy][pr][2][0], c.fast.wA[oy][pr][2][1]}; w3 = (f2){c.fast.wA[oy][pr][3][0], c.fast.wA[oy][pr][3][1]};
+        w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}; w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
+        w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
       } else {
         const float* p0 = wt + oy * 16 + pr * 8;
-        w0 = (f2){p0[0], p0[4]} * splat(c.fast.A); w1 = (f2){p0[1], p0[5]} * splat(c.fast.A);
-        w2 = (f2){p0[2], p0[6]} * splat(c.fast.A); w3 = (f2){p0[3], p0[7]} * splat(c.fast.A);
+        w1 = (f2){p0[1], p0[5]} * splat(c.fast.A255); w2 = (f2){p0[2], p0[6]} * splat(c.fast.A255);
+        w3 = (f2){p0[3], p0[7]} * splat(c.fast.A255);
       }
-      const f2 E = pk_fma(splat(e4), w3, pk_fma(splat(e3), w2, pk_fma(splat(e2), w1, pk_fma(splat(e1), w0, splat(c.fast.B)))));
-      const f2 yraw = pr ? (f2){(float)((yrow[oy] >> 16) & 0xffu), (float)(yrow[oy] >> 24)} : (f2){(float)(yrow[oy] & 0xffu), (float)((yrow[oy] >> 8) & 0xffu)};
-      po[pr] = pr ? apply_pair<FMT, MASK, 1>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, lut)
-                  : apply_pair<FMT, MASK, 0>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, lut);
+      const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
+      const f2 yraw = pr ? (f2){cvt_byte<2>(yrow[oy]), cvt_byte<3>(yrow[oy])} : (f2){cvt_byte<0>(yrow[oy]), cvt_byte<1>(yrow[oy])};
+      po[pr] = pr ? apply_pair<FMT, MASK, 1>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, slot8, lut)
+                  : apply_pair<FMT, MASK, 0>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, slot8, lut);
     }
     const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
     if (FMT == 2 || FMT == 3) {
       uint4 o;
-      o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
-      o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
+      if (ApplyTab<FMT, MASK>::kOetf) {
+        o.x = pack10_bits(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_bits(po[0].r.y, po[0].g.y, po[0].b.y);
+        o.z = pack10_bits(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_bits(po[1].r.y, po[1].g.y, po[1].b.y);
+      } else {
+        o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
+        o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
+      }
       st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), o);
     } else if (FMT == 1) {
       const uint2 a = pack_f16_hw(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16_hw(po[0].r.y, po[0].g.y, po[0].b.y);
@@ -937,75 +990,215 @@ __device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& i
       o[1] = make_uint4(cc.x, cc.y, d.x, d.y);
     } else {  // FMT == 4: planar R,G,B uint16 (ultrahdr.cpp:460-468)
       const size_t plane = (size_t)c.width * c.height;
-      uint16_t* base = static_cast<uint16_t*>(im.dst);
+      uint16_t* base16 = static_cast<uint16_t*>(im.dst);
       const f2 ch[3][2] = {{po[0].r, po[1].r}, {po[0].g, po[1].g}, {po[0].b, po[1].b}};
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const uint32_t q0 = 0x3ffu & (uint32_t)ch[p][0].x, q1 = 0x3ffu & (uint32_t)ch[p][0].y;
         const uint32_t q2 = 0x3ffu & (uint32_t)ch[p][1].x, q3 = 0x3ffu & (uint32_t)ch[p][1].y;
-        *reinterpret_cast<uint2*>(base + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+        *reinterpret_cast<uint2*>(base16 + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
       }
     }
   }
 }
 
-// Each block copies the 32 KiB line-segment table into LDS once and then walks kApplyCellsPerThread cells per thread.
-constexpr uint32_t kApplyCellsPerThread = UHDR_APPLY_CELLS;
-#ifndef UHDR_APPLY_MIN_BLOCKS
-#define UHDR_APPLY_MIN_BLOCKS 4
-#endif
-template <int FMT, bool MASK>
-__global__ void __launch_bounds__(256, UHDR_APPLY_MIN_BLOCKS) k_apply_s4(const AppConsts c, const AppBatch b) {
-#if UHDR_APPLY_SRGB_LDS
-  __shared__ float2 s_line[kSrgbLineCells];
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(c.srgb_line);
-    uint4* dst = reinterpret_cast<uint4*>(s_line);
+// The same cell for HLG / PQ output through both tables, as a software pipeline over its 8 pixel pairs.  A pair needs two LDS round
+// trips (stage 1, stage 2), and the compiler, left alone, waits for each pair of reads right after issuing it (a SIMD's four waves
+// then spend 60 % of their time parked at s_waitcnt).  Here every iteration runs three stages of three different pairs,
+//   F(k):   E, factor, r g b of pair k, their cells; issues the 6 stage-1 reads of pair k
+//   M(k-1): the 6 fmas on the stage-1 entries of pair k-1, s = 2 + 2 T factor, the 6 slot addresses; issues its 6 stage-2 reads
+//   B(k-2): the 6 fmas on the stage-2 entries of pair k-2, packs its two pixels (and stores the row when it is complete)
+// so that every read has a whole iteration (~50 VALU instructions) between issue and use.  sched_barrier keeps the stages apart.
+struct PairF { f2 c[3]; f2 factor; float2 e[6]; };
+struct PairM { f2 s[3]; float2 e[6]; };
+template <int FMT, bool INTERIOR>
+__device__ __forceinline__ void apply_cell_piped(const AppConsts& c, void* dst, uint32_t cx, uint32_t cy,
+                                                 const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
+                                                 float m1, float m2, float m3, float m4, int tbl, uint32_t slot8, const char* lut) {
+  typedef ApplyTab<FMT, false> T;
+  constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
+  f2 crv2[2], ngs2[2], cbu2[2];
 #pragma unroll
-    for (uint32_t k = 0; k < kSrgbLineCells / 2u / 256u; ++k) dst[k * 256u + threadIdx.x] = src[k * 256u + threadIdx.x];
+  for (int r = 0; r < 2; ++r) {
+    const f2 uf = (f2){cvt_byte<0>(uu[r]), cvt_byte<1>(uu[r])};
+    const f2 vf = (f2){cvt_byte<0>(vv[r]), cvt_byte<1>(vv[r])};
+    crv2[r] = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
+    cbu2[r] = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
+    ngs2[r] = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
   }
-  __syncthreads();
-  const char* lut = reinterpret_cast<const char*>(s_line);
-#else
-  const char* lut = nullptr;
-#endif
-  const AppImage& im = b.img[blockIdx.y];
-  const uint32_t total = c.map_w * c.map_h;
-#pragma unroll 1
-  for (uint32_t it = 0; it < kApplyCellsPerThread; ++it) {
-  const uint32_t idx = (blockIdx.x * kApplyCellsPerThread + it) * 256u + threadIdx.x;
-  if (idx >= total) return;
-  const uint32_t cy = idx / c.map_w;
-  const uint32_t cx = idx - cy * c.map_w;
+  const float a255 = c.fast.A255;
+  const float base = __builtin_fmaf(m1, a255, c.fast.B);
+  const float d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
+  const float* wt = c_idw4 + tbl * 64;
+  PairF pf[2];
+  PairM pm[2];
+  uint32_t px[4];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    if (k < 8) {  // ---- F(k)
+      const int oy = k >> 1, pr = k & 1;
+      f2 w1, w2, w3;
+      if (INTERIOR) {
+        w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}; w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
+        w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
+      } else {
+        const float* p0 = wt + oy * 16 + pr * 8;
+        w1 = (f2){p0[1], p0[5]} * splat(a255); w2 = (f2){p0[2], p0[6]} * splat(a255); w3 = (f2){p0[3], p0[7]} * splat(a255);
+      }
+      PairF& f = pf[k & 1];
+      const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
+      const f2 yraw = pr ? (f2){cvt_byte<2>(yrow[oy]), cvt_byte<3>(yrow[oy])} : (f2){cvt_byte<0>(yrow[oy]), cvt_byte<1>(yrow[oy])};
+      if (pr) {
+        f.c[0] = pk_fma_sat_bc<1>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<1>(yraw, splat(k255), ngs2[oy >> 1]);
+        f.c[2] = pk_fma_sat_bc<1>(yraw, splat(k255), cbu2[oy >> 1]);
+      } else {
+        f.c[0] = pk_fma_sat_bc<0>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<0>(yraw, splat(k255), ngs2[oy >> 1]);
+        f.c[2] = pk_fma_sat_bc<0>(yraw, splat(k255), cbu2[oy >> 1]);
+      }
+      f.factor = exp2_2(E);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) pow_pair(f.c[ch], lut, f.e[2 * ch], f.e[2 * ch + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k >= 1 && k <= 8) {  // ---- M(k-1)
+      PairF& f = pf[(k - 1) & 1];
+      PairM& m = pm[(k - 1) & 1];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        f2 t;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(f.e[2 * ch].y), "v"(f.c[ch].x), "v"(f.e[2 * ch].x));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(f.e[2 * ch + 1].y), "v"(f.c[ch].y), "v"(f.e[2 * ch + 1].x));
+        m.s[ch] = pk_fma(t, f.factor, splat(2.0f));
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        m.e[2 * ch] = *reinterpret_cast<const float2*>(lut + T::kS2Base + s2_address(m.s[ch].x, slot8));
+        m.e[2 * ch + 1] = *reinterpret_cast<const float2*>(lut + T::kS2Base + s2_address(m.s[ch].y, slot8));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k >= 2) {  // ---- B(k-2)
+      const int q = k - 2, oy = q >> 1, pr = q & 1;
+      PairM& m = pm[q & 1];
+      float o[6];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o[2 * ch]) : "v"(m.e[2 * ch].y), "v"(m.s[ch].x), "v"(m.e[2 * ch].x));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o[2 * ch + 1]) : "v"(m.e[2 * ch + 1].y), "v"(m.s[ch].y), "v"(m.e[2 * ch + 1].x));
+      }
+      px[2 * pr] = pack10_bits(o[0], o[2], o[4]);
+      px[2 * pr + 1] = pack10_bits(o[1], o[3], o[5]);
+      if (pr) {
+        const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
+        st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(dst) + pix0), make_uint4(px[0], px[1], px[2], px[3]));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
-  // 32-bit offsets (an image plane is < 4 GiB): one 64-bit add per address instead of 64-bit multiply-adds
-  uint32_t yrow[4];
+// the bytes of one map cell's 4x4 pixels: four luma words, two rows of two chroma samples per plane, the four sampleMap taps
+// (gainmapmath.cpp:690-703: the reference indexes the map with map->width).  The taps stay bytes: the / 255 of gainmapmath.cpp:632
+// is folded into the weights.  32-bit offsets (an image plane is < 4 GiB): one 64-bit add per address.
+struct ApplyCellIn { uint32_t yrow[4], uu[2], vv[2], mb[4]; };
+__device__ __forceinline__ void apply_load_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, ApplyCellIn& o) {
   const uint32_t yoff = 4u * cy * im.y_stride + 4u * cx;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) yrow[r] = ld_stream(reinterpret_cast<const uint32_t*>(im.y + (yoff + r * im.y_stride)));
-  uint32_t uu[2], vv[2];
+  for (int r = 0; r < 4; ++r) o.yrow[r] = ld_stream(reinterpret_cast<const uint32_t*>(im.y + (yoff + r * im.y_stride)));
   const uint32_t coff = 2u * cy * im.c_stride + 2u * cx;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    uu[r] = *reinterpret_cast<const uint16_t*>(im.u + (coff + r * im.c_stride));
-    vv[r] = *reinterpret_cast<const uint16_t*>(im.v + (coff + r * im.c_stride));
+    o.uu[r] = *reinterpret_cast<const uint16_t*>(im.u + (coff + r * im.c_stride));
+    o.vv[r] = *reinterpret_cast<const uint16_t*>(im.v + (coff + r * im.c_stride));
   }
-  // sampleMap taps (gainmapmath.cpp:690-703): the reference indexes the map with map->width
   const uint32_t xu = min(cx + 1u, c.map_w - 1u), yu = min(cy + 1u, c.map_h - 1u);
   const uint32_t m0 = cy * c.map_w, m1 = yu * c.map_w;
-  const float e1 = map_to_float_fast(im.map[m0 + cx]);
-  const float e2 = map_to_float_fast(im.map[m1 + cx]);
-  const float e3 = map_to_float_fast(im.map[m0 + xu]);
-  const float e4 = map_to_float_fast(im.map[m1 + xu]);
-  const bool edge_x = (xu == cx), edge_y = (yu == cy);
+  o.mb[0] = im.map[m0 + cx]; o.mb[1] = im.map[m1 + cx]; o.mb[2] = im.map[m0 + xu]; o.mb[3] = im.map[m1 + xu];
+}
+
+// Each block copies its tables into LDS once (15 KiB, + 32 KiB for the replicated stage-2 table of HLG / PQ output: two blocks
+// of 512 threads per CU) and then walks c.cells_per_thread map cells per thread.
+#ifndef UHDR_APPLY_BLOCK
+#define UHDR_APPLY_BLOCK 512
+#endif
+#ifndef UHDR_APPLY_MIN_WAVES
+#define UHDR_APPLY_MIN_WAVES 4
+#endif
+#ifndef UHDR_APPLY_CELLS
+#define UHDR_APPLY_CELLS 32
+#endif
+constexpr uint32_t kApplyBlock = UHDR_APPLY_BLOCK;
+constexpr uint32_t kApplyMaxCellsPerThread = UHDR_APPLY_CELLS;
+template <int FMT, bool MASK>
+__global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_apply_s4(const AppConsts c, const AppBatch b) {
+  typedef ApplyTab<FMT, MASK> T;
+  __shared__ uint4 s_tab[T::kBytes / 16u];
+  {
+    // all loads first, then all stores: one trip through L2's latency per block instead of one per piece
+    constexpr uint32_t kN1 = T::kS1Bytes / 16u, kPer1 = (kN1 + kApplyBlock - 1u) / kApplyBlock;
+    constexpr uint32_t kN2 = T::kOetf ? kTabS2Cells * 32u : 0u, kPer2 = (kN2 + kApplyBlock - 1u) / kApplyBlock;
+    const uint4* src1 = reinterpret_cast<const uint4*>(c.tab + T::kS1Float);
+    const uint2* src2 = reinterpret_cast<const uint2*>(c.tab + T::kS2Float);
+    uint4 t1[kPer1];
+    uint2 t2[kPer2 ? kPer2 : 1u];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN1) t1[k] = src1[i]; }
+#pragma unroll
+    for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN2) t2[k] = src2[i >> 5]; }
+#pragma unroll
+    for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN1) s_tab[i] = t1[k]; }
+#pragma unroll
+    for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN2) reinterpret_cast<uint2*>(s_tab)[T::kS2Base / 8u + i] = t2[k]; }
+  }
+  __syncthreads();
+  const char* lut = reinterpret_cast<const char*>(s_tab);
+  const uint32_t slot8 = (threadIdx.x & 31u) << 3;
+  const AppImage& im = b.img[blockIdx.y];
+  void* const dst = im.dst;
+  const uint32_t total = c.map_w * c.map_h;
+  uint32_t idx = blockIdx.x * c.cells_per_thread * kApplyBlock + threadIdx.x;
+  if (idx >= total) return;
+  uint32_t cy = idx / c.map_w;
+  uint32_t cx = idx - cy * c.map_w;
+  if (T::kOetf) {
+    // Round toward zero from here on: stage 2 truncates the code inside its fma.  The integer division above is expanded into
+    // float operations that assume round-to-nearest, hence the (fake) dependence of its results on this statement; the cells that
+    // follow are reached by addition.
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(cx), "+v"(cy));
+  }
+  // The inputs of the next cell are requested before the current one is computed: a block's waves start together, and without
+  // this they would also all wait for HBM together and all compute together.
+  ApplyCellIn cur;
+  apply_load_cell(c, im, cx, cy, cur);
+#pragma unroll 1
+  for (uint32_t it = 0;; ++it) {
+  const uint32_t nidx = idx + kApplyBlock;
+  const bool more = it + 1u < c.cells_per_thread && nidx < total;
+  uint32_t ncx = cx + kApplyBlock, ncy = cy;
+  while (ncx >= c.map_w) { ncx -= c.map_w; ++ncy; }
+  ApplyCellIn nxt;
+  if (more) apply_load_cell(c, im, ncx, ncy, nxt);
+  const float e1 = (float)cur.mb[0], e2 = (float)cur.mb[1], e3 = (float)cur.mb[2], e4 = (float)cur.mb[3];
+  const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
   const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
   // all waves but those touching the last column/row of cells take the SGPR-weight path
-  if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) {
-    if (MASK) apply_cell<FMT, true, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0, lut);
-    else apply_cell<FMT, true, false>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, 0, lut);
-  } else {
-    apply_cell<FMT, false, true>(c, im, cx, cy, yrow, uu, vv, e1, e2, e3, e4, tbl, lut);
+#if UHDR_APPLY_EXPERIMENT == 1   // memory floor: the kernel's loads and stores, one XOR in between
+  {
+    const uint32_t x = cur.yrow[0] ^ cur.yrow[1] ^ cur.yrow[2] ^ cur.yrow[3] ^ cur.uu[0] ^ cur.uu[1] ^ cur.vv[0] ^ cur.vv[1] ^ __float_as_uint(e1 + e2 + e3 + e4);
+    for (int oy = 0; oy < 4; ++oy) st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(dst) + ((4u * cy + oy) * c.width + 4u * cx)), make_uint4(x, x + oy, x ^ 1u, x ^ 2u));
   }
+#else
+  if (T::kOetf) {
+    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) apply_cell_piped<FMT, true>(c, dst, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, 0, slot8, lut);
+    else apply_cell_piped<FMT, false>(c, dst, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, tbl, slot8, lut);
+  } else if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) {
+    apply_cell<FMT, true, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, 0, slot8, lut);
+  } else {
+    apply_cell<FMT, false, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, tbl, slot8, lut);
+  }
+#endif
+  if (!more) return;
+  cur = nxt; idx = nidx; cx = ncx; cy = ncy;
   }
 }
 
@@ -1133,11 +1326,27 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
   }
   if (fast_s4 && !exact) {
     const uint32_t total = c.map_w * c.map_h;
+    // Cells per thread: a block copies 39-47 KB of tables into LDS before its first pixel, so it should walk many cells -- but a
+    // launch also has to fill 256 CUs x 4 resident blocks, or a single 4K image (2025 blocks of 256 cells) would leave three
+    // quarters of the chip idle with 8 cells per thread.
+    AppConsts cc = c;
+    uint32_t cpt = kApplyMaxCellsPerThread;
+    auto blocks = [&](uint32_t k) { return (uint64_t)((total + kApplyBlock * k - 1u) / (kApplyBlock * k)) * (uint64_t)n; };
+    while (cpt > 1u && blocks(cpt) < 2u * 256u) cpt >>= 1;
+    cc.cells_per_thread = cpt;
+    const dim3 grid((unsigned)((total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt)), n);
     // channels can only reach 1024 (and wrap through the reference's & 0x3ff) when the display boost is
     // capped below the content boost
-    const uint32_t per_block = 256u * kApplyCellsPerThread;
-    if (c.display_boost < c.max_boost) hipLaunchKernelGGL((k_apply_s4<FMT, true>), dim3((total + per_block - 1u) / per_block, n), dim3(256), 0, s, c, b);
-    else hipLaunchKernelGGL((k_apply_s4<FMT, false>), dim3((total + per_block - 1u) / per_block, n), dim3(256), 0, s, c, b);
+    if (c.display_boost < c.max_boost) hipLaunchKernelGGL((k_apply_s4<FMT, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
+    else {
+      if (ApplyTab<FMT, false>::kOetf) {
+        // u = T(c) * 2^(g E), handed to stage 2 as 2 + 2u: the exponent's constants times g (1/2 for HLG: sqrt; m1 for PQ), plus 1
+        const float g = FMT == 3 ? 0.5f : UHDR_PQ_M1;
+        cc.fast.A *= g; cc.fast.A255 *= g; cc.fast.B = cc.fast.B * g + 1.0f;
+        for (int i = 0; i < 4 * 2 * 3 * 2; ++i) (&cc.fast.wD[0][0][0][0])[i] *= g;
+      }
+      hipLaunchKernelGGL((k_apply_s4<FMT, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
+    }
   } else {
     const size_t total = (size_t)c.width * c.height;
     const dim3 grid((unsigned)((total + 255u) / 256u), n);
@@ -1495,6 +1704,18 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 44: y = ec.lut[kLutHlg + lut_index(x, kLutHlgN)]; break;
     case 45: y = ec.lut[kLutPq + lut_index(x, kLutPqN)]; break;
     case 46: y = gain_lut_entry(lut_index(x, kGainLutN), ec.log2_min_d, ec.log2_max_d, 1.0f); break;
+    // FAST apply's line-segment tables, read from the device buffer with the kernel's own index arithmetic.  50 / 53 / 54: stage 1,
+    // T(x) = srgbInvOetf(x)^g for g = 1, 1/2, m1.  51 / 52: the 10-bit code stage 2 yields for u in [0, 1] (HLG: u = sqrt(e), PQ:
+    // u = e^m1); the kernel's fma rounds toward zero, which is the truncation of the exact sum formed here in double.
+    case 50: case 53: case 54: {
+      const uint32_t base = fn == 50 ? kTabS1Lin : fn == 53 ? kTabS1Hlg : kTabS1Pq;
+      const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ec.lut + base) + (fn == 50 ? tab_offset(x) : pow_offset(x)));
+      y = __builtin_fmaf(t.y, x, t.x); break; }
+    case 51: case 52: {
+      const float s = __builtin_fmaf(x, 2.0f, 2.0f);
+      const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ec.lut + (fn == 51 ? kTabS2Hlg : kTabS2Pq)) + (s2_address(s, 0u) >> 5));
+      const double v = -(((double)t.y * (double)s + (double)t.x) + 2.0) * 4194304.0;
+      y = (float)(long long)v + (v < 0.0 ? -1000.0f : 0.0f); break; }   // (a negative sum would leave the binade: flagged)
     case 30: y = map_to_float_fast((uint32_t)x); break;
     case 31: y = map_to_float((uint32_t)x); break;
     // 1.0 where the lean f64 path was accepted by the rounding test, 0.0 where the exact path ran

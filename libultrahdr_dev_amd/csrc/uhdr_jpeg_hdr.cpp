@@ -175,7 +175,7 @@ int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
       if (len < 4) return -1;
       info->restart_interval = rd16(seg);
     } else if (m == 0xDA) {
-      if (nc == 0 || seg[0] != nc || len < (size_t)(6 + 2 * nc)) return -2;
+      if (nc == 0 || len < (size_t)(6 + 2 * nc) || seg[0] != nc) return -2;   // (the length first: seg[0] of a 2-byte segment at the end of the file is past the buffer)
       info->gray = nc == 1;
       if (!info->gray && !(hs[0] == 2 && vs[0] == 2 && hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1)) return -1;   // the reference fails too, jpegdecoderhelper.cpp:283-289
       if (info->w <= 0 || info->h <= 0) return -1;

@@ -1118,6 +1118,9 @@ __device__ __forceinline__ void apply_load_cell(const AppConsts& c, const AppIma
 
 // Each block copies its tables into LDS once (15 KiB, + 32 KiB for the replicated stage-2 table of HLG / PQ output: two blocks
 // of 512 threads per CU) and then walks c.cells_per_thread map cells per thread.
+#ifndef UHDR_APPLY_EXPERIMENT
+#define UHDR_APPLY_EXPERIMENT 0
+#endif
 #ifndef UHDR_APPLY_BLOCK
 #define UHDR_APPLY_BLOCK 512
 #endif
@@ -1169,7 +1172,7 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
   // The inputs of the next cell are requested before the current one is computed: a block's waves start together, and without
   // this they would also all wait for HBM together and all compute together.
   ApplyCellIn cur;
-  apply_load_cell(c, im, cx, cy, cur);
+  if (UHDR_APPLY_EXPERIMENT != 2) apply_load_cell(c, im, cx, cy, cur);
 #pragma unroll 1
   for (uint32_t it = 0;; ++it) {
   const uint32_t nidx = idx + kApplyBlock;
@@ -1177,15 +1180,17 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
   uint32_t ncx = cx + kApplyBlock, ncy = cy;
   while (ncx >= c.map_w) { ncx -= c.map_w; ++ncy; }
   ApplyCellIn nxt;
-  if (more) apply_load_cell(c, im, ncx, ncy, nxt);
+  if (more && UHDR_APPLY_EXPERIMENT != 2) apply_load_cell(c, im, ncx, ncy, nxt);
   const float e1 = (float)cur.mb[0], e2 = (float)cur.mb[1], e3 = (float)cur.mb[2], e4 = (float)cur.mb[3];
   const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
   const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
   // all waves but those touching the last column/row of cells take the SGPR-weight path
-#if UHDR_APPLY_EXPERIMENT == 1   // memory floor: the kernel's loads and stores, one XOR in between
+#if UHDR_APPLY_EXPERIMENT   // memory floors (scripts/ab, never shipped): 1 the kernel's loads and stores, one XOR in between; 2 its stores alone; 3 its loads alone
   {
-    const uint32_t x = cur.yrow[0] ^ cur.yrow[1] ^ cur.yrow[2] ^ cur.yrow[3] ^ cur.uu[0] ^ cur.uu[1] ^ cur.vv[0] ^ cur.vv[1] ^ __float_as_uint(e1 + e2 + e3 + e4);
-    for (int oy = 0; oy < 4; ++oy) st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(dst) + ((4u * cy + oy) * c.width + 4u * cx)), make_uint4(x, x + oy, x ^ 1u, x ^ 2u));
+    uint32_t x = cur.yrow[0] ^ cur.yrow[1] ^ cur.yrow[2] ^ cur.yrow[3] ^ cur.uu[0] ^ cur.uu[1] ^ cur.vv[0] ^ cur.vv[1] ^ __float_as_uint(e1 + e2 + e3 + e4);
+    if (UHDR_APPLY_EXPERIMENT == 2) x = cx * cy;
+    if (UHDR_APPLY_EXPERIMENT != 3 || x == 0x12345678u)
+      for (int oy = 0; oy < 4; ++oy) st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(dst) + ((4u * cy + oy) * c.width + 4u * cx)), make_uint4(x, x + oy, x ^ 1u, x ^ 2u));
   }
 #else
   if (T::kOetf) {

@@ -1,0 +1,125 @@
+// Write-only / read-only floors of the access patterns of k_apply_s4 on this box (scripts/ab, never shipped).
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/store_pattern scripts/ab/store_pattern.hip && /tmp/store_pattern
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t W = 3840, H = 2160, MW = 960, MH = 540, N = 64;
+
+template <bool NT> __device__ __forceinline__ void st(uint4* p, uint4 v) {
+  if (NT) __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p)); else *p = v;
+}
+// 0: linear fill, 16 B per lane, grid-stride
+template <bool NT> __global__ void __launch_bounds__(512) k_linear(uint4* out, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 512) st<NT>(out + i, make_uint4(i, 1, 2, 3));
+}
+// 1: apply's pattern: thread = map cell, 4 rows x 16 B; block walks cpt consecutive chunks of 512 cells (mode 0) or grid-strides (mode 1)
+template <bool NT> __global__ void __launch_bounds__(512) k_cells(uint32_t* out, uint32_t cpt, int mode) {
+  uint32_t* img = out + (size_t)blockIdx.y * W * H;
+  const uint32_t total = MW * MH;
+  for (uint32_t it = 0; it < cpt; ++it) {
+    const uint32_t idx = mode == 0 ? (blockIdx.x * cpt + it) * 512u + threadIdx.x : (it * gridDim.x + blockIdx.x) * 512u + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t cy = idx / MW, cx = idx - cy * MW;
+    for (int oy = 0; oy < 4; ++oy) st<NT>(reinterpret_cast<uint4*>(img + (4u * cy + oy) * W + 4u * cx), make_uint4(idx, oy, 2, 3));
+  }
+}
+// block-contiguous linear fill: each block writes one chunk of `per` x 8 KiB, U stores in flight per thread
+template <int MODE> __device__ __forceinline__ void st_mode(uint4* p, uint4 vv) {
+  const u32x4 v = {vv.x, vv.y, vv.z, vv.w};
+  if (MODE == 0) *p = vv;
+  else if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+  else if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+  else if (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+  else if (MODE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(v) : "memory");
+  else if (MODE == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+}
+template <int MODE> __global__ void __launch_bounds__(512) k_chunk(uint4* out, uint32_t per) {
+  uint4* p = out + (size_t)blockIdx.x * per * 512 + threadIdx.x;
+  for (uint32_t i = 0; i < per; i += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st_mode<MODE>(p + (size_t)(i + k) * 512, make_uint4(i, k, 2, 3));
+  }
+}
+template <int MODE> __global__ void __launch_bounds__(512) k_cells_mode(uint32_t* out, uint32_t cpt) {
+  uint32_t* img = out + (size_t)blockIdx.y * W * H;
+  const uint32_t total = MW * MH;
+  for (uint32_t it = 0; it < cpt; ++it) {
+    const uint32_t idx = (blockIdx.x * cpt + it) * 512u + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t cy = idx / MW, cx = idx - cy * MW;
+    for (int oy = 0; oy < 4; ++oy) st_mode<MODE>(reinterpret_cast<uint4*>(img + (4u * cy + oy) * W + 4u * cx), make_uint4(idx, oy, 2, 3));
+  }
+}
+// 2: thread = 4 pixels of one row (a wave = 1 KiB of one row), rows in order: the image written strictly linearly
+// 3: read pattern of apply (Y 4 x 4 B, U/V 2 x 2 B each, 4 map bytes), result folded into one rare store
+__global__ void __launch_bounds__(512) k_cells_read(const uint8_t* y, const uint8_t* u, const uint8_t* map, uint32_t* sink, uint32_t cpt, int mode) {
+  const uint8_t* iy = y + (size_t)blockIdx.y * W * H; const uint8_t* iu = u + (size_t)blockIdx.y * (W / 2) * H; const uint8_t* iv = iu + (size_t)(W / 2) * (H / 2);
+  const uint8_t* im = map + (size_t)blockIdx.y * MW * MH;
+  const uint32_t total = MW * MH; uint32_t acc = 0;
+  for (uint32_t it = 0; it < cpt; ++it) {
+    const uint32_t idx = mode == 0 ? (blockIdx.x * cpt + it) * 512u + threadIdx.x : (it * gridDim.x + blockIdx.x) * 512u + threadIdx.x;
+    if (idx >= total) break;
+    const uint32_t cy = idx / MW, cx = idx - cy * MW;
+    for (int r = 0; r < 4; ++r) acc ^= __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(iy + (4u * cy + r) * W + 4u * cx));
+    for (int r = 0; r < 2; ++r) { acc ^= *reinterpret_cast<const uint16_t*>(iu + (2u * cy + r) * (W / 2) + 2u * cx); acc ^= *reinterpret_cast<const uint16_t*>(iv + (2u * cy + r) * (W / 2) + 2u * cx); }
+    const uint32_t xu = min(cx + 1u, MW - 1u), yu = min(cy + 1u, MH - 1u);
+    acc ^= im[cy * MW + cx] ^ im[yu * MW + cx] ^ im[cy * MW + xu] ^ im[yu * MW + xu];
+  }
+  if (acc == 0x12345678u) sink[threadIdx.x] = acc;
+}
+
+template <class F> float timed(F f) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) f();
+  hipEventRecord(a); for (int i = 0; i < 20; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms / 20;
+}
+int main() {
+  const size_t obytes = (size_t)N * W * H * 4;
+  uint32_t* out; CK(hipMalloc(&out, obytes));
+  uint8_t *y, *u, *map; CK(hipMalloc(&y, (size_t)N * W * H)); CK(hipMalloc(&u, (size_t)N * W * H / 2)); CK(hipMalloc(&map, (size_t)N * MW * MH));
+  CK(hipMemset(y, 1, (size_t)N * W * H)); CK(hipMemset(u, 2, (size_t)N * W * H / 2)); CK(hipMemset(map, 3, (size_t)N * MW * MH));
+  const double gb = obytes / 1e9, rgb = ((double)N * W * H * 1.5 + (double)N * MW * MH) / 1e9;
+  float t;
+  t = timed([&] { hipLaunchKernelGGL(k_linear<true>, dim3(2048), dim3(512), 0, 0, (uint4*)out, obytes / 16); }); printf("linear nt, 2048 blocks          %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
+  t = timed([&] { hipLaunchKernelGGL(k_linear<false>, dim3(2048), dim3(512), 0, 0, (uint4*)out, obytes / 16); }); printf("linear plain, 2048 blocks       %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
+  t = timed([&] { hipLaunchKernelGGL(k_linear<true>, dim3(512), dim3(512), 0, 0, (uint4*)out, obytes / 16); }); printf("linear nt, 512 blocks           %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
+  {
+    const char* names[7] = {"plain", "nt", "sc1", "sc0 sc1", "sc0 sc1 nt", "sc0 nt", "sc1 nt"};
+    float r[7][3];
+    for (int per_i = 0; per_i < 3; ++per_i) {
+      const uint32_t per = per_i == 0 ? 8 : per_i == 1 ? 64 : 512;   // 64 KiB / 512 KiB / 4 MiB per block
+      const dim3 grid((unsigned)(obytes / 16 / 512 / per));
+      r[0][per_i] = timed([&] { hipLaunchKernelGGL(k_chunk<0>, grid, dim3(512), 0, 0, (uint4*)out, per); });
+      r[1][per_i] = timed([&] { hipLaunchKernelGGL(k_chunk<1>, grid, dim3(512), 0, 0, (uint4*)out, per); });
+      r[2][per_i] = timed([&] { hipLaunchKernelGGL(k_chunk<2>, grid, dim3(512), 0, 0, (uint4*)out, per); });
+      r[3][per_i] = timed([&] { hipLaunchKernelGGL(k_chunk<3>, grid, dim3(512), 0, 0, (uint4*)out, per); });
+      r[4][per_i] = timed([&] { hipLaunchKernelGGL(k_chunk<4>, grid, dim3(512), 0, 0, (uint4*)out, per); });
+      r[5][per_i] = timed([&] { hipLaunchKernelGGL(k_chunk<5>, grid, dim3(512), 0, 0, (uint4*)out, per); });
+      r[6][per_i] = timed([&] { hipLaunchKernelGGL(k_chunk<6>, grid, dim3(512), 0, 0, (uint4*)out, per); });
+    }
+    for (int m = 0; m < 7; ++m) printf("chunk fill %-11s 64K/512K/4M per block: %.0f %.0f %.0f GB/s\n", names[m], gb / r[m][0] * 1e3, gb / r[m][1] * 1e3, gb / r[m][2] * 1e3);
+    const dim3 grid((MW * MH + 512 * 32 - 1) / (512 * 32), N);
+    float c[7];
+    c[0] = timed([&] { hipLaunchKernelGGL(k_cells_mode<0>, grid, dim3(512), 0, 0, out, 32u); });
+    c[1] = timed([&] { hipLaunchKernelGGL(k_cells_mode<1>, grid, dim3(512), 0, 0, out, 32u); });
+    c[2] = timed([&] { hipLaunchKernelGGL(k_cells_mode<2>, grid, dim3(512), 0, 0, out, 32u); });
+    c[3] = timed([&] { hipLaunchKernelGGL(k_cells_mode<3>, grid, dim3(512), 0, 0, out, 32u); });
+    c[4] = timed([&] { hipLaunchKernelGGL(k_cells_mode<4>, grid, dim3(512), 0, 0, out, 32u); });
+    c[5] = timed([&] { hipLaunchKernelGGL(k_cells_mode<5>, grid, dim3(512), 0, 0, out, 32u); });
+    c[6] = timed([&] { hipLaunchKernelGGL(k_cells_mode<6>, grid, dim3(512), 0, 0, out, 32u); });
+    for (int m = 0; m < 7; ++m) printf("cells cpt 32 %-11s %.3f ms %.0f GB/s\n", names[m], c[m], gb / c[m] * 1e3);
+  }
+  for (uint32_t cpt : {32u})
+    for (int mode = 0; mode < 2; ++mode) {
+      const dim3 grid((MW * MH + 512 * cpt - 1) / (512 * cpt), N);
+      t = timed([&] { hipLaunchKernelGGL(k_cells<true>, grid, dim3(512), 0, 0, out, cpt, mode); });
+      printf("cells nt, cpt %3u, %s   %.3f ms %.0f GB/s\n", cpt, mode ? "grid-stride " : "block-chunks", t, gb / t * 1e3);
+      t = timed([&] { hipLaunchKernelGGL(k_cells_read, grid, dim3(512), 0, 0, y, u, map, out, cpt, mode); });
+      printf("cells read, cpt %3u, %s %.3f ms %.0f GB/s\n", cpt, mode ? "grid-stride " : "block-chunks", t, rgb / t * 1e3);
+    }
+  return 0;
+}

@@ -105,8 +105,40 @@ static void exercise(const std::vector<uint8_t>& in) {
   free(d);
 }
 
+// parse_header on an exact-size heap copy (a read past the end is an ASan report)
+static int parse_exact(const std::vector<uint8_t>& v) {
+  uint8_t* d = static_cast<uint8_t*>(malloc(v.size() ? v.size() : 1));
+  memcpy(d, v.data(), v.size());
+  jpeg::DecInfo info;
+  const int rc = jpeg::parse_header(d, v.size(), &info);
+  free(d);
+  return rc;
+}
+// Structure-aware: every marker segment of a seed's header, with its length rewritten to 2..8 and the file cut right behind it, so
+// that the segment's declared payload ends exactly at the end of the buffer (round 1's parser read seg[0] of such an SOS).
+static void short_segments(const std::vector<uint8_t>& sd) {
+  size_t pos = 2;
+  while (pos + 4 <= sd.size() && sd[pos] == 0xFF) {
+    const unsigned m = sd[pos + 1];
+    const size_t len = ((size_t)sd[pos + 2] << 8) | sd[pos + 3];
+    for (size_t L = 2; L <= 8; ++L) {
+      std::vector<uint8_t> v(sd.begin(), sd.begin() + (long)pos + 2);
+      v.push_back((uint8_t)(L >> 8)); v.push_back((uint8_t)L);
+      for (size_t k = 0; k + 2 < L && pos + 4 + k < sd.size(); ++k) v.push_back(sd[pos + 4 + k]);
+      (void)parse_exact(v);
+      for (unsigned mm : {0xDAu, 0xC0u, 0xC4u, 0xDBu, 0xDDu}) { v[pos + 1] = (uint8_t)mm; (void)parse_exact(v); }   // the same cut under every marker the parser reads
+    }
+    if (m == 0xDA || len < 2) break;
+    pos += 2 + len;
+  }
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
+  {  // SOI + SOF0 (one component) + an SOS of length 2 as the last bytes of the buffer
+    const uint8_t sof[] = {0xFF, 0xD8, 0xFF, 0xC0, 0x00, 0x0B, 0x08, 0x00, 0x10, 0x00, 0x10, 0x01, 0x01, 0x11, 0x00, 0xFF, 0xDA, 0x00, 0x02};
+    if (parse_exact(std::vector<uint8_t>(sof, sof + sizeof(sof))) == 0) { fprintf(stderr, "accepted an empty SOS\n"); abort(); }
+  }
   std::vector<std::vector<uint8_t>> seeds;
   for (int i = 1; i < argc - 1; ++i) {
     FILE* f = fopen(argv[i], "rb");
@@ -120,6 +152,7 @@ int main(int argc, char** argv) {
   }
   const long iters = atol(argv[argc - 1]);
   for (const auto& s : seeds) exercise(s);
+  for (const auto& s : seeds) short_segments(s);
   // scans made of the bytes the walk cares about, at every alignment and length: the header of a seed that parses, then a random
   // mix of 0xFF / 0x00 / RSTn / fill / data bytes, then EOI (with and without a DRI segment in front of the scan)
   for (const auto& sd : seeds) {

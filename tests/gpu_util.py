@@ -61,16 +61,18 @@ def gpu_apply(lib, yuv_img, dmap_t, mw, mh, md, fmt, max_display_boost, mode=api
     return st, to_host(dout, nbytes), dest
 
 
-def diff_1010102(a_u32, b_u32):
-    """per-channel absolute difference of two RGBA1010102 arrays -> (max_abs_diff, fraction_differing)"""
+def diff_1010102(a_u32, b_u32, wrap=False):
+    """per-channel absolute difference of two RGBA1010102 arrays -> (max_abs_diff, fraction_differing, alpha_ok).
+    wrap: the call's max_display_boost was below maxContentBoost.  Only then can a channel land on 1024 and wrap to 0 through the
+    reference's `& 0x3ff` (gainmapmath.cpp:722-727), and only then is the distance taken modulo 1024; otherwise a channel that
+    is 0 on one side and 1023 on the other is 1023 apart."""
     a = a_u32.astype(np.int64)
     b = b_u32.astype(np.int64)
     worst, ndiff = 0, 0
     for sh in (0, 10, 20):
         d = np.abs(((a >> sh) & 0x3ff) - ((b >> sh) & 0x3ff))
-        # the reference masks with 0x3ff (gainmapmath.cpp:723-725), so a channel that lands on 1024 wraps
-        # to 0 (only reachable when max_display_boost < maxContentBoost): distance is taken modulo 1024
-        d = np.minimum(d, 1024 - d)
+        if wrap:
+            d = np.minimum(d, 1024 - d)
         worst = max(worst, int(d.max()) if d.size else 0)
         ndiff += int((d != 0).sum())
     alpha_ok = bool((((a >> 30) & 3) == ((b >> 30) & 3)).all())

@@ -268,18 +268,19 @@ def _oracle_apply(orc, yuv, w, h, gmap, maxb, fmt, boost, minb=1.0):
     return out
 
 
-def _check_apply(hip, fmt, fast, ref, w, h):
+def _check_apply(hip, fmt, fast, ref, w, h, wrap=False):
+    """wrap: max_display_boost < maxContentBoost, the one case in which values pass 1.0 and the 0x3ff mask can wrap a channel"""
     from tests.gpu_util import diff_1010102, half_ulp_diff
     if fmt == hip.OUTPUT_HDR_LINEAR:
         worst, frac = half_ulp_diff(fast.view(np.uint16), ref.view(np.uint16))
         assert worst <= HALF_ULP_TOL, worst
     elif fmt == hip.OUTPUT_HDR_LINEAR_RGB_10BIT:
         d = np.abs(fast.view(np.uint16).astype(np.int32) - ref.view(np.uint16).astype(np.int32))
-        # 10-bit wrap-around (0x3ff mask) can only happen when values exceed 1.0; compare modulo 1024
-        d = np.minimum(d, 1024 - d)
+        if wrap:   # 10-bit wrap-around (0x3ff mask) can only happen when values exceed 1.0
+            d = np.minimum(d, 1024 - d)
         assert int(d.max()) <= LSB_TOL
     else:
-        worst, frac, alpha_ok = diff_1010102(fast.view(np.uint32), ref.view(np.uint32))
+        worst, frac, alpha_ok = diff_1010102(fast.view(np.uint32), ref.view(np.uint32), wrap)
         assert alpha_ok and worst <= LSB_TOL, worst
 
 
@@ -302,7 +303,7 @@ def test_apply_formats_and_display_boost(hip, orc, fmt, boost):
     assert np.array_equal(exact, ref), "EXACT apply is not bit-exact (fmt %d): %d bytes differ" % (fmt, int((exact != ref).sum()))
     st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, boost, hip.APPLY_FAST)
     assert st == 0
-    _check_apply(hip, fmt, fast, ref, w, h)
+    _check_apply(hip, fmt, fast, ref, w, h, wrap=boost < maxb)
 
 
 @pytest.mark.parametrize("scale", [1, 2, 3, 4, 5, 8])
@@ -348,7 +349,7 @@ def test_apply_min_boost_below_one_and_strides(hip, orc):
     assert st == 0 and np.array_equal(exact, ref)
     st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, hip.OUTPUT_HDR_HLG, 4.0, hip.APPLY_FAST)
     assert st == 0
-    _check_apply(hip, hip.OUTPUT_HDR_HLG, fast, ref, w, h)
+    _check_apply(hip, hip.OUTPUT_HDR_HLG, fast, ref, w, h, wrap=True)   # max_display_boost 4.0 < maxContentBoost 6.0
 
 
 def test_apply_unwritten_formats_and_errors(hip):
@@ -612,11 +613,12 @@ def test_fast_apply_against_exact_apply_on_sixteen_4k_frames(hip, fmt):
                 assert bool(((x >> 30) & 3 == (y >> 30) & 3).all())
                 for sh in (0, 10, 20):
                     d = (((x >> sh) & 0x3ff) - ((y >> sh) & 0x3ff)).abs()
-                    d = torch.minimum(d, 1024 - d)
+                    if boost < mb:   # only a capped display boost lets a channel reach 1024 and wrap (gainmapmath.cpp:722-727)
+                        d = torch.minimum(d, 1024 - d)
                     worst = max(worst, int(d.max())); ndiff += int((d != 0).sum()); total += d.numel()
             else:
                 x, y = a.view(torch.int16).to(torch.int32), b.view(torch.int16).to(torch.int32)
-                if fmt == 4:
+                if fmt == 4 and boost < mb:
                     d = torch.minimum((x - y).abs(), 1024 - (x - y).abs())
                 else:
                     d = (x - y).abs()

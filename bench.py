@@ -7,6 +7,9 @@ generate+apply on 1 MI355X"; with N GPUs every rank holds its own 64 frames = co
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Started without torch.distributed.run and with --gpus N > 1, this file launches the N ranks itself (fresh child processes through
+torch.distributed.run, started before anything here has touched a GPU) and relays rank 0's JSON line.
+
 One step = one pass of the hot path over the rank's batch: generateGainMap (HLG, P010 BT.2100 vs
 SDR BT.709) into HBM-resident maps, then applyGainMap (FAST) of those maps -> RGBA1010102 HLG with
 max_display_boost = FLT_MAX.  Inputs are already in HBM when the timed region starts; nothing crosses
@@ -36,6 +39,8 @@ CHUNK = 64                       # images per kernel launch (kMaxChunk in csrc/u
 # algorithmic HBM bytes per 4K frame: every input byte read once, every output written once
 GEN_BYTES = W * H * 3 + W * H * 3 // 2 + (W // 4) * (H // 4)           # 24 883 200 + 12 441 600 + 518 400
 APP_BYTES = W * H * 3 // 2 + (W // 4) * (H // 4) + W * H * 4           # 12 441 600 + 518 400 + 33 177 600
+GEN_READ_BYTES = W * H * 3 + W * H * 3 // 2                            # generate: P010 + YUV420 in
+APP_READ_BYTES = W * H * 3 // 2 + (W // 4) * (H // 4)                  # apply: YUV420 + map in
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -52,7 +57,62 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra configs[1]/[4] timings (profiling runs)")
     ap.add_argument("--no-stats", action="store_true", help="experiment: generate without the per-image content min/max pass")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames of the same batch timed on the host CPU")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / reductions only, no GPU work and no measurement "
+                    "(tests/test_bench_launcher.py: the N-rank launch on a box without GPUs); prints value null")
     return ap.parse_args()
+
+
+def sources_sha16():
+    """identifies the kernels a profile was taken with: profiles/traffic_latest.json carries it, and a line whose kernels have
+    changed since reports traffic null instead of a stale number"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("uhdr_kernels.hip", "uhdr_kernels.h", "uhdr_device_math.h"):
+        h.update(open(os.path.join(ROOT, "libultrahdr_dev_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children.  Nothing in this process has
+    initialised a GPU (importing torch does not), and it stays that way: it only waits and passes the children's output on."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(a, world, rank):
+    """the multi-rank plumbing without a GPU: gloo rendezvous, the per-step content min/max reduction, the MAX over ranks of the
+    elapsed time, one JSON line from rank 0"""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    mm = torch.tensor([1.0 + rank, 4.0 + rank] * a.frames, dtype=torch.float32)
+    red = torch.zeros(2, dtype=torch.float32)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        if world > 1:
+            _, work = sharding.reduce_content_minmax(mm, dist, red, async_op=True)
+            sharding.finish_content_minmax(red, work)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "MPixels/sec gain-map generate+apply, 4K P010 batch", "value": None, "unit": "MPix/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "dry_run": True, "scaling": "weak",
+                          "content_minmax": None if world == 1 else [float(red[0]), float(-red[1])],
+                          "config": {"workload": "dry run: no GPU work", "frames_per_gpu": a.frames}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 class Batch:
@@ -303,7 +363,6 @@ def cpu_baseline(batch, fmt, nframes):
     ncpu = os.cpu_count() or 1
     torch.cuda.synchronize()
     t_gen = t_app = t_gen4 = t_app4 = 0.0
-    t_ref1 = None
     worst, ndiff, nch = 0, 0, 0
     for i in range(nframes):
         p010 = batch.p010[i].cpu().numpy().view(np.uint16)
@@ -324,16 +383,6 @@ def cpu_baseline(batch, fmt, nframes):
             O.apply("orc_", yi, omap, omd, fmt, api.FLT_MAX, threads=0)
             t2 = time.perf_counter()
             t_gen4, t_app4 = t1 - t0, t2 - t1
-        if i == 0 and O.load_ref() is not None:
-            # the reference's own gainmapmath.cpp object code (oracle/_ref, compiled in place from /root/reference; the per-pixel loops of
-            # ultrahdr.cpp restated around it, one thread) on the same frame: the oracle's speed is the reference's speed
-            t0 = time.perf_counter()
-            rst, rmap, _ = O.generate("ref_", yi, pi, O.TF_HLG)
-            t1 = time.perf_counter()
-            rst2, rref, _ = O.apply("ref_", yi, rmap, omd, fmt, api.FLT_MAX)
-            t2 = time.perf_counter()
-            assert rst == 0 and rst2 == 0 and np.array_equal(rmap, omap) and np.array_equal(rref, ref), "oracle != reference object code"
-            t_ref1 = (t1 - t0, t2 - t1)
         gmap = batch.maps[i].cpu().numpy().reshape(omap.shape)
         assert np.array_equal(gmap, omap), "GPU gain map differs from the CPU oracle on frame %d" % i
         out = batch.outs[i].cpu().numpy().view(np.uint32)
@@ -402,7 +451,8 @@ def cpu_baseline(batch, fmt, nframes):
                   "%d row-band threads" % (nframes, "HLG" if fmt == api.OUTPUT_HDR_HLG else "PQ", ncpu),
         "generate_mpix_s": round(nframes * mpix / t_gen, 3), "apply_mpix_s": round(nframes * mpix / t_app, 3),
         "ref_policy_4_threads_mpix_s": round(mpix / (t_gen4 + t_app4), 3),
-        "reference_object_code_1_thread_mpix_s": None if t_ref1 is None else round(mpix / (t_ref1[0] + t_ref1[1]), 3),
+        # the reference's own gainmapmath.cpp object code (oracle/_ref) is timed in the container only and never loaded on the GPU
+        # box: profiles/r02_reference_cpu.json (scripts/time_reference_cpu.py); it equals the oracle byte for byte there
         "gpu_vs_cpu_parity": {"map_bit_exact": True, "apply_worst_lsb": worst,
                               "apply_channels_differing": round(ndiff / max(nch, 1), 6)},
     }
@@ -410,9 +460,14 @@ def cpu_baseline(batch, fmt, nframes):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert a.gpus in (1, world), "--gpus %d but torch.distributed.run started %d ranks" % (a.gpus, world)
+    if a.dry_run:
+        return dry_run(a, world, rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -489,9 +544,22 @@ def main():
         if os.path.exists(tp) and min(CHUNK, a.frames) == 64:   # HBM bytes per 64-frame launch from rocprofv3 --pmc passes of this same command
             try:
                 tj = json.load(open(tp))
-                traffic, traffic_src = tj.get(dominant), tj.get("source")
+                if tj.get("sources_sha16") == sources_sha16():    # (scripts/profile_bench.sh stamps the kernels it profiled)
+                    traffic, traffic_src = tj.get(dominant), tj.get("source")
+                else:
+                    traffic_src = "profiles/traffic_latest.json was taken with other kernel sources (stamp %s, now %s): not reported" % (
+                        tj.get("sources_sha16"), sources_sha16())
             except Exception:
                 pass
+        # the box's own ceilings beside the 8 TB/s specification (torch kernels over 1 GiB buffers; < 1 s)
+        ceilings = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import mem_ceiling
+            ceilings = {k: round(v, 1) for k, v in mem_ceiling.measure(1 << 30).items()}
+        except Exception:
+            pass
+        read_gbs = (GEN_READ_BYTES + APP_READ_BYTES) * total_frames / world / elapsed / 1e9
         out = {
             "metric": "MPixels/sec gain-map generate+apply, 4K P010 batch", "value": round(value, 1), "unit": "MPix/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
@@ -505,7 +573,11 @@ def main():
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_launch,
-                         "avg_launch_ms": round(app_ms if dominant == "apply" else gen_ms, 4)},
+                         "avg_launch_ms": round(app_ms if dominant == "apply" else gen_ms, 4),
+                         # north_star's "HBM-read roofline": the bytes the step READS (50 284 800 per frame pair) over the step time
+                         "read_only": {"achieved": round(read_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(read_gbs / HBM_PEAK_GBS, 4),
+                                       "bytes_per_frame_pair": GEN_READ_BYTES + APP_READ_BYTES, "scope": "generate+apply step, per GPU"},
+                         "measured_ceilings_this_box_GBs": ceilings},
             "kernels": {
                 "generate": {"avg_launch_ms": round(gen_ms, 4), "GB/s": round(gen_gbs, 1), "frac_of_8TBs": round(gen_gbs / HBM_PEAK_GBS, 4),
                              "bytes_per_frame": GEN_BYTES},

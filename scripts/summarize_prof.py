@@ -59,6 +59,11 @@ for key, pat in (("generate", "k_generate"), ("apply", "k_apply_s4")):
         traffic[key] = int(2 * f[0] * 1024 + w[0] * 1024)
         traffic[key + "_read_bytes"] = int(2 * f[0] * 1024)
         traffic[key + "_write_bytes"] = int(w[0] * 1024)
+import hashlib
+_h = hashlib.sha256()
+for _f in ("uhdr_kernels.hip", "uhdr_kernels.h", "uhdr_device_math.h"):
+    _h.update(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "libultrahdr_dev_amd", "csrc", _f), "rb").read())
+traffic["sources_sha16"] = _h.hexdigest()[:16]   # bench.py reports these bytes only while the kernels are the ones profiled
 summary["traffic"] = traffic
 json.dump(traffic, open(outp + "_traffic.json", "w"), indent=1)
 json.dump(summary, open(outp + ".json", "w"), indent=1)

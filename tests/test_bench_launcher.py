@@ -1,0 +1,35 @@
+"""bench.py's own N-rank launch (no GPU needed): `python bench.py --gpus 2 --dry-run`, started WITHOUT torch.distributed.run,
+must start two ranks (fresh children through torch.distributed.run), run the path's only exchange (the content min/max
+all-reduce) between them over gloo and print ONE JSON line from rank 0 with n_gpus = 2.  --dry-run does no GPU work and
+reports value null; everything else is the launcher and rendezvous code the driver's `bench.py --gpus N` goes through."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_gpus_2_launches_two_ranks_and_reports_them():
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--frames", "4"])
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["steps"] == 3
+    # rank r contributes (min, max) = (1 + r, 4 + r): the reduction went across both ranks
+    assert d["content_minmax"] == [1.0, 5.0]
+
+
+def test_single_rank_dry_run_and_gpus_mismatch():
+    r = _run(["--dry-run", "--steps", "1"])
+    assert r.returncode == 0 and json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+    # under torch.distributed.run the flag has to agree with the number of ranks that were started
+    r = _run(["--gpus", "4", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4" in r.stderr

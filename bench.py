@@ -192,6 +192,13 @@ def other_configs(lib, stream):
                                                      api.MEM_DEVICE, stream))
     out["configs[1] single 4K HLG generate"] = {"ms": round(ms, 4), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1),
                                                 "GB/s": round(GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    o1 = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
+    mi1, oi1 = api.mono_image(m.data_ptr(), W // 4, H // 4), api.out_image(o1.data_ptr())
+    ms = timed(lambda: lib.uhdr_hip_apply_gainmap(C.byref(yi), C.byref(mi1), C.byref(md), api.OUTPUT_HDR_HLG, api.FLT_MAX, C.byref(oi1),
+                                                  api.APPLY_FAST, api.MEM_DEVICE, stream))
+    out["single 4K apply -> HLG RGBA1010102"] = {"ms": round(ms, 4), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1),
+                                                 "GB/s": round(APP_BYTES / (ms * 1e-3) / 1e9, 1)}
+    del o1
     # PQ generate (P010 BT.2100 PQ vs SDR BT.709): 2 f64 pow per HDR channel instead of 1 exp on the exact path, the f32 pre-filter
     # in front of it as for HLG -- 32 frames in one launch (8 left the chip half empty), plus the unfiltered kernel beside it
     nb = 32
@@ -206,6 +213,21 @@ def other_configs(lib, stream):
     ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch_ex(nb, ya, pa, api.TF_PQ, C.byref(md), ma, 0, api.GENERATE_UNFILTERED, None, stream), 10)
     out["4K PQ generate, 32-frame launch, pre-filter off (UHDR_HIP_GENERATE_UNFILTERED)"] = {
         "ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1), "GB/s": round(nb * GEN_BYTES / (ms * 1e-3) / 1e9, 1)}
+    # the two other pointwise loops of the encode path in their batched form (API-0's toneMap, API-0/1's convertYuv to BT.601):
+    # 32 x 4K per call.  toneMap reads 3 B and writes 1.5 B per pixel; convertYuv reads and writes 1.5 B per pixel in place.
+    tdst = [torch.zeros(W * H * 3 // 2, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+    ta = api.image_array([api.yuv420_image(t.data_ptr(), W, H, -1) for t in tdst])
+    ms = timed(lambda: lib.uhdr_hip_tonemap_batch(nb, pa, ta, stream), 10)
+    out["toneMap, 32 x 4K per call (uhdr_hip_tonemap_batch)"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
+                                                                "GB/s": round(nb * W * H * 4.5 / (ms * 1e-3) / 1e9, 1)}
+    ms = timed(lambda: lib.uhdr_hip_tonemap(C.byref(pa[0]), C.byref(ta[0]), api.MEM_DEVICE, stream))
+    out["toneMap, one 4K frame"] = {"ms": round(ms, 4), "GB/s": round(W * H * 4.5 / (ms * 1e-3) / 1e9, 1)}
+    ms = timed(lambda: lib.uhdr_hip_convert_yuv_batch(nb, ta, api.CG_BT2100, api.CG_P3, stream), 10)
+    out["convertYuv BT.2100 -> BT.601 in place, 32 x 4K per call (uhdr_hip_convert_yuv_batch)"] = {
+        "ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1), "GB/s": round(nb * W * H * 3.0 / (ms * 1e-3) / 1e9, 1)}
+    ms = timed(lambda: lib.uhdr_hip_convert_yuv(C.byref(ta[0]), api.CG_BT2100, api.CG_P3, api.MEM_DEVICE, stream))
+    out["convertYuv, one 4K frame"] = {"ms": round(ms, 4), "GB/s": round(W * H * 3.0 / (ms * 1e-3) / 1e9, 1)}
+    del tdst
     # opt-in LUT mode (upstream libultrahdr's USE_*_LUT configuration; bit-exact against the reference's LUT functions)
     ms = timed(lambda: lib.uhdr_hip_generate_gainmap_batch_ex(nb, ya, pa, api.TF_HLG, C.byref(md), ma, 0, api.GENERATE_LUT, None, stream), 10)
     out["LUT mode: 4K HLG generate, 32-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),

@@ -177,6 +177,12 @@ int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int me
 int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_encoding, int mem_space,
                          void* stream);
 
+/* The same two over n images in DEVICE memory (every op in single and batched form; the reference runs them once
+ * per image, ultrahdr.cpp:517-558 / jpegr.cpp:1132-1206).  Images of equal size share one launch (grid.z = image, up to 32), so an
+ * API-0 / API-1 encode of a batch does not pay a launch pair per image.  Checks are the single form's, all images before any launch. */
+int uhdr_hip_tonemap_batch(int n, const uhdr_hip_image_t* srcs, uhdr_hip_image_t* dests, void* stream);
+int uhdr_hip_convert_yuv_batch(int n, uhdr_hip_image_t* images, int src_encoding, int dest_encoding, void* stream);
+
 /* ---- editing effects (SURVEY.md 8(f) "next", rank 3) -------------------------------------------------
  * crop / mirror / rotate / resize of lib/src/editorhelper.cpp:26-360 (lib/include/ultrahdr/editorhelper.h:49-63)
  * on YUV420 or MONOCHROME images, byte-identical to the reference including its layout rules: the output is

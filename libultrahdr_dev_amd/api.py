@@ -68,6 +68,8 @@ SIGNATURES = {
     "uhdr_hip_apply_gainmap": (C.c_int, [_IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_tonemap": (C.c_int, [_IP, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_convert_yuv": (C.c_int, [_IP, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "uhdr_hip_tonemap_batch": (C.c_int, [C.c_int, _IP, _IP, C.c_void_p]),
+    "uhdr_hip_convert_yuv_batch": (C.c_int, [C.c_int, _IP, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_generate_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_void_p, C.c_void_p]),
     "uhdr_hip_apply_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_crop": (C.c_int, [_IP, C.c_int, C.c_int, C.c_int, C.c_int, _IP, C.c_int, C.c_void_p]),

@@ -1253,7 +1253,8 @@ const float* yuv_matrix(int src_encoding, int dest_encoding) {
 }
 // convertYuv of `src` into the planes of `dst` (device memory, same size): the private copy API-1 converts is written by the
 // conversion itself instead of by three plane copies in front of it
-int convert_yuv_into(const uhdr_hip_image_t& src, const uhdr_hip_image_t& dst, const float* m, hipStream_t s) {
+// descriptor of one convertYuv: `src`'s samples through m into `dst`'s planes (the same image for the in-place form)
+CvtImage cvt_image(const uhdr_hip_image_t& src, const uhdr_hip_image_t& dst, const float* m, bool* aligned) {
   CvtImage t;
   t.y = static_cast<uint8_t*>(dst.data);
   t.u = static_cast<uint8_t*>(dst.chroma_data);
@@ -1265,9 +1266,15 @@ int convert_yuv_into(const uhdr_hip_image_t& src, const uhdr_hip_image_t& dst, c
   t.su = static_cast<const uint8_t*>(src.chroma_data);
   t.sv = t.su + src.chroma_stride * (src.height / 2);
   t.sy_stride = (uint32_t)src.luma_stride; t.sc_stride = (uint32_t)src.chroma_stride;
-  const bool aligned = t.width % 8u == 0 && al(t.y, 8) && t.y_stride % 8u == 0 && al(t.u, 4) && al(t.v, 4) && t.c_stride % 4u == 0 &&
-                       al(t.sy, 8) && t.sy_stride % 8u == 0 && al(t.su, 4) && al(t.sv, 4) && t.sc_stride % 4u == 0;
-  HIP_TRY(launch_convert_yuv(t, aligned, s));
+  *aligned = t.width % 8u == 0 && al(t.y, 8) && t.y_stride % 8u == 0 && al(t.u, 4) && al(t.v, 4) && t.c_stride % 4u == 0 &&
+             al(t.sy, 8) && t.sy_stride % 8u == 0 && al(t.su, 4) && al(t.sv, 4) && t.sc_stride % 4u == 0;
+  return t;
+}
+int convert_yuv_into(const uhdr_hip_image_t& src, const uhdr_hip_image_t& dst, const float* m, hipStream_t s) {
+  CvtBatch b;
+  bool aligned;
+  b.img[0] = cvt_image(src, dst, m, &aligned);
+  HIP_TRY(launch_convert_yuv(b, 1, aligned, s));
   return UHDR_HIP_NO_ERROR;
 }
 
@@ -1782,39 +1789,77 @@ int uhdr_hip_apply_gainmap(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* 
   return UHDR_HIP_NO_ERROR;
 }
 
-int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int mem_space, void* stream) {
-  // ultrahdr.cpp:518-523
+namespace {
+ToneImage tone_image(const uhdr_hip_image_t& sd, const uhdr_hip_image_t& dd, bool* aligned) {
+  ToneImage t;
+  t.sy = static_cast<const uint16_t*>(sd.data);
+  t.suv = static_cast<const uint16_t*>(sd.chroma_data);
+  t.dy = static_cast<uint8_t*>(dd.data);
+  t.du = static_cast<uint8_t*>(dd.chroma_data);
+  t.dv = t.du + (dd.chroma_stride * dd.height / 2);  // ultrahdr.cpp:539
+  t.sy_stride = (uint32_t)sd.luma_stride; t.suv_stride = (uint32_t)sd.chroma_stride;
+  t.dy_stride = (uint32_t)dd.luma_stride; t.dc_stride = (uint32_t)dd.chroma_stride;
+  t.width = (uint32_t)sd.width; t.height = (uint32_t)sd.height;
+  *aligned = t.width % 16u == 0 && al(t.sy, 16) && t.sy_stride % 8u == 0 && al(t.suv, 16) &&
+             t.suv_stride % 8u == 0 && al(t.dy, 8) && t.dy_stride % 8u == 0 && t.dy_stride >= t.width &&
+             al(t.du, 8) && al(t.dv, 8) && t.dc_stride % 8u == 0 && t.dc_stride >= t.width / 2u;
+  return t;
+}
+int tonemap_check(const uhdr_hip_image_t* src, const uhdr_hip_image_t* dest) {   // ultrahdr.cpp:518-523
   if (src == nullptr || dest == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   if (src->width != dest->width || src->height != dest->height) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;
   if (src->data == nullptr || src->chroma_data == nullptr || dest->data == nullptr || dest->chroma_data == nullptr)
     return UHDR_HIP_ERROR_BAD_PTR;  // (the reference would dereference them)
+  return UHDR_HIP_NO_ERROR;
+}
+}  // namespace
+
+// UltraHdr::toneMap over n images in device memory: images of equal size (and equal alignment class) share a launch, grid.z = image
+int uhdr_hip_tonemap_batch(int n, const uhdr_hip_image_t* srcs, uhdr_hip_image_t* dests, void* stream) {
+  if (n < 0 || (n > 0 && (srcs == nullptr || dests == nullptr))) return UHDR_HIP_ERROR_BAD_PTR;
+  for (int i = 0; i < n; ++i) {
+    const int rc = tonemap_check(&srcs[i], &dests[i]);
+    if (rc != UHDR_HIP_NO_ERROR) return rc;
+  }
   DeviceState* st = nullptr;
   int rc = current_state(&st);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int i = 0;
+  while (i < n) {
+    ToneBatch b;
+    bool aligned = true;
+    int m = 0;
+    while (i + m < n && m < kToneChunk) {
+      bool a;
+      const ToneImage t = tone_image(srcs[i + m], dests[i + m], &a);
+      if (m == 0) aligned = a;
+      else if (a != aligned || t.width != b.img[0].width || t.height != b.img[0].height) break;
+      b.img[m++] = t;
+    }
+    HIP_TRY(launch_tonemap(b, m, aligned, s));
+    for (int k = 0; k < m; ++k) dests[i + k].colorGamut = srcs[i + k].colorGamut;  // ultrahdr.cpp:556
+    i += m;
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int mem_space, void* stream) {
+  int rc = tonemap_check(src, dest);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (mem_space == UHDR_HIP_MEM_DEVICE) return uhdr_hip_tonemap_batch(1, src, dest, stream);
+  DeviceState* st = nullptr;
+  if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
 
   auto run = [&](const uhdr_hip_image_t& sd, const uhdr_hip_image_t& dd) -> int {
-    ToneImage t;
-    t.sy = static_cast<const uint16_t*>(sd.data);
-    t.suv = static_cast<const uint16_t*>(sd.chroma_data);
-    t.dy = static_cast<uint8_t*>(dd.data);
-    t.du = static_cast<uint8_t*>(dd.chroma_data);
-    t.dv = t.du + (dd.chroma_stride * dd.height / 2);  // ultrahdr.cpp:539
-    t.sy_stride = (uint32_t)sd.luma_stride; t.suv_stride = (uint32_t)sd.chroma_stride;
-    t.dy_stride = (uint32_t)dd.luma_stride; t.dc_stride = (uint32_t)dd.chroma_stride;
-    t.width = (uint32_t)sd.width; t.height = (uint32_t)sd.height;
-    const bool aligned = t.width % 16u == 0 && al(t.sy, 16) && t.sy_stride % 8u == 0 && al(t.suv, 16) &&
-                         t.suv_stride % 8u == 0 && al(t.dy, 8) && t.dy_stride % 8u == 0 && t.dy_stride >= t.width &&
-                         al(t.du, 8) && al(t.dv, 8) && t.dc_stride % 8u == 0 && t.dc_stride >= t.width / 2u;
-    HIP_TRY(launch_tonemap(t, aligned, s));
+    ToneBatch b;
+    bool aligned;
+    b.img[0] = tone_image(sd, dd, &aligned);
+    HIP_TRY(launch_tonemap(b, 1, aligned, s));
     return UHDR_HIP_NO_ERROR;
   };
 
-  if (mem_space == UHDR_HIP_MEM_DEVICE) {
-    if ((rc = run(*src, *dest)) != 0) return rc;
-    dest->colorGamut = src->colorGamut;  // ultrahdr.cpp:556
-    return UHDR_HIP_NO_ERROR;
-  }
   std::lock_guard<std::mutex> lk(g_host_mu);
   uhdr_hip_image_t ds, dd = *dest;
   if ((rc = stage_p010_in(st, 2, *src, &ds, s)) != 0) return rc;
@@ -1837,41 +1882,59 @@ int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int me
   return UHDR_HIP_NO_ERROR;
 }
 
-int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_encoding, int mem_space, void* stream) {
-  // jpegr.cpp:1134-1197
+namespace {
+int convert_check(const uhdr_hip_image_t* image, int src_encoding, int dest_encoding) {   // jpegr.cpp:1134-1197
   if (image == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   if (src_encoding == UHDR_HIP_CG_UNSPECIFIED || dest_encoding == UHDR_HIP_CG_UNSPECIFIED)
     return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
   if (!valid_gamut(src_encoding) || !valid_gamut(dest_encoding)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
+  return UHDR_HIP_NO_ERROR;
+}
+}  // namespace
+
+// JpegR::convertYuv over n images in device memory, in place: images of equal size (and equal alignment class) share a launch
+int uhdr_hip_convert_yuv_batch(int n, uhdr_hip_image_t* images, int src_encoding, int dest_encoding, void* stream) {
+  if (n < 0 || (n > 0 && images == nullptr)) return UHDR_HIP_ERROR_BAD_PTR;
+  int rc = convert_check(n > 0 ? &images[0] : nullptr, src_encoding, dest_encoding);
+  if (n == 0) rc = (src_encoding == UHDR_HIP_CG_UNSPECIFIED || dest_encoding == UHDR_HIP_CG_UNSPECIFIED || !valid_gamut(src_encoding) ||
+                    !valid_gamut(dest_encoding)) ? UHDR_HIP_ERROR_INVALID_COLORGAMUT : UHDR_HIP_NO_ERROR;
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (src_encoding == dest_encoding) return UHDR_HIP_NO_ERROR;
+  for (int i = 0; i < n; ++i)
+    if (images[i].data == nullptr || images[i].chroma_data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  const float* m = yuv_matrix(src_encoding, dest_encoding);
+  DeviceState* st = nullptr;
+  if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int i = 0;
+  while (i < n) {
+    CvtBatch b;
+    bool aligned = true;
+    int k = 0;
+    while (i + k < n && k < kToneChunk) {
+      bool a;
+      const CvtImage t = cvt_image(images[i + k], images[i + k], m, &a);
+      if (k == 0) aligned = a;
+      else if (a != aligned || t.width != b.img[0].width || t.height != b.img[0].height) break;
+      b.img[k++] = t;
+    }
+    HIP_TRY(launch_convert_yuv(b, k, aligned, s));
+    i += k;
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_encoding, int mem_space, void* stream) {
+  int rc = convert_check(image, src_encoding, dest_encoding);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
   if (src_encoding == dest_encoding) return UHDR_HIP_NO_ERROR;
   if (image->data == nullptr || image->chroma_data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
-  const float* m = nullptr;
-  switch (src_encoding) {
-    case UHDR_HIP_CG_BT709: m = dest_encoding == UHDR_HIP_CG_P3 ? kYuv709To601 : kYuv709To2100; break;
-    case UHDR_HIP_CG_P3: m = dest_encoding == UHDR_HIP_CG_BT709 ? kYuv601To709 : kYuv601To2100; break;
-    default: m = dest_encoding == UHDR_HIP_CG_BT709 ? kYuv2100To709 : kYuv2100To601; break;
-  }
+  if (mem_space == UHDR_HIP_MEM_DEVICE) return uhdr_hip_convert_yuv_batch(1, image, src_encoding, dest_encoding, stream);
+  const float* m = yuv_matrix(src_encoding, dest_encoding);
   DeviceState* st = nullptr;
-  int rc = current_state(&st);
-  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-
-  auto run = [&](const uhdr_hip_image_t& d) -> int {
-    CvtImage t;
-    t.y = static_cast<uint8_t*>(d.data);
-    t.u = static_cast<uint8_t*>(d.chroma_data);
-    t.v = t.u + d.chroma_stride * (d.height / 2);
-    t.y_stride = (uint32_t)d.luma_stride; t.c_stride = (uint32_t)d.chroma_stride;
-    t.width = (uint32_t)d.width; t.height = (uint32_t)d.height;
-    for (int i = 0; i < 9; ++i) t.m[i] = m[i];
-    t.sy = t.y; t.su = t.u; t.sv = t.v; t.sy_stride = t.y_stride; t.sc_stride = t.c_stride;   // in place
-    const bool aligned = t.width % 8u == 0 && al(t.y, 8) && t.y_stride % 8u == 0 && al(t.u, 4) && al(t.v, 4) &&
-                         t.c_stride % 4u == 0;
-    HIP_TRY(launch_convert_yuv(t, aligned, s));
-    return UHDR_HIP_NO_ERROR;
-  };
-  if (mem_space == UHDR_HIP_MEM_DEVICE) return run(*image);
-
+  auto run = [&](const uhdr_hip_image_t& d) -> int { return convert_yuv_into(d, d, m, s); };
   std::lock_guard<std::mutex> lk(g_host_mu);
   uhdr_hip_image_t d;
   if ((rc = stage_yuv420_in(st, 0, *image, &d, s)) != 0) return rc;

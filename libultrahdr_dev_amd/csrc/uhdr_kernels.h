@@ -116,6 +116,10 @@ struct ToneImage {
   uint32_t sy_stride, suv_stride, dy_stride, dc_stride;
   uint32_t width, height;
 };
+constexpr int kToneChunk = 32;  // images per toneMap / convertYuv launch (grid.z = image; 32 x 112 B of descriptors)
+struct ToneBatch {
+  ToneImage img[kToneChunk];
+};
 struct CvtImage {
   uint8_t* y;   // where the converted planes go ...
   uint8_t* u;
@@ -126,6 +130,9 @@ struct CvtImage {
   const uint8_t* su;   // image when the conversion is also the private copy encodeJPEGR API-1 takes first (jpegr.cpp:297-358)
   const uint8_t* sv;
   uint32_t sy_stride, sc_stride;
+};
+struct CvtBatch {   // m, width, height are taken from img[0]: one launch converts equally sized images between the same encodings
+  CvtImage img[kToneChunk];
 };
 
 // ---- editorhelper effects (crop / mirror / rotate / resize): byte gathers over planes ---------------
@@ -157,8 +164,9 @@ hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, i
 hipError_t launch_build_luts(float* lut /* kLutTotal floats */, hipStream_t s);
 // GainLUT table (kGainLutN floats, device) for (log2 min, log2 max, boost factor)
 hipError_t launch_build_gain_lut(float* table, double log2_min, double log2_max, float boost_factor, hipStream_t s);
-hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s);
-hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s);
+hipError_t launch_tonemap(const ToneBatch& b, int n, bool aligned, hipStream_t s);      // n <= kToneChunk images of equal width / height
+hipError_t launch_convert_yuv(const CvtBatch& b, int n, bool aligned, hipStream_t s);
+static_assert(sizeof(CvtBatch) <= 4096 && sizeof(ToneBatch) <= 4096, "toneMap / convertYuv kernel arguments exceed the kernarg segment");
 // decoded 4:2:0 planes -> RGBA8888 with libjpeg-turbo's arithmetic (k_ycc420_rgba); w, h even, strides in bytes
 hipError_t launch_ycc420_to_rgba(const uint8_t* y, const uint8_t* cb, const uint8_t* cr, uint32_t w, uint32_t h, uint32_t y_stride,
                                  uint32_t c_stride, uint8_t* rgba, hipStream_t s);

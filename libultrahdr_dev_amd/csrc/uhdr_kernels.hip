@@ -1427,9 +1427,10 @@ hipError_t launch_ycc420_to_rgba(const uint8_t* y, const uint8_t* cb, const uint
 // toneMap (ultrahdr.cpp:517-558): Y8 = (Y16 >> 6 >> 2) & 0xff == bits 15..8 of the P010 word
 // =================================================================================================
 
-// luma: grid.y = row; one thread per 8 (ALIGNED) or 1 destination bytes across [0, dy_stride)
+// luma: grid.y = row, grid.z = image; one thread per 8 (ALIGNED) or 1 destination bytes across [0, dy_stride)
 template <bool ALIGNED>
-__global__ void __launch_bounds__(256) k_tonemap_luma(const ToneImage t) {
+__global__ void __launch_bounds__(256) k_tonemap_luma(const ToneBatch b) {
+  const ToneImage& t = b.img[blockIdx.z];
   const uint32_t row = blockIdx.y;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint16_t* src = t.sy + (size_t)row * t.sy_stride;
@@ -1453,7 +1454,8 @@ __global__ void __launch_bounds__(256) k_tonemap_luma(const ToneImage t) {
 
 // chroma: grid.y = chroma row; U and V de-interleaved, padding [width/2, dc_stride) zeroed
 template <bool ALIGNED>
-__global__ void __launch_bounds__(256) k_tonemap_chroma(const ToneImage t) {
+__global__ void __launch_bounds__(256) k_tonemap_chroma(const ToneBatch b) {
+  const ToneImage& t = b.img[blockIdx.z];
   const uint32_t row = blockIdx.y;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t cw = t.width / 2u;
@@ -1485,19 +1487,20 @@ __global__ void __launch_bounds__(256) k_tonemap_chroma(const ToneImage t) {
   }
 }
 
-hipError_t launch_tonemap(const ToneImage& t, bool aligned, hipStream_t s) {
-  if (t.width == 0 || t.height == 0) return hipSuccess;
-  const uint32_t lcols = t.dy_stride > t.width ? t.dy_stride : t.width;
-  const uint32_t cw = t.width / 2u;
-  const uint32_t ccols = t.dc_stride > cw ? t.dc_stride : cw;
+hipError_t launch_tonemap(const ToneBatch& b, int n, bool aligned, hipStream_t s) {
+  const ToneImage& t = b.img[0];
+  if (n <= 0 || t.width == 0 || t.height == 0) return hipSuccess;
+  // the grid covers the widest destination row of the launch (every thread checks its own image's strides)
+  uint32_t lcols = t.width, ccols = t.width / 2u;
+  for (int i = 0; i < n; ++i) { lcols = b.img[i].dy_stride > lcols ? b.img[i].dy_stride : lcols; ccols = b.img[i].dc_stride > ccols ? b.img[i].dc_stride : ccols; }
   if (aligned) {
-    hipLaunchKernelGGL((k_tonemap_luma<true>), dim3((lcols / 8u + 255u) / 256u, t.height), dim3(256), 0, s, t);
+    hipLaunchKernelGGL((k_tonemap_luma<true>), dim3((lcols / 8u + 255u) / 256u, t.height, n), dim3(256), 0, s, b);
     if (t.height / 2u)
-      hipLaunchKernelGGL((k_tonemap_chroma<true>), dim3((ccols / 8u + 255u) / 256u, t.height / 2u), dim3(256), 0, s, t);
+      hipLaunchKernelGGL((k_tonemap_chroma<true>), dim3((ccols / 8u + 255u) / 256u, t.height / 2u, n), dim3(256), 0, s, b);
   } else {
-    hipLaunchKernelGGL((k_tonemap_luma<false>), dim3((lcols + 255u) / 256u, t.height), dim3(256), 0, s, t);
+    hipLaunchKernelGGL((k_tonemap_luma<false>), dim3((lcols + 255u) / 256u, t.height, n), dim3(256), 0, s, b);
     if (t.height / 2u && ccols)
-      hipLaunchKernelGGL((k_tonemap_chroma<false>), dim3((ccols + 255u) / 256u, t.height / 2u), dim3(256), 0, s, t);
+      hipLaunchKernelGGL((k_tonemap_chroma<false>), dim3((ccols + 255u) / 256u, t.height / 2u, n), dim3(256), 0, s, b);
   }
   return hipGetLastError();
 }
@@ -1534,7 +1537,8 @@ __device__ __forceinline__ void cvt_block(const float (&m)[9], uint32_t (&yb)[4]
 }
 
 template <bool ALIGNED>
-__global__ void __launch_bounds__(256) k_convert_yuv(const CvtImage t) {
+__global__ void __launch_bounds__(256) k_convert_yuv(const CvtBatch b) {
+  const CvtImage& t = b.img[blockIdx.z];
   const uint32_t cyr = blockIdx.y;  // chroma row
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t cw = t.width / 2u;
@@ -1561,7 +1565,7 @@ __global__ void __launch_bounds__(256) k_convert_yuv(const CvtImage t) {
       uint32_t yb[4] = {(top[k >> 1] >> sh) & 0xffu, (top[k >> 1] >> (sh + 8)) & 0xffu,
                         (bot[k >> 1] >> sh) & 0xffu, (bot[k >> 1] >> (sh + 8)) & 0xffu};
       uint32_t ub = (uw >> (8 * k)) & 0xffu, vb = (vw >> (8 * k)) & 0xffu;
-      cvt_block(t.m, yb, ub, vb);
+      cvt_block(b.img[0].m, yb, ub, vb);
       otop[k >> 1] |= (yb[0] << sh) | (yb[1] << (sh + 8));
       obot[k >> 1] |= (yb[2] << sh) | (yb[3] << (sh + 8));
       ou |= ub << (8 * k); ov |= vb << (8 * k);
@@ -1574,18 +1578,18 @@ __global__ void __launch_bounds__(256) k_convert_yuv(const CvtImage t) {
     if (i >= cw) return;
     uint32_t yb[4] = {sy0[2u * i], sy0[2u * i + 1u], sy1[2u * i], sy1[2u * i + 1u]};
     uint32_t ub = sur[i], vb = svr[i];
-    cvt_block(t.m, yb, ub, vb);
+    cvt_block(b.img[0].m, yb, ub, vb);
     y0[2u * i] = (uint8_t)yb[0]; y0[2u * i + 1u] = (uint8_t)yb[1];
     y1[2u * i] = (uint8_t)yb[2]; y1[2u * i + 1u] = (uint8_t)yb[3];
     ur[i] = (uint8_t)ub; vr[i] = (uint8_t)vb;
   }
 }
 
-hipError_t launch_convert_yuv(const CvtImage& t, bool aligned, hipStream_t s) {
-  const uint32_t cw = t.width / 2u, ch = t.height / 2u;
-  if (cw == 0 || ch == 0) return hipSuccess;
-  if (aligned) hipLaunchKernelGGL((k_convert_yuv<true>), dim3((cw / 4u + 255u) / 256u, ch), dim3(256), 0, s, t);
-  else hipLaunchKernelGGL((k_convert_yuv<false>), dim3((cw + 255u) / 256u, ch), dim3(256), 0, s, t);
+hipError_t launch_convert_yuv(const CvtBatch& b, int n, bool aligned, hipStream_t s) {
+  const uint32_t cw = b.img[0].width / 2u, ch = b.img[0].height / 2u;
+  if (n <= 0 || cw == 0 || ch == 0) return hipSuccess;
+  if (aligned) hipLaunchKernelGGL((k_convert_yuv<true>), dim3((cw / 4u + 255u) / 256u, ch, n), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((k_convert_yuv<false>), dim3((cw + 255u) / 256u, ch, n), dim3(256), 0, s, b);
   return hipGetLastError();
 }
 

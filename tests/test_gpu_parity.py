@@ -454,6 +454,48 @@ def test_convert_yuv_all_matrices(hip, orc, pair, layout):
     assert lib.uhdr_hip_convert_yuv(None, 0, 1, hip.MEM_DEVICE, stream_ptr()) == hip.ERROR_BAD_PTR
 
 
+def test_tonemap_and_convert_yuv_batches(hip, orc):
+    """the batched forms: 70 images in one call -- three launches of <= 32 equally sized images plus a ragged
+    tail that breaks the size run (and takes the element-wise kernels) -- every image equal to the oracle's single-image result"""
+    from tests.gpu_util import to_dev, to_host, stream_ptr
+    lib, olib = hip.load(), orc.load()
+    dims = [(128, 64)] * 67 + [(70, 34), (70, 34), (128, 64)]
+    srcs, dsts, keep, want = [], [], [], []
+    for i, (w, h) in enumerate(dims):
+        p010, yuv = orc.lcg_frame(w, h, 900 + i)
+        dls, dcs = (w, w // 2) if w == 128 else (w + 5, w // 2 + 3)
+        oy = np.full(dls * h, 0xEE, np.uint8); oc = np.full(dcs * h + dcs, 0xEE, np.uint8)
+        osrc, odst = orc.p010_image(p010, w, h, orc.CG_BT2100), orc.yuv420_image(oy, w, h, -1, dls, dcs, oc)
+        assert olib.orc_toneMap(C.byref(osrc), C.byref(odst)) == 0
+        dp = to_dev(p010)
+        dy, dc = to_dev(np.full(dls * h, 0xEE, np.uint8)), to_dev(np.full(dcs * h + dcs, 0xEE, np.uint8))
+        keep += [dp, dy, dc]
+        srcs.append(hip.p010_image(dp.data_ptr(), w, h, hip.CG_BT2100))
+        dsts.append(hip.yuv420_image(dy.data_ptr(), w, h, -1, dls, dcs, dc.data_ptr()))
+        want.append((oy, oc, dy, dc, dls, dcs, w, h))
+    sa, da = hip.image_array(srcs), hip.image_array(dsts)
+    assert lib.uhdr_hip_tonemap_batch(len(dims), sa, da, stream_ptr()) == 0
+    for i, (oy, oc, dy, dc, dls, dcs, w, h) in enumerate(want):
+        assert da[i].colorGamut == hip.CG_BT2100
+        assert np.array_equal(to_host(dy, dls * h), oy) and np.array_equal(to_host(dc, dcs * h + dcs), oc), i
+    # convertYuv in place on the tone-mapped images: BT.2100 -> BT.601, against the oracle on its own copies
+    assert lib.uhdr_hip_convert_yuv_batch(len(dims), da, hip.CG_BT2100, hip.CG_P3, stream_ptr()) == 0
+    for i, (oy, oc, dy, dc, dls, dcs, w, h) in enumerate(want):
+        oimg = orc.yuv420_image(oy, w, h, orc.CG_BT2100, dls, dcs, oc)
+        assert olib.orc_convertYuv(C.byref(oimg), orc.CG_BT2100, orc.CG_P3) == 0
+        assert np.array_equal(to_host(dy, dls * h), oy) and np.array_equal(to_host(dc, dcs * h + dcs), oc), i
+    # argument checks are the single form's, made for every image before anything is launched
+    assert lib.uhdr_hip_tonemap_batch(0, None, None, stream_ptr()) == 0
+    assert lib.uhdr_hip_tonemap_batch(2, None, da, stream_ptr()) == hip.ERROR_BAD_PTR
+    bad = hip.image_array([dsts[0], hip.yuv420_image(0, 128, 64, -1)])
+    assert lib.uhdr_hip_tonemap_batch(2, sa, bad, stream_ptr()) == hip.ERROR_BAD_PTR
+    mism = hip.image_array([dsts[0], hip.yuv420_image(want[1][2].data_ptr(), 64, 64, -1)])
+    assert lib.uhdr_hip_tonemap_batch(2, sa, mism, stream_ptr()) == hip.ERROR_RESOLUTION_MISMATCH
+    assert lib.uhdr_hip_convert_yuv_batch(2, da, -1, 1, stream_ptr()) == hip.ERROR_INVALID_COLORGAMUT
+    assert lib.uhdr_hip_convert_yuv_batch(2, da, 1, 1, stream_ptr()) == 0
+    assert lib.uhdr_hip_convert_yuv_batch(2, None, 0, 1, stream_ptr()) == hip.ERROR_BAD_PTR
+
+
 # --------------------------------------------------------------------------------------------------
 # batches, content min/max, host-memory entry points
 # --------------------------------------------------------------------------------------------------

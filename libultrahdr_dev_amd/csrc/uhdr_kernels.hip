@@ -527,12 +527,12 @@ __device__ __forceinline__ void exact_pair_gains(const GenConsts& c, const GenIm
 // extreme -- and could still beat the extreme already published for the image -- are re-evaluated on the exact path
 // (typically none).  Waves never wait for each other: a block-wide reduction here measured +25 % on the whole kernel,
 // because one wave in seven takes the exact path in some tile and its three siblings would idle at the barrier.
-template <int TF, bool ALIGNED, bool LUT, bool FILTER>
+template <int TF, bool ALIGNED, bool LUT, bool FILTER, int TILES>
 __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(const GenConsts c, const GenBatch b) {
   // LUT mode: block-private copies of the two tables (4 KiB + 16 KiB), so every lookup is an LDS gather
   __shared__ float s_srgb[LUT ? kLutSrgbInvN : 1];
   __shared__ float s_hdr[(LUT && TF != 0) ? kLutHlgInvN : 1];
-  __shared__ float s_kept[FILTER ? UHDR_GEN_TILES * 2 * UHDR_GEN_BLOCK : 1];  // FILTER: every thread's gains, for the candidate pass
+  __shared__ float s_kept[FILTER ? TILES * 2 * UHDR_GEN_BLOCK : 1];  // FILTER: every thread's gains, for the candidate pass
   if (LUT) {
     for (uint32_t i = threadIdx.x; i < kLutSrgbInvN / 4u; i += UHDR_GEN_BLOCK)
       reinterpret_cast<float4*>(s_srgb)[i] = reinterpret_cast<const float4*>(c.lut + kLutSrgbInv)[i];
@@ -554,11 +554,11 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
   float amin = __builtin_inff(), amax = -__builtin_inff();   // over all gains (estimates included)
   uint32_t kept_exact = 0u, kept_valid = 0u;                 // 2 bits per tile
 
-  // each block walks UHDR_GEN_TILES consecutive spans of UHDR_GEN_BLOCK pairs: fewer, longer-lived waves
+  // each block walks TILES consecutive spans of UHDR_GEN_BLOCK pairs: fewer, longer-lived waves
   // (wave launch + descriptor fetch is a measurable share of a ~10 us wave)
 #pragma unroll 1
-  for (uint32_t t = 0; t < (uint32_t)UHDR_GEN_TILES; ++t) {
-    const uint32_t idx = (blk * (uint32_t)UHDR_GEN_TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
+  for (uint32_t t = 0; t < (uint32_t)TILES; ++t) {
+    const uint32_t idx = (blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
     if (idx >= total) break;
     const uint32_t my = idx / pairs_per_row;
     const uint32_t pr = idx - my * pairs_per_row;
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
     const float max_lo = fmaxf(amax - e * __builtin_fabsf(amax), pub_max);
     uint32_t cand = 0u;                      // one bit per tile of this lane
 #pragma unroll
-    for (uint32_t t = 0; t < (uint32_t)UHDR_GEN_TILES; ++t)
+    for (uint32_t t = 0; t < (uint32_t)TILES; ++t)
 #pragma unroll
       for (uint32_t k = 0; k < 2u; ++k) {
         const uint32_t bit = 1u << (2u * t + k);
@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
       if (cand != 0u) {
         const uint32_t t = (uint32_t)__builtin_ctz(cand);
         cand &= cand - 1u;
-        const uint32_t idx = (blk * (uint32_t)UHDR_GEN_TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
+        const uint32_t idx = (blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
         const uint32_t my = idx / pairs_per_row, pr = idx - my * pairs_per_row;
         const bool two = ALIGNED || (pr * 2u + 1u < c.map_w);
         float gn[2];
@@ -658,9 +658,16 @@ template <int TF, bool ALIGNED, bool LUT, bool FILTER>
 static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   if (total == 0 || n == 0) return hipSuccess;
+  // Spans per block: UHDR_GEN_TILES (fewer, longer-lived waves) where the launch still fills the chip, one otherwise -- a single
+  // 4K image is 1013 spans: 254 blocks of 4 would put one wave on each SIMD and leave the memory system nothing to overlap.
   constexpr uint32_t kSpan = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
-  dim3 grid((unsigned)n, (total + kSpan - 1u) / kSpan, 1), block(UHDR_GEN_BLOCK, 1, 1);
-  hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER>), grid, block, 0, s, c, b);
+  const uint32_t blocks = (total + kSpan - 1u) / kSpan;
+  if ((uint64_t)blocks * (uint64_t)n >= 2048u) {
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES>), dim3((unsigned)n, blocks, 1), dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+  } else {
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1>), dim3((unsigned)n, (total + UHDR_GEN_BLOCK - 1u) / UHDR_GEN_BLOCK, 1),
+                       dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+  }
   return hipGetLastError();
 }
 
@@ -1136,6 +1143,16 @@ template <int FMT, bool MASK>
 __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_apply_s4(const AppConsts c, const AppBatch b) {
   typedef ApplyTab<FMT, MASK> T;
   __shared__ uint4 s_tab[T::kBytes / 16u];
+  const AppImage& im = b.img[blockIdx.y];
+  void* const dst = im.dst;
+  const uint32_t total = c.map_w * c.map_h;
+  uint32_t idx = blockIdx.x * c.cells_per_thread * kApplyBlock + threadIdx.x;
+  const bool any = idx < total;
+  uint32_t cy = idx / c.map_w;
+  uint32_t cx = idx - cy * c.map_w;
+  // the first cell's pixels are requested before the tables: both trips to memory overlap
+  ApplyCellIn cur;
+  if (any && UHDR_APPLY_EXPERIMENT != 2) apply_load_cell(c, im, cx, cy, cur);
   {
     // all loads first, then all stores: one trip through L2's latency per block instead of one per piece
     constexpr uint32_t kN1 = T::kS1Bytes / 16u, kPer1 = (kN1 + kApplyBlock - 1u) / kApplyBlock;
@@ -1156,13 +1173,7 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
   __syncthreads();
   const char* lut = reinterpret_cast<const char*>(s_tab);
   const uint32_t slot8 = (threadIdx.x & 31u) << 3;
-  const AppImage& im = b.img[blockIdx.y];
-  void* const dst = im.dst;
-  const uint32_t total = c.map_w * c.map_h;
-  uint32_t idx = blockIdx.x * c.cells_per_thread * kApplyBlock + threadIdx.x;
-  if (idx >= total) return;
-  uint32_t cy = idx / c.map_w;
-  uint32_t cx = idx - cy * c.map_w;
+  if (!any) return;
   if (T::kOetf) {
     // Round toward zero from here on: stage 2 truncates the code inside its fma.  The integer division above is expanded into
     // float operations that assume round-to-nearest, hence the (fake) dependence of its results on this statement; the cells that
@@ -1171,8 +1182,6 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
   }
   // The inputs of the next cell are requested before the current one is computed: a block's waves start together, and without
   // this they would also all wait for HBM together and all compute together.
-  ApplyCellIn cur;
-  if (UHDR_APPLY_EXPERIMENT != 2) apply_load_cell(c, im, cx, cy, cur);
 #pragma unroll 1
   for (uint32_t it = 0;; ++it) {
   const uint32_t nidx = idx + kApplyBlock;
@@ -1337,7 +1346,7 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     AppConsts cc = c;
     uint32_t cpt = kApplyMaxCellsPerThread;
     auto blocks = [&](uint32_t k) { return (uint64_t)((total + kApplyBlock * k - 1u) / (kApplyBlock * k)) * (uint64_t)n; };
-    while (cpt > 1u && blocks(cpt) < 2u * 256u) cpt >>= 1;
+    while (cpt > 1u && blocks(cpt) < 448u) cpt >>= 1;   // (a single 4K image: 507 blocks of 2 cells per thread, all resident at once)
     cc.cells_per_thread = cpt;
     const dim3 grid((unsigned)((total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt)), n);
     // channels can only reach 1024 (and wrap through the reference's & 0x3ff) when the display boost is

@@ -52,6 +52,9 @@ struct DeviceState {
   // encodeJPEGR: the gain-map JPEG is compressed on a stream of its own, next to the SDR image's conversion and compression
   hipStream_t aux = nullptr;
   hipEvent_t map_ready = nullptr;
+  // generate with statistics: the candidate lists of one launch (kStatWsBytes), one workspace per stream the caller has used --
+  // launches of one stream follow each other, launches of different streams may overlap
+  std::map<hipStream_t, uint32_t*> stat_ws;
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
 std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
@@ -242,6 +245,9 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   c.width = (uint32_t)w; c.height = (uint32_t)h;
   c.map_w = (uint32_t)(w / 4); c.map_h = (uint32_t)(h / 4);
   c.stat_keys = nullptr;
+  c.stat_stride = 2;
+  c.stat_ws = nullptr;
+  c.stat_out = nullptr;
   c.lut = nullptr;
   c.bias4096 = 4096.0f;
   // f32 pre-filter (gen_pair; error budget in DESIGN.md section 5): the fast gain is within kRel of the exact one
@@ -569,6 +575,7 @@ int uhdr_hip_shutdown(void) {
     for (auto& t : kv.second.idw) (void)hipFree(t.second);
     if (kv.second.lut) (void)hipFree(kv.second.lut);
     for (void* q : kv.second.pool) if (q) (void)hipFree(q);
+    for (auto& w : kv.second.stat_ws) if (w.second) (void)hipFree(w.second);
     for (int i = 0; i < 14; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
     if (kv.second.map_ready) (void)hipEventDestroy(kv.second.map_ready);
@@ -1643,8 +1650,10 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   fill_generate_metadata(hdr_tf, metadata);
+  // Content min / max.  The filtered kernel (the usual case) works in a workspace of the library: its candidates are resolved, the
+  // result written to content_minmax and the workspace cleared by k_stats_resolve.  The other kernels keep exact keys in
+  // content_minmax itself: cleared here, turned into floats by k_stats_finalize at the end.
   uint32_t* keys = reinterpret_cast<uint32_t*>(content_minmax);
-  if (keys && n > 0) HIP_TRY(launch_stats_init(keys, n, s));
 
   int i = 0;
   while (i < n) {
@@ -1652,6 +1661,7 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
     const uhdr_hip_image_t& y0 = yuvs[i];
     GenConsts c = generate_consts(y0.colorGamut, p010s[i].colorGamut, hdr_tf, sdr_is_601, y0.width, y0.height, *metadata);
     c.stat_keys = keys ? keys + 2 * i : nullptr;
+    c.stat_stride = 2;
     c.lut = lut ? st->lut : nullptr;
     GenBatch b;
     int m = 0;
@@ -1668,10 +1678,27 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
       fill_generate_dest(&y, &dests[i + m]);
       ++m;
     }
-    HIP_TRY(launch_generate(c, b, m, hdr_tf, aligned, lut, /*filter=*/generate_mode == UHDR_HIP_GENERATE_EXACT && c.flt_delta < 0.25f && c.min_boost >= 0.25f && c.max_boost <= 64.0f, s));
+    const bool filter = generate_mode == UHDR_HIP_GENERATE_EXACT && c.flt_delta < 0.25f && c.min_boost >= 0.25f && c.max_boost <= 64.0f;
+    const bool resolve = keys != nullptr && filter && aligned && !lut;   // the filtered kernel leaves the exact extremes to k_stats_resolve
+    if (resolve) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      uint32_t*& w = st->stat_ws[s];
+      if (w == nullptr) {   // cleared once: every launch leaves the headers cleared behind it
+        HIP_TRY(hipMalloc(&w, kStatWsBytes));
+        HIP_TRY(hipMemset(w, 0, kStatWsBytes));
+      }
+      c.stat_ws = w;
+      c.stat_keys = w + 4;
+      c.stat_stride = kStatWords;
+      c.stat_out = content_minmax + 2 * i;
+    } else if (keys != nullptr) {
+      HIP_TRY(launch_stats_init(keys + 2 * i, m, s));
+    }
+    HIP_TRY(launch_generate(c, b, m, hdr_tf, aligned, lut, filter, s));
+    if (resolve) HIP_TRY(launch_stats_resolve(c, b, m, hdr_tf, aligned, s));
+    else if (keys != nullptr) HIP_TRY(launch_stats_finalize(keys + 2 * i, m, s));
     i += m;
   }
-  if (keys && n > 0) HIP_TRY(launch_stats_finalize(keys, n, s));
   return UHDR_HIP_NO_ERROR;
 }
 

@@ -5,6 +5,7 @@
 
 namespace uhdr {
 
+constexpr uint32_t kStatHdr = 8, kStatCap = 2040, kStatWords = kStatHdr + kStatCap;   // candidate pairs per image before the image is swept exactly
 constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4 KiB kernarg segment: 64 x 56 B + consts)
 
 // ---- LUT mode (gainmapmath.cpp:21-64 static tables; opt-in) --------------------
@@ -51,6 +52,13 @@ struct GenConsts {
   uint32_t enc_byte_min, enc_byte_max;
   uint32_t width, height, map_w, map_h;
   uint32_t* stat_keys;  // 2 words per image of the launch (min key, max key), or nullptr
+  uint32_t stat_stride; // words between the key pairs of consecutive images (2 in a caller's min/max array)
+  // filtered kernel with statistics: per image kStatWords words -- [0] ~key of the smallest ESTIMATE seen, [1] key of the largest,
+  // [2] number of candidate pairs appended, [3] slices of k_stats_resolve that have finished, [4] [5] the exact keys (stat_keys points
+  // here, stat_stride = kStatWords), [8..] the candidates (pair indices).  k_stats_resolve evaluates them exactly, writes the
+  // image's (min, max) to stat_out and clears the header for the next launch: no memset and no finalize kernel around the launch.
+  uint32_t* stat_ws;
+  float* stat_out;
   const float* lut;     // device LUT buffer (LUT mode only)
   // f32 pre-filter of the exact path (see gen_pair): code-value scale, half-width of the "too close to an integer"
   // band, and the gains below / above which the clamp certainly applies
@@ -157,6 +165,9 @@ static_assert(sizeof(AppConsts) + sizeof(AppBatch) <= 4096, "apply kernel argume
 hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, bool lut,
                            bool filter, hipStream_t s);
 hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s);
+// after a filtered launch with statistics: the candidates of its images on the exact path, folded into stat_keys
+hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, hipStream_t s);
+constexpr size_t kStatWsBytes = sizeof(uint32_t) * kStatWords * (size_t)kMaxChunk;
 hipError_t launch_stats_finalize(uint32_t* keys, int n, hipStream_t s);
 // mode: 0 FAST, 1 EXACT, 2 LUT
 hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, int mode,

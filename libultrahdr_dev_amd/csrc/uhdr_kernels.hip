@@ -433,6 +433,9 @@ __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *p; }
 #ifndef UHDR_GEN_MINWAVES
 #define UHDR_GEN_MINWAVES 1
 #endif
+#ifndef UHDR_GEN_IMAGE_MAJOR
+#define UHDR_GEN_IMAGE_MAJOR 0   // 1: the blocks of an image are consecutive (scripts/ab)
+#endif
 
 // inputs of pair `idx` (two horizontally adjacent map pixels = an 8x4 pixel block of both images) -> registers
 template <bool ALIGNED>
@@ -544,7 +547,11 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
   }
   // consecutive workgroups belong to different images (grid.x = image): the images of a launch progress together, so
   // the extremes a finished wave publishes prune the statistics candidates of the image's later waves
+#if UHDR_GEN_IMAGE_MAJOR
+  const uint32_t img_i = blockIdx.y, blk = blockIdx.x;
+#else
   const uint32_t img_i = blockIdx.x, blk = blockIdx.y;
+#endif
   const GenImage& im = b.img[img_i];
   const uint8_t* im_v = im.u + (size_t)im.c_stride * (c.height / 2u);
   const uint32_t pairs_per_row = (c.map_w + 1u) >> 1;
@@ -597,46 +604,54 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
     }
   }
   if (!stats) return;
-  uint32_t* keys = c.stat_keys + 2u * img_i;
+  uint32_t* keys = c.stat_keys + (size_t)c.stat_stride * img_i;
 
   if (FILTER) {
-    // which estimates could be this wave's exact minimum / maximum, and could still move the image's extreme?
-    const uint32_t k0 = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t k1 = __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Which estimates could be the image's exact minimum / maximum?  An estimate a stands for an exact gain within e|a| of it, so
+    // the exact minimum of the image lies at or below (1 + e) x any estimate and at or below any exact gain seen -- by this wave or,
+    // through the image's words in device memory, by any wave before it.  A pixel whose a (1 - e) lies above that bound cannot be
+    // the minimum; the others (the pixel that IS the minimum always among them) are appended to the image's candidate list, which
+    // k_stats_resolve evaluates on the exact path after this kernel.  Nothing here runs the exact path: the streaming kernel keeps
+    // neither its code nor its registers.
+    uint32_t* ws = c.stat_ws + (size_t)kStatWords * img_i;
     wave_minmax(amin, amax);
     float wmin = emin, wmax = emax;          // what this wave already knows exactly (tiles that took the exact path)
     wave_minmax(wmin, wmax);
-    const float pub_min = fminf(k1 != 0u ? key_to_float(~k0) : __builtin_inff(), wmin);   // exact values only
-    const float pub_max = fmaxf(k1 != 0u ? key_to_float(k1) : -__builtin_inff(), wmax);
     const float e = c.flt_gain_rel;
-    const float min_hi = fminf(amin + e * __builtin_fabsf(amin), pub_min);   // an exact minimum cannot lie above this
-    const float max_lo = fmaxf(amax - e * __builtin_fabsf(amax), pub_max);
-    uint32_t cand = 0u;                      // one bit per tile of this lane
+    uint32_t e0 = __hip_atomic_load(&ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t e1 = __hip_atomic_load(&ws[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k0 = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k1 = __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (amin <= amax) {   // publish this wave's estimates (one lane; the words only grow)
+      const uint32_t m0 = ~float_to_key(amin), m1 = float_to_key(amax);
+      if ((threadIdx.x & 63u) == 0u) {
+        if (e0 < m0) atomicMax(&ws[0], m0);
+        if (e1 < m1) atomicMax(&ws[1], m1);
+      }
+      e0 = e0 < m0 ? m0 : e0; e1 = e1 < m1 ? m1 : e1;
+    }
+    float min_hi = fminf(k1 != 0u ? key_to_float(~k0) : __builtin_inff(), wmin);   // exact gains: the bound as it stands
+    float max_lo = fmaxf(k1 != 0u ? key_to_float(k1) : -__builtin_inff(), wmax);
+    if (e1 != 0u) {
+      const float pmin = key_to_float(~e0), pmax = key_to_float(e1);
+      min_hi = fminf(min_hi, pmin + e * __builtin_fabsf(pmin));
+      max_lo = fmaxf(max_lo, pmax - e * __builtin_fabsf(pmax));
+    }
 #pragma unroll
-    for (uint32_t t = 0; t < (uint32_t)TILES; ++t)
+    for (uint32_t t = 0; t < (uint32_t)TILES; ++t) {
+      bool cand = false;
 #pragma unroll
       for (uint32_t k = 0; k < 2u; ++k) {
         const uint32_t bit = 1u << (2u * t + k);
         if ((kept_valid & bit) && !(kept_exact & bit)) {
           const float a = s_kept[(2u * t + k) * UHDR_GEN_BLOCK + threadIdx.x], slack = e * __builtin_fabsf(a);
-          if ((a - slack <= min_hi) || (a + slack >= max_lo)) cand |= 1u << t;
+          cand = cand || (a - slack <= min_hi) || (a + slack >= max_lo);
         }
       }
-    // every pass lets each lane re-evaluate one of its candidate pairs (lanes may sit in different tiles), so the
-    // usual "one minimum, one maximum" costs one exact pass; flat content degrades to redoing the wave's tiles
-#pragma unroll 1
-    while (__builtin_amdgcn_ballot_w64(cand != 0u) != 0ull) {
-      UHDR_COUNT(2, 1);
-      if (cand != 0u) {
-        const uint32_t t = (uint32_t)__builtin_ctz(cand);
-        cand &= cand - 1u;
-        const uint32_t idx = (blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
-        const uint32_t my = idx / pairs_per_row, pr = idx - my * pairs_per_row;
-        const bool two = ALIGNED || (pr * 2u + 1u < c.map_w);
-        float gn[2];
-        exact_pair_gains<TF, ALIGNED, LUT>(c, im, im_v, my, pr, two, s_srgb, s_hdr, gn);
-        emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]);
-        if (two) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
+      if (cand) {
+        UHDR_COUNT(2, 1);
+        const uint32_t pos = atomicAdd(&ws[2], 1u);   // (beyond the capacity the count alone matters: the image is swept)
+        if (pos < kStatCap) ws[kStatHdr + pos] = (blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
       }
     }
   }
@@ -654,6 +669,68 @@ __global__ void k_stats_finalize(uint32_t* keys, int n) {
   keys[2 * i + 1] = __float_as_uint(mx);
 }
 
+// The candidates the filtered kernel left for an image (pair indices), evaluated on the exact path; an image whose list overflowed
+// (flat content: every pixel shares the extreme) is swept whole.  grid = (image, kResolveSlices), each block a slice of the work.
+constexpr uint32_t kResolveSlices = 16;
+template <int TF, bool ALIGNED>
+__global__ void __launch_bounds__(256) k_stats_resolve(const GenConsts c, const GenBatch b) {
+  const uint32_t img_i = blockIdx.x;
+  const GenImage& im = b.img[img_i];
+  const uint8_t* im_v = im.u + (size_t)im.c_stride * (c.height / 2u);
+  uint32_t* ws = c.stat_ws + (size_t)kStatWords * img_i;
+  const uint32_t pairs_per_row = (c.map_w + 1u) >> 1, total = pairs_per_row * c.map_h;
+  const uint32_t count = ws[2];
+  const bool sweep = count > kStatCap;
+  const uint32_t n = sweep ? total : count;
+  float emin = __builtin_inff(), emax = -__builtin_inff();
+#pragma unroll 1
+  for (uint32_t i = blockIdx.y * 256u + threadIdx.x; i < n; i += kResolveSlices * 256u) {
+    const uint32_t idx = sweep ? i : ws[kStatHdr + i];
+    const uint32_t my = idx / pairs_per_row, pr = idx - my * pairs_per_row;
+    const bool two = ALIGNED || (pr * 2u + 1u < c.map_w);
+    float gn[2];
+    exact_pair_gains<TF, ALIGNED, false>(c, im, im_v, my, pr, two, nullptr, nullptr, gn);
+    emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]);
+    if (two) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
+  }
+  wave_minmax(emin, emax);
+  publish_minmax(emin, emax, ws + 4);
+  // the slice that finishes last hands the image's extremes to the caller and clears the header for the next launch
+  // (no fence: a release at agent scope would write this XCD's whole L2 back -- the maps k_generate has just stored.  The keys
+  // are only ever touched by agent-scope atomics, which are performed at the memory side; waiting for this wave's to be
+  // acknowledged before the slice counts itself finished is the order that is needed.)
+  __shared__ uint32_t s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&ws[3], 1u);
+  __syncthreads();
+  if (s_last == kResolveSlices - 1u && threadIdx.x == 0) {
+    const uint32_t k0 = __hip_atomic_load(&ws[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k1 = __hip_atomic_load(&ws[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float mn = __builtin_inff(), mx = -__builtin_inff();  // image without map pixels
+    if (k1 != 0u) { mn = key_to_float(~k0); mx = key_to_float(k1); }
+    c.stat_out[2u * img_i] = mn;
+    c.stat_out[2u * img_i + 1u] = mx;
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; ++k) __hip_atomic_store(&ws[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <int TF>
+static hipError_t launch_stats_resolve_tf(const GenConsts& c, const GenBatch& b, int n, bool aligned, hipStream_t s) {
+  if (aligned) hipLaunchKernelGGL((k_stats_resolve<TF, true>), dim3((unsigned)n, kResolveSlices), dim3(256), 0, s, c, b);
+  else hipLaunchKernelGGL((k_stats_resolve<TF, false>), dim3((unsigned)n, kResolveSlices), dim3(256), 0, s, c, b);
+  return hipGetLastError();
+}
+hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, hipStream_t s) {
+  if (n <= 0 || c.stat_ws == nullptr || c.stat_out == nullptr) return hipSuccess;
+  switch (hdr_tf) {
+    case 0: return launch_stats_resolve_tf<0>(c, b, n, aligned, s);
+    case 1: return launch_stats_resolve_tf<1>(c, b, n, aligned, s);
+    case 2: return launch_stats_resolve_tf<2>(c, b, n, aligned, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <int TF, bool ALIGNED, bool LUT, bool FILTER>
 static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
@@ -663,9 +740,10 @@ static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n
   constexpr uint32_t kSpan = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
   const uint32_t blocks = (total + kSpan - 1u) / kSpan;
   if ((uint64_t)blocks * (uint64_t)n >= 2048u) {
-    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES>), dim3((unsigned)n, blocks, 1), dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES>), UHDR_GEN_IMAGE_MAJOR ? dim3(blocks, (unsigned)n, 1) : dim3((unsigned)n, blocks, 1), dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
   } else {
-    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1>), dim3((unsigned)n, (total + UHDR_GEN_BLOCK - 1u) / UHDR_GEN_BLOCK, 1),
+    const unsigned b1 = (total + UHDR_GEN_BLOCK - 1u) / UHDR_GEN_BLOCK;
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1>), UHDR_GEN_IMAGE_MAJOR ? dim3(b1, (unsigned)n, 1) : dim3((unsigned)n, b1, 1),
                        dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
   }
   return hipGetLastError();

@@ -1678,8 +1678,13 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
       fill_generate_dest(&y, &dests[i + m]);
       ++m;
     }
-    const bool filter = generate_mode == UHDR_HIP_GENERATE_EXACT && c.flt_delta < 0.25f && c.min_boost >= 0.25f && c.max_boost <= 64.0f;
-    const bool resolve = keys != nullptr && filter && aligned && !lut;   // the filtered kernel leaves the exact extremes to k_stats_resolve
+    bool filter = generate_mode == UHDR_HIP_GENERATE_EXACT && c.flt_delta < 0.25f && c.min_boost >= 0.25f && c.max_boost <= 64.0f;
+    // The filtered kernel of a large launch leaves its pixels in doubt and the exact extremes to k_generate_resolve.  A small
+    // launch (one 4K image) would pay that second kernel's latency with nothing to hide it behind: without statistics it runs the
+    // filtered kernel that falls back to the exact path in place, with statistics the exact kernel.
+    const bool small = generate_is_small(c, m);
+    if (small && keys != nullptr) filter = false;
+    const bool resolve = filter && aligned && !lut && !small;
     if (resolve) {
       std::lock_guard<std::mutex> lk(g_mu);
       uint32_t*& w = st->stat_ws[s];
@@ -1688,9 +1693,9 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
         HIP_TRY(hipMemset(w, 0, kStatWsBytes));
       }
       c.stat_ws = w;
-      c.stat_keys = w + 4;
+      c.stat_keys = keys ? w + 4 : nullptr;
       c.stat_stride = kStatWords;
-      c.stat_out = content_minmax + 2 * i;
+      c.stat_out = keys ? content_minmax + 2 * i : nullptr;
     } else if (keys != nullptr) {
       HIP_TRY(launch_stats_init(keys + 2 * i, m, s));
     }

@@ -5,7 +5,11 @@
 
 namespace uhdr {
 
-constexpr uint32_t kStatHdr = 8, kStatCap = 2040, kStatWords = kStatHdr + kStatCap;   // candidate pairs per image before the image is swept exactly
+// 64 KiB per image: header, then kStatLists lists of kStatCap entries (0.2 % of a 4K map's pixels are in doubt: ~1000 entries per
+// image, ~16 per list).  Several lists per image because a wave appends with ONE returning atomic on its list's count, and atomics
+// on one address are served one after the other at the memory side (~1 us each: a single count per image cost the kernel 30 %).
+constexpr uint32_t kStatLists = 64, kStatCap = 254, kStatHdr = 8 + kStatLists, kStatWords = kStatHdr + kStatLists * kStatCap;
+static_assert(kStatWords <= 16384, "statistics workspace per image");   // candidate pairs per image before the image is swept exactly
 constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4 KiB kernarg segment: 64 x 56 B + consts)
 
 // ---- LUT mode (gainmapmath.cpp:21-64 static tables; opt-in) --------------------
@@ -53,10 +57,12 @@ struct GenConsts {
   uint32_t width, height, map_w, map_h;
   uint32_t* stat_keys;  // 2 words per image of the launch (min key, max key), or nullptr
   uint32_t stat_stride; // words between the key pairs of consecutive images (2 in a caller's min/max array)
-  // filtered kernel with statistics: per image kStatWords words -- [0] ~key of the smallest ESTIMATE seen, [1] key of the largest,
-  // [2] number of candidate pairs appended, [3] slices of k_stats_resolve that have finished, [4] [5] the exact keys (stat_keys points
-  // here, stat_stride = kStatWords), [8..] the candidates (pair indices).  k_stats_resolve evaluates them exactly, writes the
-  // image's (min, max) to stat_out and clears the header for the next launch: no memset and no finalize kernel around the launch.
+  // filtered kernel (always): per image kStatWords words -- [0] ~key of the smallest ESTIMATE seen, [1] key of the largest,
+  // [3] slices of k_generate_resolve that have finished, [4] [5] the exact keys (stat_keys points here, stat_stride = kStatWords),
+  // [8 + l] entries in list l, [kStatHdr + l * kStatCap ..] list l: pairs with a pixel in doubt or a statistics candidate (a block
+  // appends to list blk % kStatLists; a count beyond kStatCap means: sweep the image).  k_generate_resolve
+  // redoes them on the exact path, writes the image's (min, max) to stat_out (when not null) and clears the header for the next
+  // launch: no memset and no finalize kernel around the launch.
   uint32_t* stat_ws;
   float* stat_out;
   const float* lut;     // device LUT buffer (LUT mode only)
@@ -164,8 +170,10 @@ static_assert(sizeof(AppConsts) + sizeof(AppBatch) <= 4096, "apply kernel argume
 // launchers (enqueue only; return hipError_t of the launch)
 hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, bool lut,
                            bool filter, hipStream_t s);
+// a launch of n images this size is too small to be worth k_generate_resolve's latency (a single 4K image: 13 us against 24)
+bool generate_is_small(const GenConsts& c, int n);
 hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s);
-// after a filtered launch with statistics: the candidates of its images on the exact path, folded into stat_keys
+// after every filtered launch: the pixels it left in doubt and its statistics candidates on the exact path
 hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, hipStream_t s);
 constexpr size_t kStatWsBytes = sizeof(uint32_t) * kStatWords * (size_t)kMaxChunk;
 hipError_t launch_stats_finalize(uint32_t* keys, int n, hipStream_t s);

@@ -182,9 +182,10 @@ __device__ __forceinline__ float cvt_word1(uint32_t w) {
 // within kFilterRelErr of the exact one (bounds measured exhaustively per function), so the
 // truncated code value can only differ when it lies within flt_delta of an integer; only waves holding such a
 // pixel (or one whose clamp decision is in doubt) pay for the exact path.  Bytes are identical either way.
-// Returns a 2-bit mask: bit k set <=> gain[k] is the exact (reference) unclamped gain; a clear bit means gain[k] is the
-// filter's estimate, within GenConsts::flt_gain_rel of it.
-template <int TF, bool LUT, bool FILTER>
+// Returns a mask: bit k (k = 0, 1) set <=> gain[k] is the exact (reference) unclamped gain; a clear bit means gain[k] is the
+// filter's estimate, within GenConsts::flt_gain_rel of it -- unless bit 2 + k is set: that pixel is in doubt (FILTER only), its
+// byte and gain are provisional.
+template <int TF, bool LUT, bool FILTER, bool DEFER = false>
 __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t (&hy)[2][4][2],
                                              const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
                                              const uint32_t (&u8)[2][2], const uint32_t (&v8)[2][2],
@@ -283,8 +284,7 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
       qr = t0; qg = t1; qb = t2;
     }
     const f2 fh = (splat(c.lum_r) * qr + splat(c.lum_g) * qg + splat(c.lum_b) * qb) * splat(c.hdr_white_nits);
-    bool doubt = false;
-    uint32_t fbyte[2], fexact = 0u;
+    uint32_t fbyte[2], fexact = 0u, doubt = 0u;
     float fgain[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -297,7 +297,7 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
       const bool mid = (fr2 >= c.flt_delta) && (fr2 <= 1.0f - c.flt_delta);
       // luminances below 1e-10 leave the relative-error regime of the fast functions (denormal intermediates)
       const bool sane = !(ys > 0.0f && ys < 1e-10f) && !(yh != 0.0f && __builtin_fabsf(yh) < 1e-10f);
-      doubt |= !((lo || hi || mid) && sane);
+      if (!((lo || hi || mid) && sane)) doubt |= 1u << k;
       fbyte[k] = lo ? c.enc_byte_min : hi ? c.enc_byte_max : (uint32_t)fl;
       fgain[k] = gf;
       // the fast and the exact sRGB EOTF are zero for the same inputs only, so "SDR luminance is zero" (gain := 1,
@@ -305,15 +305,17 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
       if (!(ys > 0.0f)) fexact |= 1u << k;
     }
 #if UHDR_GEN_EXPERIMENT == 3   // filter without fallback
-    doubt = false;
+    doubt = 0u;
 #endif
     UHDR_COUNT(0, 1);
-    UHDR_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(doubt)));
-    if (__builtin_amdgcn_ballot_w64(doubt) != 0ull) UHDR_COUNT(1, 1);
-    if (__builtin_amdgcn_ballot_w64(doubt) == 0ull) {
+    UHDR_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(doubt != 0u)));
+    // DEFER (large launches): the kernel never runs the exact path: a pixel in doubt keeps its estimate's byte for now and is
+    // handed (bits 2, 3 of the result) to k_generate_resolve, which replaces the byte and accounts for the pixel's exact gain.
+    // Otherwise (a launch too small to be worth a second kernel's latency) a wave holding such a pixel runs the exact path below.
+    if (DEFER || __builtin_amdgcn_ballot_w64(doubt != 0u) == 0ull) {
       out[0] = (uint8_t)fbyte[0]; out[1] = (uint8_t)fbyte[1];
       gain[0] = fgain[0]; gain[1] = fgain[1];
-      return fexact;
+      return fexact | (doubt << 2);
     }
   }
   // independent f64 evaluations advanced in lock step: 6 = 3 channels x 2 pixels.  Measured on MI355X
@@ -508,14 +510,12 @@ __device__ __forceinline__ void publish_minmax(float gmin, float gmax, uint32_t*
   }
 }
 
-// exact unclamped gains of pair (my, pr): the statistics pass re-evaluates a handful of pixels with this
-// (inlined: as an out-of-line call it needs 168 VGPRs and 3.7 KB of scratch for the argument arrays)
+// exact bytes and unclamped gains of pair (my, pr): what k_generate_resolve runs on the pixels the filtered kernel left to it
 template <int TF, bool ALIGNED, bool LUT>
-__device__ __forceinline__ void exact_pair_gains(const GenConsts& c, const GenImage& im, const uint8_t* im_v, uint32_t my,
-                                                 uint32_t pr, bool two, const float* s_srgb, const float* s_hdr, float (&gn)[2]) {
+__device__ __forceinline__ void exact_pair(const GenConsts& c, const GenImage& im, const uint8_t* im_v, uint32_t my,
+                                           uint32_t pr, bool two, const float* s_srgb, const float* s_hdr, uint8_t (&o)[2], float (&gn)[2]) {
   uint32_t hy[2][4][2], huv[2][2][2], y8[2][4], u8[2][2], v8[2][2];
   load_pair<ALIGNED>(c, im, im_v, my, pr, two, hy, huv, y8, u8, v8);
-  uint8_t o[2];
   gen_pair<TF, LUT, false>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);
 }
 
@@ -530,12 +530,17 @@ __device__ __forceinline__ void exact_pair_gains(const GenConsts& c, const GenIm
 // extreme -- and could still beat the extreme already published for the image -- are re-evaluated on the exact path
 // (typically none).  Waves never wait for each other: a block-wide reduction here measured +25 % on the whole kernel,
 // because one wave in seven takes the exact path in some tile and its three siblings would idle at the barrier.
-template <int TF, bool ALIGNED, bool LUT, bool FILTER, int TILES>
-__global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(const GenConsts c, const GenBatch b) {
+#ifdef UHDR_GEN_MAXWAVES
+#define UHDR_GEN_OCC __attribute__((amdgpu_waves_per_eu(1, UHDR_GEN_MAXWAVES)))
+#else
+#define UHDR_GEN_OCC
+#endif
+template <int TF, bool ALIGNED, bool LUT, bool FILTER, int TILES, bool DEFER>
+__global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OCC k_generate(const GenConsts c, const GenBatch b) {
   // LUT mode: block-private copies of the two tables (4 KiB + 16 KiB), so every lookup is an LDS gather
   __shared__ float s_srgb[LUT ? kLutSrgbInvN : 1];
   __shared__ float s_hdr[(LUT && TF != 0) ? kLutHlgInvN : 1];
-  __shared__ float s_kept[FILTER ? TILES * 2 * UHDR_GEN_BLOCK : 1];  // FILTER: every thread's gains, for the candidate pass
+  __shared__ float s_kept[(FILTER && DEFER) ? TILES * 2 * UHDR_GEN_BLOCK : 1];  // FILTER: every thread's gains, for the candidate pass
   if (LUT) {
     for (uint32_t i = threadIdx.x; i < kLutSrgbInvN / 4u; i += UHDR_GEN_BLOCK)
       reinterpret_cast<float4*>(s_srgb)[i] = reinterpret_cast<const float4*>(c.lut + kLutSrgbInv)[i];
@@ -559,7 +564,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
   const bool stats = c.stat_keys != nullptr;
   float emin = __builtin_inff(), emax = -__builtin_inff();   // over gains known exactly
   float amin = __builtin_inff(), amax = -__builtin_inff();   // over all gains (estimates included)
-  uint32_t kept_exact = 0u, kept_valid = 0u;                 // 2 bits per tile
+  uint32_t kept_exact = 0u, kept_valid = 0u, kept_doubt = 0u;   // 2 bits per tile
 
   // each block walks TILES consecutive spans of UHDR_GEN_BLOCK pairs: fewer, longer-lived waves
   // (wave launch + descriptor fetch is a measurable share of a ~10 us wave)
@@ -578,19 +583,24 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
     uint8_t o[2];
     float gn[2];
     // a missing second pixel is computed on zeros and dropped
-    const uint32_t ex = gen_pair<TF, LUT, FILTER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);
+    const uint32_t ex = gen_pair<TF, LUT, FILTER, DEFER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);
     const uint8_t o0 = o[0], o1 = o[1];
-    if (FILTER) {
+    if (FILTER && DEFER) {
+      // pixels in doubt: their bytes are provisional -- the pair goes onto the image's list once the wave has finished its tiles,
+      // flags = which of its two pixels k_generate_resolve has to redo -- and their gains take no part in the statistics here
+      const uint32_t dm = (ex >> 2) & (two ? 3u : 1u);
+      kept_doubt |= dm << (2u * t);
       if (stats) {
         s_kept[(2u * t) * UHDR_GEN_BLOCK + threadIdx.x] = gn[0];
         s_kept[(2u * t + 1u) * UHDR_GEN_BLOCK + threadIdx.x] = gn[1];
+        const uint32_t valid = (two ? 3u : 1u) & ~dm;
+        kept_exact |= (ex & 3u) << (2u * t);
+        kept_valid |= valid << (2u * t);
+        if (valid & 1u) { amin = fminf(amin, gn[0]); amax = fmaxf(amax, gn[0]); }
+        if (valid & 2u) { amin = fminf(amin, gn[1]); amax = fmaxf(amax, gn[1]); }
+        if (ex & valid & 1u) { emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]); }
+        if (ex & valid & 2u) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
       }
-      kept_exact |= ex << (2u * t);
-      kept_valid |= (two ? 3u : 1u) << (2u * t);
-      amin = fminf(amin, gn[0]); amax = fmaxf(amax, gn[0]);
-      if (two) { amin = fminf(amin, gn[1]); amax = fmaxf(amax, gn[1]); }
-      if (ex & 1u) { emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]); }
-      if (two && (ex & 2u)) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
     } else {
       emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]);
       if (two) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
@@ -603,57 +613,78 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) k_generate(
       if (two) mp[1] = o1;
     }
   }
-  if (!stats) return;
-  uint32_t* keys = c.stat_keys + (size_t)c.stat_stride * img_i;
+  if (FILTER && !DEFER) return;   // (small launches without statistics: launch_generate_t)
+  if (!FILTER && !stats) return;
+  uint32_t* keys = stats ? c.stat_keys + (size_t)c.stat_stride * img_i : nullptr;
 
   if (FILTER) {
-    // Which estimates could be the image's exact minimum / maximum?  An estimate a stands for an exact gain within e|a| of it, so
-    // the exact minimum of the image lies at or below (1 + e) x any estimate and at or below any exact gain seen -- by this wave or,
-    // through the image's words in device memory, by any wave before it.  A pixel whose a (1 - e) lies above that bound cannot be
-    // the minimum; the others (the pixel that IS the minimum always among them) are appended to the image's candidate list, which
-    // k_stats_resolve evaluates on the exact path after this kernel.  Nothing here runs the exact path: the streaming kernel keeps
-    // neither its code nor its registers.
     uint32_t* ws = c.stat_ws + (size_t)kStatWords * img_i;
-    wave_minmax(amin, amax);
-    float wmin = emin, wmax = emax;          // what this wave already knows exactly (tiles that took the exact path)
-    wave_minmax(wmin, wmax);
-    const float e = c.flt_gain_rel;
-    uint32_t e0 = __hip_atomic_load(&ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t e1 = __hip_atomic_load(&ws[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t k0 = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t k1 = __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (amin <= amax) {   // publish this wave's estimates (one lane; the words only grow)
-      const uint32_t m0 = ~float_to_key(amin), m1 = float_to_key(amax);
-      if ((threadIdx.x & 63u) == 0u) {
-        if (e0 < m0) atomicMax(&ws[0], m0);
-        if (e1 < m1) atomicMax(&ws[1], m1);
+    uint32_t cand = 0u;   // one bit per tile: a statistics candidate
+    if (stats) {
+      // Which estimates could be the image's exact minimum / maximum?  An estimate a stands for an exact gain within e|a| of it, so
+      // the exact minimum of the image lies at or below (1 + e) x any estimate and at or below any exact gain seen -- by this wave
+      // or, through the image's words in device memory, by any wave before it.  A pixel whose a (1 - e) lies above that bound
+      // cannot be the minimum; the others (the pixel that IS the minimum always among them) go onto the image's list, which
+      // k_generate_resolve evaluates on the exact path after this kernel.
+      wave_minmax(amin, amax);
+      float wmin = emin, wmax = emax;          // what this wave already knows exactly (gain := 1 of pixels without SDR luminance)
+      wave_minmax(wmin, wmax);
+      const float e = c.flt_gain_rel;
+      uint32_t e0 = __hip_atomic_load(&ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t e1 = __hip_atomic_load(&ws[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t k0 = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t k1 = __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (amin <= amax) {   // publish this wave's estimates (one lane; the words only grow)
+        const uint32_t m0 = ~float_to_key(amin), m1 = float_to_key(amax);
+        if ((threadIdx.x & 63u) == 0u) {
+          if (e0 < m0) atomicMax(&ws[0], m0);
+          if (e1 < m1) atomicMax(&ws[1], m1);
+        }
+        e0 = e0 < m0 ? m0 : e0; e1 = e1 < m1 ? m1 : e1;
       }
-      e0 = e0 < m0 ? m0 : e0; e1 = e1 < m1 ? m1 : e1;
+      float min_hi = fminf(k1 != 0u ? key_to_float(~k0) : __builtin_inff(), wmin);   // exact gains: the bound as it stands
+      float max_lo = fmaxf(k1 != 0u ? key_to_float(k1) : -__builtin_inff(), wmax);
+      if (e1 != 0u) {
+        const float pmin = key_to_float(~e0), pmax = key_to_float(e1);
+        min_hi = fminf(min_hi, pmin + e * __builtin_fabsf(pmin));
+        max_lo = fmaxf(max_lo, pmax - e * __builtin_fabsf(pmax));
+      }
+#pragma unroll
+      for (uint32_t t = 0; t < (uint32_t)TILES; ++t)
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+          const uint32_t bit = 1u << (2u * t + k);
+          if ((kept_valid & bit) && !(kept_exact & bit)) {
+            const float a = s_kept[(2u * t + k) * UHDR_GEN_BLOCK + threadIdx.x], slack = e * __builtin_fabsf(a);
+            if ((a - slack <= min_hi) || (a + slack >= max_lo)) cand |= 1u << t;
+          }
+        }
     }
-    float min_hi = fminf(k1 != 0u ? key_to_float(~k0) : __builtin_inff(), wmin);   // exact gains: the bound as it stands
-    float max_lo = fmaxf(k1 != 0u ? key_to_float(k1) : -__builtin_inff(), wmax);
-    if (e1 != 0u) {
-      const float pmin = key_to_float(~e0), pmax = key_to_float(e1);
-      min_hi = fminf(min_hi, pmin + e * __builtin_fabsf(pmin));
-      max_lo = fmaxf(max_lo, pmax - e * __builtin_fabsf(pmax));
-    }
+    // One append per wave for everything it leaves to k_generate_resolve: a returning atomic per tile would park the wave for a
+    // trip to the memory side in one tile out of five.
+    unsigned long long mask[TILES];
+    uint32_t total = 0u;
 #pragma unroll
     for (uint32_t t = 0; t < (uint32_t)TILES; ++t) {
-      bool cand = false;
+      mask[t] = __builtin_amdgcn_ballot_w64((((kept_doubt >> (2u * t)) & 3u) | ((cand >> t) & 1u)) != 0u);
+      total += (uint32_t)__builtin_popcountll(mask[t]);
+    }
+    if (total != 0u) {
+      UHDR_COUNT(2, total);
+      const uint32_t lane = threadIdx.x & 63u, list = blk % kStatLists;
+      uint32_t base = 0u;
+      if (lane == 0u) base = atomicAdd(&ws[8u + list], total);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      uint32_t* lw = ws + kStatHdr + list * kStatCap;
 #pragma unroll
-      for (uint32_t k = 0; k < 2u; ++k) {
-        const uint32_t bit = 1u << (2u * t + k);
-        if ((kept_valid & bit) && !(kept_exact & bit)) {
-          const float a = s_kept[(2u * t + k) * UHDR_GEN_BLOCK + threadIdx.x], slack = e * __builtin_fabsf(a);
-          cand = cand || (a - slack <= min_hi) || (a + slack >= max_lo);
-        }
-      }
-      if (cand) {
-        UHDR_COUNT(2, 1);
-        const uint32_t pos = atomicAdd(&ws[2], 1u);   // (beyond the capacity the count alone matters: the image is swept)
-        if (pos < kStatCap) ws[kStatHdr + pos] = (blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
+      for (uint32_t t = 0; t < (uint32_t)TILES; ++t) {
+        const uint32_t flags = ((kept_doubt >> (2u * t)) & 3u) | (((cand >> t) & 1u) << 2);
+        const uint32_t pos = base + (uint32_t)__builtin_popcountll(mask[t] & ((1ull << lane) - 1ull));
+        if (flags != 0u && pos < kStatCap) lw[pos] = (((blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x) << 3) | flags;
+        base += (uint32_t)__builtin_popcountll(mask[t]);
       }
     }
+    if (!stats) return;
   }
   wave_minmax(emin, emax);
   publish_minmax(emin, emax, keys);
@@ -669,33 +700,66 @@ __global__ void k_stats_finalize(uint32_t* keys, int n) {
   keys[2 * i + 1] = __float_as_uint(mx);
 }
 
-// The candidates the filtered kernel left for an image (pair indices), evaluated on the exact path; an image whose list overflowed
-// (flat content: every pixel shares the extreme) is swept whole.  grid = (image, kResolveSlices), each block a slice of the work.
+// What the filtered kernel left for an image, on the exact path: list entries are (pair index << 3 | flags) -- flags 1 / 2: that
+// pixel of the pair was in doubt, its byte is replaced and its exact gain joins the statistics; flag 4: a statistics candidate,
+// both gains join.  An image whose list overflowed (flat content at a code boundary: every pixel in doubt) is swept whole.
+// grid = (image, kResolveSlices), each block a slice of the work; the slice that finishes last writes the image's (min, max) and
+// clears the header words for the next launch.
 constexpr uint32_t kResolveSlices = 16;
+static_assert(kStatLists == 64u, "k_generate_resolve reads the list counts with one wave");
 template <int TF, bool ALIGNED>
-__global__ void __launch_bounds__(256) k_stats_resolve(const GenConsts c, const GenBatch b) {
+__global__ void __launch_bounds__(256) k_generate_resolve(const GenConsts c, const GenBatch b) {
   const uint32_t img_i = blockIdx.x;
   const GenImage& im = b.img[img_i];
   const uint8_t* im_v = im.u + (size_t)im.c_stride * (c.height / 2u);
   uint32_t* ws = c.stat_ws + (size_t)kStatWords * img_i;
   const uint32_t pairs_per_row = (c.map_w + 1u) >> 1, total = pairs_per_row * c.map_h;
-  const uint32_t count = ws[2];
-  const bool sweep = count > kStatCap;
-  const uint32_t n = sweep ? total : count;
+  const bool stats = c.stat_out != nullptr;
   float emin = __builtin_inff(), emax = -__builtin_inff();
+  // one loop for both forms (the exact path is large): thread g of the image takes pair g (sweep) or entry g of the image's lists
+  // laid end to end (their exclusive prefix sums in LDS), so that the few entries fill whole waves
+  __shared__ uint32_t s_first[kStatLists + 1u];
+  __shared__ uint32_t s_sweep;
+  if (threadIdx.x < 64u) {   // the counts in one trip to memory (kStatLists == 64), prefix sums by wave shuffles
+    const uint32_t cnt = ws[8u + threadIdx.x];
+    const bool over = __builtin_amdgcn_ballot_w64(cnt > kStatCap) != 0ull;
+    uint32_t inc = min(cnt, kStatCap);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)inc, off, 64);
+      if ((int)threadIdx.x >= off) inc += v;
+    }
+    s_first[threadIdx.x + 1u] = inc;
+    if (threadIdx.x == 0) { s_first[0] = 0u; s_sweep = over ? 1u : 0u; }
+  }
+  __syncthreads();
+  const bool sweep = s_sweep != 0u;
+  const uint32_t n = sweep ? total : s_first[kStatLists];
 #pragma unroll 1
-  for (uint32_t i = blockIdx.y * 256u + threadIdx.x; i < n; i += kResolveSlices * 256u) {
-    const uint32_t idx = sweep ? i : ws[kStatHdr + i];
+  for (uint32_t g = blockIdx.y * 256u + threadIdx.x; g < n; g += kResolveSlices * 256u) {
+    uint32_t entry = (g << 3) | 7u;
+    if (!sweep) {
+      uint32_t l = 0u;
+#pragma unroll
+      for (uint32_t s2 = kStatLists / 2u; s2 != 0u; s2 >>= 1) if (s_first[l + s2] <= g) l += s2;   // the list that holds entry g
+      entry = ws[kStatHdr + l * kStatCap + (g - s_first[l])];
+    }
+    const uint32_t idx = entry >> 3;
     const uint32_t my = idx / pairs_per_row, pr = idx - my * pairs_per_row;
     const bool two = ALIGNED || (pr * 2u + 1u < c.map_w);
+    uint8_t o[2];
     float gn[2];
-    exact_pair_gains<TF, ALIGNED, false>(c, im, im_v, my, pr, two, nullptr, nullptr, gn);
-    emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]);
-    if (two) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
+    exact_pair<TF, ALIGNED, false>(c, im, im_v, my, pr, two, nullptr, nullptr, o, gn);
+    uint8_t* mp = im.map + (size_t)my * c.map_w + 2u * pr;
+    if (entry & 1u) mp[0] = o[0];
+    if ((entry & 2u) && two) mp[1] = o[1];
+    if ((entry & 5u) != 0u) { emin = fminf(emin, gn[0]); emax = fmaxf(emax, gn[0]); }
+    if ((entry & 6u) != 0u && two) { emin = fminf(emin, gn[1]); emax = fmaxf(emax, gn[1]); }
   }
-  wave_minmax(emin, emax);
-  publish_minmax(emin, emax, ws + 4);
-  // the slice that finishes last hands the image's extremes to the caller and clears the header for the next launch
+  if (stats) {
+    wave_minmax(emin, emax);
+    publish_minmax(emin, emax, ws + 4);
+  }
   // (no fence: a release at agent scope would write this XCD's whole L2 back -- the maps k_generate has just stored.  The keys
   // are only ever touched by agent-scope atomics, which are performed at the memory side; waiting for this wave's to be
   // acknowledged before the slice counts itself finished is the order that is needed.)
@@ -705,24 +769,26 @@ __global__ void __launch_bounds__(256) k_stats_resolve(const GenConsts c, const 
   if (threadIdx.x == 0) s_last = atomicAdd(&ws[3], 1u);
   __syncthreads();
   if (s_last == kResolveSlices - 1u && threadIdx.x == 0) {
-    const uint32_t k0 = __hip_atomic_load(&ws[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t k1 = __hip_atomic_load(&ws[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float mn = __builtin_inff(), mx = -__builtin_inff();  // image without map pixels
-    if (k1 != 0u) { mn = key_to_float(~k0); mx = key_to_float(k1); }
-    c.stat_out[2u * img_i] = mn;
-    c.stat_out[2u * img_i + 1u] = mx;
+    if (stats) {
+      const uint32_t k0 = __hip_atomic_load(&ws[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t k1 = __hip_atomic_load(&ws[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float mn = __builtin_inff(), mx = -__builtin_inff();  // image without map pixels
+      if (k1 != 0u) { mn = key_to_float(~k0); mx = key_to_float(k1); }
+      c.stat_out[2u * img_i] = mn;
+      c.stat_out[2u * img_i + 1u] = mx;
+    }
 #pragma unroll
-    for (uint32_t k = 0; k < 6u; ++k) __hip_atomic_store(&ws[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t k = 0; k < 8u + kStatLists; ++k) __hip_atomic_store(&ws[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 template <int TF>
 static hipError_t launch_stats_resolve_tf(const GenConsts& c, const GenBatch& b, int n, bool aligned, hipStream_t s) {
-  if (aligned) hipLaunchKernelGGL((k_stats_resolve<TF, true>), dim3((unsigned)n, kResolveSlices), dim3(256), 0, s, c, b);
-  else hipLaunchKernelGGL((k_stats_resolve<TF, false>), dim3((unsigned)n, kResolveSlices), dim3(256), 0, s, c, b);
+  if (aligned) hipLaunchKernelGGL((k_generate_resolve<TF, true>), dim3((unsigned)n, kResolveSlices), dim3(256), 0, s, c, b);
+  else hipLaunchKernelGGL((k_generate_resolve<TF, false>), dim3((unsigned)n, kResolveSlices), dim3(256), 0, s, c, b);
   return hipGetLastError();
 }
 hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, hipStream_t s) {
-  if (n <= 0 || c.stat_ws == nullptr || c.stat_out == nullptr) return hipSuccess;
+  if (n <= 0 || c.stat_ws == nullptr) return hipSuccess;
   switch (hdr_tf) {
     case 0: return launch_stats_resolve_tf<0>(c, b, n, aligned, s);
     case 1: return launch_stats_resolve_tf<1>(c, b, n, aligned, s);
@@ -731,20 +797,37 @@ hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, in
   }
 }
 
+bool generate_is_small(const GenConsts& c, int n) {
+  const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
+  const uint32_t span = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
+  return (uint64_t)((total + span - 1u) / span) * (uint64_t)n < 2048u;
+}
+
 template <int TF, bool ALIGNED, bool LUT, bool FILTER>
 static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   if (total == 0 || n == 0) return hipSuccess;
   // Spans per block: UHDR_GEN_TILES (fewer, longer-lived waves) where the launch still fills the chip, one otherwise -- a single
   // 4K image is 1013 spans: 254 blocks of 4 would put one wave on each SIMD and leave the memory system nothing to overlap.
-  constexpr uint32_t kSpan = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
-  const uint32_t blocks = (total + kSpan - 1u) / kSpan;
-  if ((uint64_t)blocks * (uint64_t)n >= 2048u) {
-    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES>), UHDR_GEN_IMAGE_MAJOR ? dim3(blocks, (unsigned)n, 1) : dim3((unsigned)n, blocks, 1), dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+  // Filtered kernel: a large launch leaves its pixels in doubt to k_generate_resolve (c.stat_ws set by the caller); a small one
+  // (c.stat_ws null) runs the exact path in place, for the waves that hold such a pixel.
+  const bool small = generate_is_small(c, n);
+  const unsigned b4 = (total + (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES - 1u) / ((uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES);
+  const unsigned b1 = (total + UHDR_GEN_BLOCK - 1u) / UHDR_GEN_BLOCK;
+  const dim3 g4 = UHDR_GEN_IMAGE_MAJOR ? dim3(b4, (unsigned)n, 1) : dim3((unsigned)n, b4, 1);
+  const dim3 g1 = UHDR_GEN_IMAGE_MAJOR ? dim3(b1, (unsigned)n, 1) : dim3((unsigned)n, b1, 1);
+  if (FILTER) {
+    if (c.stat_ws != nullptr) {
+      if (small) hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, true>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+      else hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES, true>), g4, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+    } else {
+      if (c.stat_keys != nullptr) return hipErrorInvalidValue;   // statistics of a filtered launch need the workspace
+      hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+    }
+  } else if (small) {
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
   } else {
-    const unsigned b1 = (total + UHDR_GEN_BLOCK - 1u) / UHDR_GEN_BLOCK;
-    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1>), UHDR_GEN_IMAGE_MAJOR ? dim3(b1, (unsigned)n, 1) : dim3((unsigned)n, b1, 1),
-                       dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES, false>), g4, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
   }
   return hipGetLastError();
 }

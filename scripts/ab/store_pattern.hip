@@ -71,6 +71,31 @@ __global__ void __launch_bounds__(512) k_cells_read(const uint8_t* y, const uint
   if (acc == 0x12345678u) sink[threadIdx.x] = acc;
 }
 
+// generate's read pattern: thread = 2 map pixels = 8 x 4 px of both images: P010 Y 4 x 16 B, P010 UV 2 x 16 B, Y8 4 x 8 B, U / V 2 x 4 B each
+template <int BLOCK, bool NT> __global__ void __launch_bounds__(BLOCK) k_gen_read(const uint16_t* hy, const uint16_t* huv, const uint8_t* y, const uint8_t* u, uint32_t* sink, uint32_t tiles, int image_major) {
+  const uint32_t img = image_major ? blockIdx.y : blockIdx.x, blk = image_major ? blockIdx.x : blockIdx.y;
+  const uint16_t* ihy = hy + (size_t)img * W * H; const uint16_t* ihuv = huv + (size_t)img * W * (H / 2);
+  const uint8_t* iy = y + (size_t)img * W * H; const uint8_t* iu = u + (size_t)img * (W / 2) * H; const uint8_t* iv = iu + (size_t)(W / 2) * (H / 2);
+  const uint32_t ppr = MW / 2, total = ppr * MH; uint32_t acc = 0;
+  for (uint32_t t = 0; t < tiles; ++t) {
+    const uint32_t idx = (blk * tiles + t) * BLOCK + threadIdx.x;
+    if (idx >= total) break;
+    const uint32_t my = idx / ppr, pr = idx - my * ppr;
+    for (int r = 0; r < 4; ++r) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(ihy + (4u * my + r) * W + 8u * pr);
+      const u32x4 q = NT ? __builtin_nontemporal_load(p) : *p; acc ^= q.x ^ q.y ^ q.z ^ q.w;
+      const uint2* p2 = reinterpret_cast<const uint2*>(iy + (4u * my + r) * W + 8u * pr);
+      const uint2 q2 = *p2; acc ^= q2.x ^ q2.y;
+    }
+    for (int r = 0; r < 2; ++r) {
+      const u32x4* p = reinterpret_cast<const u32x4*>(ihuv + (2u * my + r) * W + 8u * pr);
+      const u32x4 q = NT ? __builtin_nontemporal_load(p) : *p; acc ^= q.x ^ q.y ^ q.z ^ q.w;
+      acc ^= *reinterpret_cast<const uint32_t*>(iu + (2u * my + r) * (W / 2) + 4u * pr) ^ *reinterpret_cast<const uint32_t*>(iv + (2u * my + r) * (W / 2) + 4u * pr);
+    }
+  }
+  if (acc == 0x12345678u) sink[threadIdx.x] = acc;
+}
+
 template <class F> float timed(F f) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 3; ++i) f();
@@ -112,6 +137,21 @@ int main() {
     c[5] = timed([&] { hipLaunchKernelGGL(k_cells_mode<5>, grid, dim3(512), 0, 0, out, 32u); });
     c[6] = timed([&] { hipLaunchKernelGGL(k_cells_mode<6>, grid, dim3(512), 0, 0, out, 32u); });
     for (int m = 0; m < 7; ++m) printf("cells cpt 32 %-11s %.3f ms %.0f GB/s\n", names[m], c[m], gb / c[m] * 1e3);
+  }
+  {
+    uint16_t *hy, *huv; CK(hipMalloc(&hy, (size_t)N * W * H * 2)); CK(hipMalloc(&huv, (size_t)N * W * H)); CK(hipMemset(hy, 1, (size_t)N * W * H * 2)); CK(hipMemset(huv, 1, (size_t)N * W * H));
+    const double ggb = (double)N * W * H * 4.5 / 1e9;
+    for (int im = 0; im < 2; ++im)
+      for (uint32_t tiles : {1u, 4u, 16u}) {
+        const uint32_t tot = (MW / 2) * MH;
+        const uint32_t b256 = (tot + 256 * tiles - 1) / (256 * tiles), b512 = (tot + 512 * tiles - 1) / (512 * tiles);
+        t = timed([&] { hipLaunchKernelGGL((k_gen_read<256, true>), im ? dim3(b256, N) : dim3(N, b256), dim3(256), 0, 0, hy, huv, y, u, out, tiles, im); });
+        printf("generate reads nt, block 256, tiles %2u, %s  %.3f ms %.0f GB/s\n", tiles, im ? "image-major" : "interleaved", t, ggb / t * 1e3);
+        t = timed([&] { hipLaunchKernelGGL((k_gen_read<512, true>), im ? dim3(b512, N) : dim3(N, b512), dim3(512), 0, 0, hy, huv, y, u, out, tiles, im); });
+        printf("generate reads nt, block 512, tiles %2u, %s  %.3f ms %.0f GB/s\n", tiles, im ? "image-major" : "interleaved", t, ggb / t * 1e3);
+        t = timed([&] { hipLaunchKernelGGL((k_gen_read<256, false>), im ? dim3(b256, N) : dim3(N, b256), dim3(256), 0, 0, hy, huv, y, u, out, tiles, im); });
+        printf("generate reads plain, block 256, tiles %2u, %s  %.3f ms %.0f GB/s\n", tiles, im ? "image-major" : "interleaved", t, ggb / t * 1e3);
+      }
   }
   for (uint32_t cpt : {32u})
     for (int mode = 0; mode < 2; ++mode) {

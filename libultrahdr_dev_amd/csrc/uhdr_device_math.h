@@ -359,6 +359,76 @@ __device__ __forceinline__ float pq_inv_oetf_guarded(float e) {
   return v[0];
 }
 
+// ---- the forward OETFs and applyGain's factor for apply's EXACT mode: the same lean f64 + rounding test -------------------
+__device__ __attribute__((noinline)) float hlg_oetf_slow(float e) { return hlg_oetf_exact(e); }
+__device__ __attribute__((noinline)) float pq_oetf_slow(float e) { return pq_oetf_exact(e); }
+__device__ __attribute__((noinline)) float exp2_to_float_slow(float x) { return (float)exp2((double)x); }
+
+// hlgOetf (gainmapmath.cpp:259-265).  e <= 1/12: (float)sqrt((double)(3.0f * e)) from the f32 special-function square root
+// (2^-23) and one Newton step in double -- t - y0^2 is exact there -- leaving ~2^-45, then the rounding test; otherwise
+// a * ln(12 e - b) + c in double from the lean log2.
+template <int N>
+__device__ __forceinline__ void hlg_oetf_guarded_n(float (&e)[N]) {
+  double t[N];
+  float lo[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float t3 = 3.0f * e[j];
+    const float y0 = __builtin_amdgcn_sqrtf(t3);
+    const double d = __builtin_fma(-(double)y0, (double)y0, (double)t3);
+    const double y1 = __builtin_fma(d, (double)(0.5f * __builtin_amdgcn_rcpf(y0)), (double)y0);
+    lo[j] = (float)y1;
+    if (t3 == 0.0f) lo[j] = 0.0f;
+    else if (e[j] <= 1.0f / 12.0f && (t3 < 0x1p-100f || !ziv_safe<true>(y1))) lo[j] = hlg_oetf_slow(e[j]);
+    const float x = 12.0f * e[j] - UHDR_HLG_B;
+    t[j] = (double)((e[j] <= 1.0f / 12.0f) ? 1.0f : x);   // (x >= 0.715 on the branch that uses it)
+  }
+  fast_log2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double yy = __builtin_fma((double)UHDR_HLG_A * 0x1.62e42fefa39efp-1, t[j], (double)UHDR_HLG_C);
+    float hi = (float)yy;
+    // a * ln2 is one more rounding than the reference's a * log(x) (2^-53): inside the test's margin
+    if (e[j] > 1.0f / 12.0f && !ziv_safe<true>(yy)) hi = hlg_oetf_slow(e[j]);
+    e[j] = (e[j] <= 1.0f / 12.0f) ? lo[j] : hi;
+  }
+}
+// pqOetf (gainmapmath.cpp:309-312): two pow() as exp2(m log2 x)
+template <int N>
+__device__ __forceinline__ void pq_oetf_guarded_n(float (&e)[N]) {
+  double t[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = (double)((e[j] <= 0.0f) ? 1.0f : e[j]);
+  fast_log2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] *= (double)UHDR_PQ_M1;
+  fast_exp2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double num = __builtin_fma((double)UHDR_PQ_C2, t[j], (double)UHDR_PQ_C1), den = __builtin_fma((double)UHDR_PQ_C3, t[j], 1.0);
+    double r = (double)__builtin_amdgcn_rcpf((float)den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    t[j] = num * r;
+  }
+  fast_log2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] *= (double)UHDR_PQ_M2;
+  fast_exp2_n<N>(t, t);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float o = (float)t[j];
+    if (e[j] > 0.0f && !ziv_safe(t[j])) o = pq_oetf_slow(e[j]);
+    e[j] = (e[j] <= 0.0f) ? 0.0f : o;
+  }
+}
+// (float)exp2((double)x), applyGain's factor (gainmapmath.cpp:553)
+__device__ __forceinline__ float exp2_to_float_guarded(float x) {
+  if (!(__builtin_fabsf(x) < 120.0f)) return exp2_to_float_slow(x);   // NaN, overflow and the subnormal results
+  const double y = fast_exp2((double)x);
+  return ziv_safe<true>(y) ? (float)y : exp2_to_float_slow(x);
+}
+
 // ---- encodeGain (gainmapmath.cpp:529-541) ------------------------------------------------------
 __device__ __forceinline__ float raw_gain(float y_sdr, float y_hdr) {
   float gain = 1.0f;

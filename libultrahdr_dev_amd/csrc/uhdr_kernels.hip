@@ -877,8 +877,12 @@ __device__ __forceinline__ F3 recover_hdr(const AppConsts& c, float yf, float cr
   const float log_boost = (float)(c.log2_min_d * (double)(1.0f - gain) + c.log2_max_d * (double)gain);
   F3 o;
   if (EXACT) {
-    r = srgb_inv_oetf_exact(r); g = srgb_inv_oetf_exact(g); b = srgb_inv_oetf_exact(b);
-    const float factor = (float)exp2((double)(log_boost * c.display_boost / c.max_boost));
+    // the reference's double-precision pow / exp2, as lean f64 + a rounding test (uhdr_device_math.h): the float each call
+    // returns is the one the libm call rounds to (tests/test_gpu_transfer_exhaustive.py), three channels in lock step
+    float ch[3] = {r, g, b};
+    srgb_inv_oetf_guarded_n<3>(ch);
+    r = ch[0]; g = ch[1]; b = ch[2];
+    const float factor = exp2_to_float_guarded(log_boost * c.display_boost / c.max_boost);
     o.x = (r * factor) / c.display_boost;  // ultrahdr.cpp:451
     o.y = (g * factor) / c.display_boost;
     o.z = (b * factor) / c.display_boost;
@@ -895,10 +899,10 @@ __device__ __forceinline__ F3 recover_hdr(const AppConsts& c, float yf, float cr
 template <int FMT, bool EXACT>
 __device__ __forceinline__ F3 hdr_oetf(F3 e) {
   if (FMT == 3) {
-    if (EXACT) { e.x = hlg_oetf_exact(e.x); e.y = hlg_oetf_exact(e.y); e.z = hlg_oetf_exact(e.z); }
+    if (EXACT) { float ch[3] = {e.x, e.y, e.z}; hlg_oetf_guarded_n<3>(ch); e.x = ch[0]; e.y = ch[1]; e.z = ch[2]; }
     else { e.x = hlg_oetf_fast(e.x); e.y = hlg_oetf_fast(e.y); e.z = hlg_oetf_fast(e.z); }
   } else if (FMT == 2) {
-    if (EXACT) { e.x = pq_oetf_exact(e.x); e.y = pq_oetf_exact(e.y); e.z = pq_oetf_exact(e.z); }
+    if (EXACT) { float ch[3] = {e.x, e.y, e.z}; pq_oetf_guarded_n<3>(ch); e.x = ch[0]; e.y = ch[1]; e.z = ch[2]; }
     else { e.x = pq_oetf_fast(e.x); e.y = pq_oetf_fast(e.y); e.z = pq_oetf_fast(e.z); }
   }
   return e;
@@ -1864,6 +1868,10 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 2: y = pq_inv_oetf_guarded(x); break;
     case 3: y = (float)encode_gain_guarded(x, ec.min_boost, ec.max_boost, ec.log2_min, ec.log2_max, ec.enc_scale,
                                            ec.enc_byte_min, ec.enc_byte_max); break;
+    case 4: { float v[1] = {x}; hlg_oetf_guarded_n<1>(v); y = v[0]; break; }
+    case 5: { float v[1] = {x}; pq_oetf_guarded_n<1>(v); y = v[0]; break; }
+    case 6: y = exp2_to_float_guarded(x); break;
+    case 16: y = (float)exp2((double)x); break;
     case 10: y = srgb_inv_oetf_exact(x); break;
     case 11: y = hlg_inv_oetf_exact(x); break;
     case 12: y = pq_inv_oetf_exact(x); break;

@@ -43,6 +43,36 @@ def test_guarded_equals_exact_for_every_float_in_0_1(hip, fn, name):
     assert total == 0x3F800001 and bad == 0, "%s: %d of %d inputs differ from the exact path" % (name, bad, total)
 
 
+@pytest.mark.parametrize("fn,name", [(4, "hlgOetf"), (5, "pqOetf")])
+def test_guarded_forward_oetf_equals_exact_for_every_float_in_0_64(hip, fn, name):
+    """apply's EXACT mode (k_apply_px): the lean forward OETFs return the float of the exact (ocml double) path for every float
+    in [0, 64] -- [0, 1] is what a call produces, values above 1 appear when max_display_boost < maxContentBoost"""
+    lib = hip.load()
+    total = bad = 0
+    for x in _all_floats(0, 0x42800000):
+        a = _eval(lib, hip, fn, x).view(torch.int32)
+        b = _eval(lib, hip, fn + 10, x).view(torch.int32)
+        bad += int((a != b).sum().item())
+        total += x.numel()
+    assert total == 0x42800001 and bad == 0, "%s: %d of %d inputs differ from the exact path" % (name, bad, total)
+
+
+def test_guarded_gain_factor_equals_exact_for_every_float_in_minus32_32(hip):
+    """(float)exp2((double)x), applyGain's factor (gainmapmath.cpp:553), for every float with |x| <= 32 (log2 of a content boost
+    stays far inside), plus the values outside that take the exact path by construction"""
+    lib = hip.load()
+    bad = total = 0
+    for lo, hi in ((0, 0x42000000), (0x80000000 - (1 << 32), 0xC2000000 - (1 << 32))):
+        for x in _all_floats(lo, hi):
+            a = _eval(lib, hip, 6, x).view(torch.int32)
+            b = _eval(lib, hip, 16, x).view(torch.int32)
+            bad += int((a != b).sum().item())
+            total += x.numel()
+    z = torch.tensor([100.0, -100.0, 127.9, -126.5, -140.0, 200.0, float("inf"), float("-inf")], dtype=torch.float32, device="cuda")
+    assert torch.equal(_eval(lib, hip, 6, z).view(torch.int32), _eval(lib, hip, 16, z).view(torch.int32))
+    assert bad == 0, (bad, total)
+
+
 @pytest.mark.parametrize("boosts", [(1.0, 1000.0 / 203.0), (1.0, 10000.0 / 203.0), (0.25, 4.0)])
 def test_guarded_encode_gain_equals_exact(hip, boosts):
     lib = hip.load()

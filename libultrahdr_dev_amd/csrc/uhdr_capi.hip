@@ -108,18 +108,37 @@ int current_state(DeviceState** st) {
   return UHDR_HIP_NO_ERROR;
 }
 
-int idw_for_scale(DeviceState* st, int scale, const float** dptr) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto it = st->idw.find(scale);
-  if (it == st->idw.end()) {
-    std::vector<float> t;
-    build_idw_tables(scale, t);
-    float* d = nullptr;
-    HIP_TRY(hipMalloc(&d, t.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
-    it = st->idw.emplace(scale, d).first;
+// ShepardsIDW(scale) on the device.  The scale comes from the caller's images (a file, on the decode path): the table holds
+// 16 scale^2 floats -- 4.3 GB for an 8192-wide image over a 1-pixel map, which the reference allocates per call and frees.  Tables up
+// to kIdwCacheMaxScale (1 MiB) are built once per device and kept; larger ones live for the call (*transient: the caller frees it
+// once its launches have finished).  The table is built outside the lock; running out of memory is a status, not an exception.
+constexpr int kIdwCacheMaxScale = 128;
+int idw_for_scale(DeviceState* st, int scale, const float** dptr, float** transient) {
+  *transient = nullptr;
+  if (scale <= kIdwCacheMaxScale) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = st->idw.find(scale);
+    if (it != st->idw.end()) { *dptr = it->second; return UHDR_HIP_NO_ERROR; }
   }
-  *dptr = it->second;
+  std::vector<float> t;
+  try {
+    build_idw_tables(scale, t);
+  } catch (const std::bad_alloc&) {
+    snprintf(t_err, sizeof(t_err), "no memory for the weight table of map scale %d", scale);
+    return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  }
+  float* d = nullptr;
+  if (hipMalloc(&d, t.size() * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    snprintf(t_err, sizeof(t_err), "no device memory for the weight table of map scale %d", scale);
+    return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  }
+  if (hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return UHDR_HIP_UNKNOWN_ERROR; }
+  if (scale > kIdwCacheMaxScale) { *transient = d; *dptr = d; return UHDR_HIP_NO_ERROR; }
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto ins = st->idw.emplace(scale, d);
+  if (!ins.second) (void)hipFree(d);   // another thread was faster
+  *dptr = ins.first->second;
   return UHDR_HIP_NO_ERROR;
 }
 
@@ -845,14 +864,12 @@ int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bo
   if (!sdr || want_metadata) {
     const uint8_t* xmp = nullptr;
     size_t xmp_len = 0;
-    static const char kXmpNs[] = "http://ns.adobe.com/xap/1.0/";
-    if (!jpegr::find_app_segment(f->jpg[1], f->len[1], 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) || !jpegr::metadata_from_xmp(xmp, xmp_len, &f->md))
+    if (!jpegr::first_xmp(f->jpg[1], f->len[1], &xmp, &xmp_len) || !jpegr::metadata_from_xmp(xmp, xmp_len, &f->md))
       return UHDR_HIP_ERROR_METADATA_ERROR;
   }
   const uint8_t* icc = nullptr;
   size_t icc_len = 0;
-  static const char kIccSig[] = "ICC_PROFILE";
-  f->gamut = jpegr::find_app_segment(f->jpg[0], f->len[0], 0xE2, kIccSig, sizeof(kIccSig), &icc, &icc_len) ? jpegr::gamut_from_icc(icc, icc_len)
+  f->gamut = jpegr::first_icc(f->jpg[0], f->len[0], &icc, &icc_len) ? jpegr::gamut_from_icc(icc, icc_len)
                                                                                                              : UHDR_HIP_CG_UNSPECIFIED;
   return UHDR_HIP_NO_ERROR;
 }
@@ -1216,6 +1233,9 @@ PendingJpeg& pending_gainmap() { static thread_local PendingJpeg p; return p; }
 int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, HostBytes& jpeg, size_t* n) {
   uhdr_hip_image_t g = map;
   g.chroma_data = nullptr; g.chroma_stride = 0; g.pixelFormat = UHDR_HIP_PIX_FMT_MONOCHROME;
+  // an earlier call that left on an error path may still have kernels writing into this (page-locked, thread-local) buffer on
+  // the side stream: they must have finished before a growing resize frees it
+  if (c.st->aux != nullptr) HIP_TRY(hipStreamSynchronize(c.st->aux));
   jpeg.resize(map.width * map.height + 65536);
   if (!c.host()) {   // enqueued; *n == kPendingSize until resolve_gainmap_jpeg() (or finish_from_planes) has synchronised
     // On a stream of its own behind the kernel that wrote the map: nothing the caller's stream does next (the SDR image's BT.601
@@ -1224,7 +1244,6 @@ int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, HostBytes& 
       HIP_TRY(hipStreamCreateWithFlags(&c.st->aux, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&c.st->map_ready, hipEventDisableTiming));
     }
-    HIP_TRY(hipStreamSynchronize(c.st->aux));   // (idle unless an earlier call left on an error path)
     HIP_TRY(hipEventRecord(c.st->map_ready, c.s()));
     HIP_TRY(hipStreamWaitEvent(c.st->aux, c.st->map_ready, 0));
     EncodeCtx side = c;
@@ -1424,9 +1443,8 @@ int uhdr_hip_jpegr_encode_api4(const void* sdr_jpeg, size_t sdr_jpeg_size, int s
   if (!jpegr::has_valid_header(pj, sdr_jpeg_size)) return UHDR_HIP_ERROR_DECODE_ERROR;                            // :520-524
   const uint8_t* have = nullptr;
   size_t have_len = 0;
-  static const char kIccSig[] = "ICC_PROFILE";
   std::vector<uint8_t> icc;
-  if (!jpegr::find_app_segment(pj, sdr_jpeg_size, 0xE2, kIccSig, sizeof(kIccSig), &have, &have_len)) {          // :527-541
+  if (!jpegr::first_icc(pj, sdr_jpeg_size, &have, &have_len)) {          // :527-541
     if (sdr_jpeg_gamut <= UHDR_HIP_CG_UNSPECIFIED || sdr_jpeg_gamut > UHDR_HIP_CG_BT2100) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
     jpegr::icc_profile_srgb_transfer(sdr_jpeg_gamut, icc);
   }
@@ -1489,8 +1507,7 @@ int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_in, const void* sdr_
     // :467-488 the gamut: the ICC profile's when there is one (and it must agree with a configured gamut), else the configured one
     const uint8_t* icc = nullptr;
     size_t icc_len = 0;
-    static const char kIccSig[] = "ICC_PROFILE";
-    if (jpegr::find_app_segment(pj, sdr_jpeg_size, 0xE2, kIccSig, sizeof(kIccSig), &icc, &icc_len)) {
+    if (jpegr::first_icc(pj, sdr_jpeg_size, &icc, &icc_len)) {
       const int cg = jpegr::gamut_from_icc(icc, icc_len);
       if (cg == UHDR_HIP_CG_UNSPECIFIED || (sdr_jpeg_gamut != UHDR_HIP_CG_UNSPECIFIED && sdr_jpeg_gamut != cg)) return UHDR_HIP_ERROR_INVALID_COLORGAMUT;
       ydesc.colorGamut = cg;
@@ -1569,8 +1586,7 @@ int uhdr_hip_jpegr_metadata(const void* jpegr, size_t jpegr_size, uhdr_hip_metad
   if (found == 1) return UHDR_HIP_ERROR_GAIN_MAP_IMAGE_NOT_FOUND;
   const uint8_t* xmp = nullptr;
   size_t xmp_len = 0;
-  static const char kXmpNs[] = "http://ns.adobe.com/xap/1.0/";
-  if (!jpegr::find_app_segment(file + img[1].begin, img[1].len, 0xE1, kXmpNs, sizeof(kXmpNs), &xmp, &xmp_len) ||
+  if (!jpegr::first_xmp(file + img[1].begin, img[1].len, &xmp, &xmp_len) ||
       !jpegr::metadata_from_xmp(xmp, xmp_len, metadata))
     return UHDR_HIP_ERROR_METADATA_ERROR;
   return UHDR_HIP_NO_ERROR;
@@ -1732,7 +1748,12 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
     const uhdr_hip_image_t& m0 = maps[i];
     const int scale = (int)(y0.width / m0.width);
     const float* idw = nullptr;
-    if ((rc = idw_for_scale(st, scale, &idw)) != UHDR_HIP_NO_ERROR) return rc;
+    float* idw_transient = nullptr;
+    if ((rc = idw_for_scale(st, scale, &idw, &idw_transient)) != UHDR_HIP_NO_ERROR) return rc;
+    struct FreeAfter {   // a table too large to keep: freed when this chunk's launches have finished
+      float* p; hipStream_t s;
+      ~FreeAfter() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } }
+    } free_after{idw_transient, s};
     AppConsts c = apply_consts(y0, m0, *metadata, max_display_boost, idw);
     c.lut = apply_mode == UHDR_HIP_APPLY_LUT ? st->lut : nullptr;
     c.tab = st->lut;

@@ -388,6 +388,19 @@ void first_packets(const uint8_t* d, size_t n, size_t* xmp_off, size_t* xmp_len,
   }
 }
 
+bool first_xmp(const uint8_t* jpg, size_t n, const uint8_t** payload, size_t* payload_len) {
+  size_t a, b, c, d, e, f;
+  first_packets(jpg, n, &a, &b, &c, &d, &e, &f);
+  *payload = jpg + a; *payload_len = b;
+  return b != 0;
+}
+bool first_icc(const uint8_t* jpg, size_t n, const uint8_t** payload, size_t* payload_len) {
+  size_t a, b, c, d, e, f;
+  first_packets(jpg, n, &a, &b, &c, &d, &e, &f);
+  *payload = jpg + e; *payload_len = f;
+  return f != 0;
+}
+
 // image_width / image_height as jpeg_read_header leaves them: the first SOFn segment
 bool dimensions(const uint8_t* d, size_t n, int* w, int* h) {
   size_t p = 2;

@@ -24,6 +24,9 @@ bool icc_profile_srgb_transfer(int gamut, std::vector<uint8_t>& out);
 // exif / icc: payloads of the APP1 / APP2 segments to add (nullptr = none)
 int append_gainmap(const uint8_t* primary, size_t n1, const uint8_t* gainmap, size_t n2, const uint8_t* exif, size_t exif_len,
                    const uint8_t* icc, size_t icc_len, const uhdr_hip_metadata& md, std::vector<uint8_t>& out);
+// the XMP / ICC packet the reference's decoder would hand on: the first one of first_packets' scan (APP1 or APP2, fill bytes allowed)
+bool first_xmp(const uint8_t* jpg, size_t n, const uint8_t** payload, size_t* payload_len);
+bool first_icc(const uint8_t* jpg, size_t n, const uint8_t** payload, size_t* payload_len);
 void first_packets(const uint8_t* jpg, size_t n, size_t* xmp_off, size_t* xmp_len, size_t* exif_off, size_t* exif_len, size_t* icc_off,
                    size_t* icc_len);
 // ... written straight into dst[0, cap); *size receives the file size (ERROR_INSUFFICIENT_RESOURCE when cap is smaller)

@@ -227,6 +227,30 @@ def test_write_xmp_then_read_and_icc_write_then_read():
     assert lib.uhdr_hip_icc_profile(api.TF_SRGB, 7, C.c_void_p(icc.ctypes.data), icc.size, C.byref(n)) == api.ERROR_INVALID_COLORGAMUT
 
 
+def test_metadata_packet_in_app2_and_behind_fill_bytes():
+    """the reference's decoder takes the first XMP packet of either APP1 or APP2 from libjpeg's marker list
+    (jpegdecoderhelper.cpp:221-249), and libjpeg skips 0xFF fill bytes in front of a marker: a file whose gain-map XMP sits in
+    an APP2 segment behind a fill byte reads like the original (the same rule uhdr_hip_jpegr_info reports offsets by)"""
+    from libultrahdr_dev_amd import api
+    from oracle import jpegr_oracle as J
+    lib = api.load()
+    _, primary, gainmap = _sample_streams()
+    want = api.Metadata(b"1.0", 2.5, 1.0, 1.0, 0.0, 0.0, 1.0, 2.5)
+    rc, blob = _append(lib, api, primary, gainmap, want)
+    assert rc == 0
+    second = J.find_images(blob)[1][0]
+    at = blob.index(b"\xff\xe1", second)
+    assert blob[at + 4:at + 4 + len(J.XMP_NS)] == J.XMP_NS
+    moved = blob[:at] + b"\xff\xff\xe2" + blob[at + 2:]            # fill byte, then the same segment as APP2
+    seen = []
+    for data in (blob, moved):
+        b, got = np.frombuffer(data, np.uint8), api.Metadata()
+        assert lib.uhdr_hip_jpegr_metadata(C.c_void_p(b.ctypes.data), b.size, C.byref(got)) == 0
+        assert abs(got.maxContentBoost - 2.5) < 1e-5 and got.minContentBoost == 1.0 and got.version == b"1.0"   # (the packet stores log2 with %g)
+        seen.append((got.maxContentBoost, got.minContentBoost, got.hdrCapacityMax))
+    assert seen[0] == seen[1]
+
+
 def test_append_gainmap_exif_and_icc_handling(orc):
     """appendGainMap's EXIF / ICC arguments and the EXIF segment it lifts out of the primary JPEG (jpegr.cpp:1003-1071); host code,
     product == restatement.  What the restatement rests on: the segment order documented at jpegr.cpp:917-949 and the sample pin above."""

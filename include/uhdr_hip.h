@@ -226,6 +226,13 @@ int uhdr_hip_add_effects(const uhdr_hip_image_t* in_img, const uhdr_hip_effect_t
 int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void* icc, size_t icc_size, void* out,
                          size_t out_capacity, size_t* out_size, int mem_space, void* stream);
 
+/* Diagnostics, host only (no GPU): the quantised coefficients of a progressive (SOF2) file after all of its scans -- what the
+ * host-side entropy decoder hands to the device: blocks in MCU order (4:2:0: Y00 Y01 Y10 Y11 Cb Cr), zigzag order inside a block.
+ * *blocks receives the block count (also when coef is NULL / too small: INSUFFICIENT_RESOURCE).  Baseline files, whose entropy
+ * decoding runs on the device: UNSUPPORTED_FEATURE. */
+int uhdr_hip_jpeg_progressive_coefficients(const void* jpeg, size_t jpeg_size, int16_t* coef, size_t capacity_blocks, size_t* blocks,
+                                           int* width, int* height, int* gray);
+
 /* JpegDecoderHelper::decompressImage(image, length, DECODE_TO_YCBCR) (lib/src/jpegdecoderhelper.cpp:188-516;
  * lib/include/ultrahdr/jpegdecoderhelper.h:54-56): a baseline 4:2:0 YCbCr or grayscale JPEG (HOST memory) -> the bytes
  * libjpeg returns with raw_data_out and JDCT_ISLOW, laid out as the reference's result buffer: width x height luma, then
@@ -233,8 +240,9 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
  * the memory space given by mem_space.  *desc is filled (data = out, chroma_data, strides, pixelFormat YUV420 or
  * MONOCHROME) when the header is readable, also on ERROR_INSUFFICIENT_RESOURCE (out_capacity too small: width*height*3/2
  * resp. width*height bytes are needed).  Huffman decoding (self-synchronising parallel decoder), dequantisation and IDCT
- * run on the device; restart intervals (DRI / RSTn) are read.  ERROR_UNSUPPORTED_FEATURE: progressive / arithmetic-coded files (libjpeg reads them, this
- * decoder does not); UNKNOWN_ERROR: malformed file, or a sampling other than 4:2:0 / single plane, where the reference's call
+ * run on the device; restart intervals (DRI / RSTn) are read.  Progressive files (SOF2) are read too: their scans are entropy-decoded
+ * on the host, dequantisation and IDCT run on the device (complete files; the planes are libjpeg's).  ERROR_UNSUPPORTED_FEATURE:
+ * arithmetic-coded / lossless files (libjpeg reads some of them, this decoder does not); UNKNOWN_ERROR: malformed file, or a sampling other than 4:2:0 / single plane, where the reference's call
  * returns false as well (:283-289).  The call waits for the stream. */
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
                          int mem_space, void* stream);
@@ -254,7 +262,7 @@ int uhdr_hip_jpeg_decode_rgba(const void* jpeg, size_t jpeg_size, void* out, siz
  * and colorGamut; *metadata (optional) the parsed metadata.  Status values are the reference's: BAD_PTR,
  * INVALID_DISPLAY_BOOST (max_display_boost < 1), INVALID_OUTPUT_FORMAT, NO_IMAGES_FOUND, GAIN_MAP_IMAGE_NOT_FOUND, DECODE_ERROR,
  * METADATA_ERROR, then applyGainMap's own; plus ERROR_INSUFFICIENT_RESOURCE when dest_capacity is too small (*dest is filled)
- * and ERROR_UNSUPPORTED_FEATURE for progressive JPEGs.  UHDR_HIP_OUTPUT_SDR (:768-786) returns the primary image alone as
+ * and ERROR_UNSUPPORTED_FEATURE for arithmetic-coded JPEGs (progressive ones are read).  UHDR_HIP_OUTPUT_SDR (:768-786) returns the primary image alone as
  * RGBA8888 (4 bytes per pixel, alpha 0xFF) with the arithmetic libjpeg-turbo applies for DECODE_TO_RGBA (fancy 4:2:0 upsampling and
  * its fixed-point YCbCr -> RGB tables; jpegdecoderhelper.cpp:251-281); the gain map is then not decompressed and its XMP packet is
  * only read when `metadata` is not NULL, as in the reference. */

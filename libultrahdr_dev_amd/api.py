@@ -79,6 +79,8 @@ SIGNATURES = {
     "uhdr_hip_generate_gainmap_ex": (C.c_int, [_IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_generate_gainmap_batch_ex": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uhdr_hip_add_effects": (C.c_int, [_IP, C.c_void_p, C.c_int, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_jpeg_progressive_coefficients": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "uhdr_hip_jpeg_encode": (C.c_int, [_IP, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, C.c_void_p]),
     "uhdr_hip_jpeg_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_jpegr_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_void_p, C.c_size_t, _IP, _MP, C.c_int, C.c_int, C.c_void_p]),

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libuhdr_hip.so")
 SHIM_LIB = os.path.join(HERE, "libultrahdr_shim.so")
 
-SOURCES = ["uhdr_kernels.hip", "uhdr_capi.hip", "uhdr_jpeg.hip", "uhdr_jpeg_dec.hip", "uhdr_jpeg_hdr.cpp", "uhdr_jpegr.cpp"]
+SOURCES = ["uhdr_kernels.hip", "uhdr_capi.hip", "uhdr_jpeg.hip", "uhdr_jpeg_dec.hip", "uhdr_jpeg_hdr.cpp", "uhdr_jpeg_prog.cpp", "uhdr_jpegr.cpp"]
 DEPS = SOURCES + ["uhdr_kernels.h", "uhdr_device_math.h", "uhdr_jpeg.h", "uhdr_jpegr.h", os.path.join(ROOT, "include", "uhdr_hip.h")]
 SHIM_SOURCES = ["ultrahdr_shim.cpp"]
 SHIM_DEPS = SHIM_SOURCES + [os.path.join(ROOT, "include", "uhdr_hip.h"),

@@ -728,6 +728,30 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
   return UHDR_HIP_NO_ERROR;
 }
 
+// Diagnostics (host only, no GPU): the quantised coefficients of a PROGRESSIVE file after all of its scans, as the host-side
+// entropy decoder hands them to the device (csrc/uhdr_jpeg_prog.cpp) -- blocks in MCU order, zigzag order inside a block, DC as the
+// value.  tests/test_jpeg_progressive.py compares them with libjpeg's jpeg_read_coefficients.  Returns the number of blocks through
+// *blocks; baseline files: UNSUPPORTED_FEATURE (their entropy decoding runs on the device).
+int uhdr_hip_jpeg_progressive_coefficients(const void* jpeg, size_t jpeg_size, int16_t* coef, size_t capacity_blocks, size_t* blocks, int* width,
+                                           int* height, int* gray) {
+  if (jpeg == nullptr || blocks == nullptr || width == nullptr || height == nullptr || gray == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  jpeg::DecInfo info;
+  const int prc = jpeg::parse_header(static_cast<const uint8_t*>(jpeg), jpeg_size, &info);
+  if (prc == -2 || (prc == 0 && !info.progressive)) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  if (prc != 0) return UHDR_HIP_UNKNOWN_ERROR;
+  *width = info.w; *height = info.h; *gray = info.gray;
+  *blocks = info.coef.size() / 64u;
+  if (coef == nullptr || capacity_blocks < *blocks) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  memcpy(coef, info.coef.data(), info.coef.size() * sizeof(int16_t));
+  int prev[3] = {0, 0, 0};   // differences back to values
+  for (size_t b = 0; b < *blocks; ++b) {
+    const int c = info.gray ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
+    prev[c] += coef[b * 64u];
+    coef[b * 64u] = (int16_t)prev[c];
+  }
+  return UHDR_HIP_NO_ERROR;
+}
+
 // JpegDecoderHelper::decompressImage(..., DECODE_TO_YCBCR) (jpegdecoderhelper.cpp:188-327) on the device
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
                          int mem_space, void* stream) {

@@ -73,6 +73,11 @@ struct DecInfo {
   uint32_t restart_interval = 0;
   std::vector<uint32_t> interval_start;
   uint32_t raw_bytes = 0;
+  // progressive files (SOF2): every scan is entropy-decoded on the host (uhdr_jpeg_prog.cpp); coef = nblk x 64 coefficients, zigzag
+  // order, blocks in the device decoder's order, DC as the difference to the component's previous block; scan_bytes = 0 and
+  // scan_offset = the position of EOI.  The device runs its DC prefix sum and the IDCT.
+  bool progressive = false;
+  std::vector<int16_t> coef;
 };
 struct DecLayout {
   size_t src, raw, lut, adv, st_a, st_b, dirty_a, dirty_b, coef;
@@ -98,6 +103,8 @@ struct DecJob {
 };
 // 0 ok, -1 malformed, -2 outside what this decoder (or the reference: sampling) supports
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info);
+// the same for a progressive file, all scans decoded (parse_header calls it when it meets SOF2)
+int decode_progressive(const uint8_t* jpg, size_t n, DecInfo* info);
 // the walk over an entropy-coded segment on its own (the container scan uses it): position of the 0xFF of the first marker at or
 // behind `e` that is neither a stuffed zero, a fill byte nor an RSTn; n if there is none
 size_t skip_entropy_coded(const uint8_t* p, size_t e, size_t n);

@@ -32,8 +32,9 @@
 // end of the segment (parse_header) and the unstuffing pass drops them like the stuffed zeros.
 // Every kernel has a second grid dimension over images (blockIdx.y; the per-image jobs sit in device memory): a JPEG/R file is two
 // JPEGs and a server decodes many files at once, and since a decode is latency-bound the images of a call cost little more than one.
-// Progressive or arithmetic-coded files return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE (libjpeg reads them, the reference's encoder
-// never writes them); samplings other than 4:2:0 / grayscale fail as they do in the reference.
+// Progressive files: their scans are entropy-decoded on the host (uhdr_jpeg_prog.cpp) and join the batch at the coefficient blocks
+// (DC prefix sum + IDCT here).  Arithmetic-coded / lossless files return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE; samplings other than
+// 4:2:0 / grayscale fail as they do in the reference.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -882,11 +883,18 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
         j.restart_blocks = in.restart_interval * (in.gray ? 1u : 6u);
       }
     }
-    if (j.nsub == 0u || j.nsub > L.nsub_max) bad[k] = 1;
+    // a progressive file arrives with its coefficients decoded (uhdr_jpeg_prog.cpp): no segment, no subsequences -- every
+    // entropy-decoding kernel's bounds check skips the image; its coefficients are uploaded behind the clearing kernel below and
+    // the DC prefix sum and the IDCT treat it like any other image
+    const bool prog = in.progressive;
+    if (prog) {
+      j.nsub = 0u; j.total_bits = 0u; b.src_bytes = 0u;
+      if (in.coef.size() != (size_t)L.nblk * 64u) bad[k] = 1;
+    } else if (j.nsub == 0u || j.nsub > L.nsub_max) bad[k] = 1;
     if (bad[k]) { j.nsub = 0u; j.nblk = 0u; b.src_bytes = 0u; }   // every kernel's bounds check then skips this image
     b.zero[0] = reinterpret_cast<uint8_t*>(b.flags); b.zero_words[0] = kFlagWords / 4u;
     b.zero[1] = w + L.raw; b.zero_words[1] = bad[k] ? 0u : (uint32_t)((((size_t)in.scan_bytes + 64 + 255) / 256 * 256) / 16);
-    b.zero[2] = reinterpret_cast<uint8_t*>(j.coef); b.zero_words[2] = (uint32_t)(((size_t)j.nblk * 128) / 16);
+    b.zero[2] = reinterpret_cast<uint8_t*>(j.coef); b.zero_words[2] = prog ? 0u : (uint32_t)(((size_t)j.nblk * 128) / 16);
     koff[k + 1] = koff[k] + (bad[k] ? 0u : L.nchunks + 1u);
     soff[k + 1] = soff[k] + j.nsub;
     boff[k + 1] = boff[k] + j.nblk;
@@ -904,6 +912,9 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   const dim3 b256(256);
   const unsigned ny = (unsigned)n;
   hipLaunchKernelGGL(k_jd_prepare_multi, dim3(gu + kLutBlocks + kZeroBlocks, ny), b256, 0, s, (const DecBatchJob*)djobs, gu);
+  for (int k = 0; k < n; ++k)   // progressive images: the host's coefficients (pageable memory: the copy returns when it has been staged)
+    if (info[k]->progressive && !bad[k])
+      JD_TRY(hipMemcpyAsync(jobs[k].j.coef, info[k]->coef.data(), info[k]->coef.size() * sizeof(int16_t), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_jd_unstuff_copy_multi, dim3(gu, ny), b256, 0, s, (const DecBatchJob*)djobs);
   hipLaunchKernelGGL(k_jd_sync_multi<0>, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs, 0, 0u);
   JD_LAP("enqueued through sync<0>");

@@ -169,8 +169,10 @@ int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
       if (nc != 1 && nc != 3) return -2;
       if (len < (size_t)(8 + 3 * nc)) return -1;
       for (int c = 0; c < nc; ++c) { cid[c] = seg[6 + 3 * c]; hs[c] = seg[7 + 3 * c] >> 4; vs[c] = seg[7 + 3 * c] & 15; tq[c] = seg[8 + 3 * c]; }
-    } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-      return -2;   // progressive, lossless, arithmetic: libjpeg reads some of these, this decoder does not
+    } else if (m == 0xC2) {
+      return decode_progressive(jpg, n, info);   // every scan on the host, the device takes over at the coefficients (uhdr_jpeg_prog.cpp)
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      return -2;   // lossless, arithmetic, hierarchical: libjpeg reads some of these, this decoder does not
     } else if (m == 0xDD) {
       if (len < 4) return -1;
       info->restart_interval = rd16(seg);

@@ -161,3 +161,51 @@ long lj_jpeg_decode(const unsigned char* jpg, long n, unsigned char* out, long c
   free(scratch);
   return need;
 }
+
+/* jpeg_read_coefficients: the quantised coefficients libjpeg holds after all scans of a (progressive or baseline) file, laid out
+ * as the device decoder takes them -- blocks in MCU order (4:2:0: Y00 Y01 Y10 Y11 Cb Cr; padding blocks beyond a component's own
+ * extent as zeros), 64 coefficients each in ZIGZAG order, DC as the value (not the difference).  Checker for the product's
+ * host-side progressive entropy decoder (csrc/uhdr_jpeg_prog.cpp).  Returns the number of blocks, -1 on a libjpeg error,
+ * -2 for a sampling other than 4:2:0 / grayscale, -3 when cap_blocks is too small. */
+long lj_jpeg_coefficients(const unsigned char* jpg, long n, short* out, long cap_blocks, int* pw, int* ph, int* pgray) {
+  static const unsigned char nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                        41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                        30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  struct jpeg_decompress_struct c;
+  struct lj_err e;
+  c.err = jpeg_std_error(&e.pub);
+  e.pub.error_exit = lj_error_exit;
+  e.pub.output_message = lj_silent;
+  if (setjmp(e.jb)) { jpeg_destroy_decompress(&c); return -1; }
+  jpeg_create_decompress(&c);
+  jpeg_mem_src(&c, (unsigned char*)jpg, (unsigned long)n);
+  if (jpeg_read_header(&c, TRUE) != JPEG_HEADER_OK) { jpeg_destroy_decompress(&c); return -1; }
+  const int w = (int)c.image_width, h = (int)c.image_height;
+  int gray = c.jpeg_color_space == JCS_GRAYSCALE;
+  if (!gray && (c.jpeg_color_space != JCS_YCbCr || c.comp_info[0].h_samp_factor != 2 || c.comp_info[0].v_samp_factor != 2 ||
+                c.comp_info[1].h_samp_factor != 1 || c.comp_info[1].v_samp_factor != 1 || c.comp_info[2].h_samp_factor != 1 ||
+                c.comp_info[2].v_samp_factor != 1)) { jpeg_destroy_decompress(&c); return -2; }
+  *pw = w; *ph = h; *pgray = gray;
+  const long mx = gray ? (w + 7) / 8 : (w + 15) / 16, my = gray ? (h + 7) / 8 : (h + 15) / 16;
+  const long nblk = mx * my * (gray ? 1 : 6);
+  if (nblk > cap_blocks) { jpeg_destroy_decompress(&c); return -3; }
+  jvirt_barray_ptr* arrays = jpeg_read_coefficients(&c);
+  memset(out, 0, (size_t)nblk * 128);
+  for (int ci = 0; ci < c.num_components; ci++) {
+    jpeg_component_info* comp = &c.comp_info[ci];
+    for (JDIMENSION br = 0; br < comp->height_in_blocks; br++) {
+      JBLOCKARRAY rows = (*c.mem->access_virt_barray)((j_common_ptr)&c, arrays[ci], br, 1, FALSE);
+      for (JDIMENSION bc = 0; bc < comp->width_in_blocks; bc++) {
+        long idx;
+        if (gray) idx = (long)br * mx + bc;
+        else if (ci == 0) idx = (((long)(br >> 1) * mx + (bc >> 1)) * 6 + ((br & 1) * 2 + (bc & 1)));
+        else idx = ((long)br * mx + bc) * 6 + 3 + ci;
+        if (idx >= nblk) continue;
+        for (int k = 0; k < 64; k++) out[idx * 64 + k] = rows[0][bc][nat[k]];
+      }
+    }
+  }
+  jpeg_finish_decompress(&c);
+  jpeg_destroy_decompress(&c);
+  return nblk;
+}

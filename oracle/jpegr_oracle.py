@@ -160,6 +160,8 @@ def decode(data, output_format, max_display_boost, threads=8):
         return -20003, None, 0, 0, -1, None
     pj, gj = data[imgs[0][0]:imgs[0][0] + imgs[0][1]], data[imgs[1][0]:imgs[1][0] + imgs[1][1]]
     st, planes, w, h, gray = O.jpeg_decode("orc", pj)
+    if st == -2 and O.load_libjpeg() is not None:   # a progressive primary image: outside the baseline restatement, libjpeg itself decodes it
+        st, planes, w, h, gray = O.jpeg_decode("lj", pj)
     if st <= 0 or gray:
         return -20002, None, 0, 0, -1, None
     if output_format == O.OUT_SDR:      # jpegr.cpp:768-786: the primary image through libjpeg-turbo's DECODE_TO_RGBA, nothing else

@@ -83,6 +83,10 @@ static void exercise(const std::vector<uint8_t>& in) {
     jpeg::DecInfo info;
     const int prc = jpeg::parse_header(j, img[i].len, &info);
     check_walk(j, img[i].len, prc, info);
+    if (prc == 0 && info.progressive && info.w <= 8192 && info.h <= 8192) {
+      const size_t mx = info.gray ? (info.w + 7) / 8 : (info.w + 15) / 16, my = info.gray ? (info.h + 7) / 8 : (info.h + 15) / 16;
+      if (info.coef.size() != mx * my * (info.gray ? 1u : 6u) * 64u) { fprintf(stderr, "progressive: coefficient count\n"); abort(); }
+    }
     if (prc == 0) {
       if (info.scan_offset + info.scan_bytes > img[i].len || info.w <= 0 || info.h <= 0 || info.w > 65535 || info.h > 65535) { fprintf(stderr, "bad DecInfo\n"); abort(); }
       if (info.raw_bytes > info.scan_bytes) { fprintf(stderr, "raw > scan\n"); abort(); }
@@ -157,7 +161,7 @@ int main(int argc, char** argv) {
   // mix of 0xFF / 0x00 / RSTn / fill / data bytes, then EOI (with and without a DRI segment in front of the scan)
   for (const auto& sd : seeds) {
     jpeg::DecInfo hdr;
-    if (jpeg::parse_header(sd.data(), sd.size(), &hdr) != 0) continue;
+    if (jpeg::parse_header(sd.data(), sd.size(), &hdr) != 0 || hdr.progressive) continue;   // (a progressive file has no single scan to replace)
     for (int it = 0; it < 4000; ++it) {
       std::vector<uint8_t> v(sd.begin(), sd.begin() + (long)hdr.scan_offset);
       const size_t len = rnd() % 700;

@@ -131,8 +131,10 @@ def test_decoder_is_byte_exact_on_the_corpus(hip, orc, tmp_path, device):
         assert rc == 0 and st > 0, (name, rc, st)
         assert (desc.width, desc.height) == (w, h) and (desc.pixelFormat == hip.PIX_FMT_MONOCHROME) == bool(gray), name
         assert np.array_equal(got, want), (name, int((got != want).sum()))
-    if "prog" in extra:      # a file libjpeg reads and the device decoder does not: said out loud
-        assert _gpu_decode(lib, hip, extra["prog"], device)[0] == hip.ERROR_UNSUPPORTED_FEATURE
+    if "prog" in extra:      # a progressive file: its scans are decoded on the host, the planes are libjpeg's (tests/test_jpeg_progressive.py)
+        rc, got, desc = _gpu_decode(lib, hip, extra["prog"], device)
+        st, want, w, h, gray = orc.jpeg_decode("lj", extra["prog"])
+        assert rc == 0 and st > 0 and (desc.width, desc.height) == (w, h) and np.array_equal(got, want)
     if "s444" in extra:                          # 4:4:4: the reference's decompressImage fails as well (jpegdecoderhelper.cpp:283-289)
         assert _gpu_decode(lib, hip, extra["s444"], device)[0] == hip.UNKNOWN_ERROR
 

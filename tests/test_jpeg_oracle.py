@@ -213,7 +213,7 @@ def test_decoder_restatement_equals_libjpeg(orc, tmp_path):
         b = orc.jpeg_decode("lj", data)
         assert a[0] == b[0] > 0 and a[2:] == b[2:], (name, a[0], b[0])
         assert np.array_equal(a[1], b[1]), (name, int((a[1] != b[1]).sum()))
-    if "prog" in extra:   # libjpeg reads progressive files; the restatement (and the device decoder) say "unsupported"
+    if "prog" in extra:   # libjpeg reads progressive files; the baseline restatement says "unsupported" (the product decodes them: test_jpeg_progressive.py)
         assert orc.jpeg_decode("lj", extra["prog"])[0] > 0 and orc.jpeg_decode("orc", extra["prog"])[0] == -2
     if "s444" in extra:   # jpegdecoderhelper.cpp:256-262: only 4:2:0
         assert orc.jpeg_decode("lj", extra["s444"])[0] == -2 and orc.jpeg_decode("orc", extra["s444"])[0] == -2

@@ -497,13 +497,21 @@ def test_host_parsers_survive_mutated_files_under_asan(orc, tmp_path):
         Image.fromarray(y[:w * h].reshape(h, w), mode="L").save(b, "JPEG", quality=80, restart_marker_blocks=2)
         (tmp_path / "rst.jpg").write_bytes(b.getvalue())
         seeds.append(str(tmp_path / "rst.jpg"))
+        # progressive files: every scan is entropy-decoded by host code (uhdr_jpeg_prog.cpp) -- colour with restart intervals, gray
+        rgb = np.stack([y[:w * h].reshape(h, w)] * 3, axis=-1)
+        for name, img, kw in (("prog.jpg", Image.fromarray(rgb, mode="RGB"), dict(subsampling="4:2:0", restart_marker_blocks=1)),
+                              ("prog_gray.jpg", Image.fromarray(y[:w * h].reshape(h, w), mode="L"), dict(optimize=True))):
+            b = io.BytesIO()
+            img.save(b, "JPEG", quality=85, progressive=True, **kw)
+            (tmp_path / name).write_bytes(b.getvalue())
+            seeds.append(str(tmp_path / name))
     except Exception:
         pass
     exe = str(tmp_path / "fuzz")
     csrc = os.path.join(ROOT, "libultrahdr_dev_amd", "csrc")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__",
                            "-I/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "fuzz_host_parsers.cpp"), os.path.join(csrc, "uhdr_jpegr.cpp"),
-                           os.path.join(csrc, "uhdr_jpeg_hdr.cpp"), "-o", exe])
+                           os.path.join(csrc, "uhdr_jpeg_hdr.cpp"), os.path.join(csrc, "uhdr_jpeg_prog.cpp"), "-o", exe])
     r = subprocess.run([exe, SAMPLE] + seeds + ["60000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
 

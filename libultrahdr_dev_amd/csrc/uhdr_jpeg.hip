@@ -17,7 +17,7 @@
 // Byte-exact against libjpeg for every size, stride regime and quality tested (tests/test_gpu_jpeg.py against
 // oracle/jpeg_oracle.c, which tests/test_jpeg_oracle.py pins to the libjpeg builds of the image).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "uhdr_wave_scan.h"
 
 #include <cstring>
 #include <vector>
@@ -321,13 +321,12 @@ __device__ __forceinline__ int comp_of(const Job& j, uint32_t i) { return j.gray
 __device__ __forceinline__ uint32_t fdct_quant_count_block(const Job& j, const uint32_t i);
 __global__ void __launch_bounds__(128) k_jpeg_fdct_quant_count(const Job j) {
   const uint32_t i = blockIdx.x * 128u + threadIdx.x;
-  typedef hipcub::BlockReduce<uint32_t, 128> Reduce;
-  __shared__ typename Reduce::TempStorage s_tmp;
+  __shared__ uint32_t s_part[2];
   uint32_t my_bits = 0;
   if (i < j.nblk) my_bits = fdct_quant_count_block(j, i);
   // bits_blk[g]: the bits of workgroup g's 128 blocks.  k_jpeg_emit needs the bit offset of every block: inside a workgroup a block
   // scan, across workgroups the sum of the totals in front (a 4K frame has 1519), formed by every workgroup of the emit for itself
-  const uint32_t total = Reduce(s_tmp).Sum(my_bits);
+  const uint32_t total = block_sum<128>(my_bits, s_part);
   if (threadIdx.x == 0u) j.bits_blk[blockIdx.x] = total;
 }
 
@@ -413,19 +412,16 @@ struct EmitSink {
 };
 
 __global__ void __launch_bounds__(128) k_jpeg_emit(const Job j) {
-  typedef hipcub::BlockReduce<uint64_t, 128> Reduce;
-  typedef hipcub::BlockScan<uint64_t, 128> Scan;
-  __shared__ union { typename Reduce::TempStorage reduce; typename Scan::TempStorage scan; } s_tmp;
+  __shared__ uint64_t s_part[2];
   __shared__ uint64_t s_base;
   const uint32_t i = blockIdx.x * 128u + threadIdx.x;
   uint64_t before = 0;
   for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 128u) before += j.bits_blk[g];
-  before = Reduce(s_tmp.reduce).Sum(before);
+  before = block_sum<128>(before, s_part);
   if (threadIdx.x == 0u) s_base = before;
   __syncthreads();
   const uint64_t my_bits = i < j.nblk ? j.bits[i] : 0u;
-  uint64_t in_front = 0;
-  Scan(s_tmp.scan).ExclusiveSum(my_bits, in_front);
+  const uint64_t in_front = block_exclusive_sum<128>(my_bits, s_part);
   if (i >= j.nblk) return;
   const uint64_t off = s_base + in_front;
   if (i == j.nblk - 1u) *j.total_bits = off + my_bits;   // read by the stuffing kernels behind this one
@@ -451,8 +447,7 @@ constexpr uint32_t kChunk = 64;
 // front of every chunk: inside a workgroup a block scan of 256 counts, across workgroups the sum of the totals in front, which
 // every workgroup of the copy forms for itself (a 4K frame has ~100 of them) -- no device-wide scan between the two kernels.
 __global__ void __launch_bounds__(256) k_jpeg_stuff_count(const Job j, const uint64_t* total_bits) {
-  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
-  __shared__ typename Reduce::TempStorage s_tmp;
+  __shared__ uint32_t s_part[4];
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint64_t nbytes = (*total_bits + 7u) >> 3;
   const uint64_t b0 = (uint64_t)t * kChunk;
@@ -464,7 +459,7 @@ __global__ void __launch_bounds__(256) k_jpeg_stuff_count(const Job j, const uin
     for (uint32_t k = 0; k < len; ++k) n += p[k] == 0xFFu;
     j.ff_count[t] = n;
   }
-  const uint32_t total = Reduce(s_tmp).Sum(n);
+  const uint32_t total = block_sum<256>(n, s_part);
   if (threadIdx.x == 0u) j.ff_blk[blockIdx.x] = total;
 }
 // One workgroup = 256 chunks = 16 KiB of the packed stream.  Every thread expands its chunk into LDS (0x00 after each
@@ -473,9 +468,7 @@ __global__ void __launch_bounds__(256) k_jpeg_stuff_count(const Job j, const uin
 // stores over 256 cache lines per instruction (28 us per 4K frame measured; this form: see DESIGN.md).
 __global__ void __launch_bounds__(256) k_jpeg_stuff_copy(const Job j, const uint64_t* total_bits, uint8_t* out, uint64_t out_cap,
                                                          uint64_t header_len, uint64_t* out_size) {
-  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
-  typedef hipcub::BlockScan<uint32_t, 256> Scan;
-  __shared__ union { typename Reduce::TempStorage reduce; typename Scan::TempStorage scan; } s_tmp;
+  __shared__ uint32_t s_part[4];
   __shared__ uint8_t s_buf[256 * kChunk * 2 + 8];
   __shared__ uint32_t s_len, s_base;
   const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
@@ -484,14 +477,13 @@ __global__ void __launch_bounds__(256) k_jpeg_stuff_copy(const Job j, const uint
   if (blk_b0 >= nbytes) return;                       // uniform per workgroup
   uint32_t before = 0;
   for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 256u) before += j.ff_blk[g];
-  before = Reduce(s_tmp.reduce).Sum(before);
+  before = block_sum<256>(before, s_part);
   if (threadIdx.x == 0) { s_len = 0u; s_base = before; }
   __syncthreads();
   const uint32_t base_ff = s_base;
   const uint64_t b0 = (uint64_t)t * kChunk;
   const bool mine = t < j.max_chunks && b0 < nbytes;
-  uint32_t ff_before = 0;
-  Scan(s_tmp.scan).ExclusiveSum(mine ? j.ff_count[t] : 0u, ff_before);
+  const uint32_t ff_before = block_exclusive_sum<256>(mine ? j.ff_count[t] : 0u, s_part);
   if (mine) {
     const uint32_t len = (uint32_t)(nbytes - b0 < kChunk ? nbytes - b0 : kChunk);
     uint32_t lo = (uint32_t)(b0 - blk_b0) + ff_before;

@@ -36,7 +36,11 @@
 // (DC prefix sum + IDCT here).  Arithmetic-coded / lossless files return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE; samplings other than
 // 4:2:0 / grayscale fail as they do in the reference.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_scan_by_key.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -45,6 +49,7 @@
 #include <vector>
 
 #include "uhdr_jpeg.h"
+#include "uhdr_wave_scan.h"
 
 namespace uhdr {
 namespace jpeg {
@@ -66,8 +71,7 @@ __device__ __forceinline__ bool dropped_byte(const uint8_t* src, uint32_t n, uin
 // bytes kept in front of every chunk: inside a workgroup that is a block scan of 256 counts, across workgroups a sum of at most a
 // few hundred totals, which every workgroup of the copy forms for itself -- no device-wide scan between the two kernels.
 __device__ __forceinline__ void unstuff_count_body(const uint8_t* src, uint32_t n, uint32_t* kept, uint32_t* kept_blk, int rst) {
-  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
-  __shared__ typename Reduce::TempStorage s_tmp;
+  __shared__ uint32_t s_part[4];
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t b0 = t * kUnstuffChunk;
   if (blockIdx.x * 256u * kUnstuffChunk >= n) return;   // (uniform: a workgroup behind the end of this image's segment owns no total)
@@ -82,14 +86,12 @@ __device__ __forceinline__ void unstuff_count_body(const uint8_t* src, uint32_t 
     }
     kept[t] = k;
   }
-  const uint32_t total = Reduce(s_tmp).Sum(k);
+  const uint32_t total = block_sum<256>(k, s_part);
   if (threadIdx.x == 0u) kept_blk[blockIdx.x] = total;
 }
 // a workgroup compacts its 16 KiB into LDS and writes the run out as aligned dwords (its start in `dst` is arbitrary)
 __device__ __forceinline__ void unstuff_copy_body(const uint8_t* src, uint32_t n, const uint32_t* kept, const uint32_t* kept_blk, uint8_t* dst, int rst) {
-  typedef hipcub::BlockReduce<uint32_t, 256> Reduce;
-  typedef hipcub::BlockScan<uint32_t, 256> Scan;
-  __shared__ union { typename Reduce::TempStorage reduce; typename Scan::TempStorage scan; } s_tmp;
+  __shared__ uint32_t s_part[4];
   __shared__ uint8_t s_buf[256 * kUnstuffChunk + 8];
   __shared__ uint32_t s_len, s_base;
   const uint32_t first = blockIdx.x * 256u, t = first + threadIdx.x;
@@ -97,14 +99,13 @@ __device__ __forceinline__ void unstuff_copy_body(const uint8_t* src, uint32_t n
   if (blk_b0 >= n) return;
   uint32_t before = 0;
   for (uint32_t g = threadIdx.x; g < blockIdx.x; g += 256u) before += kept_blk[g];
-  before = Reduce(s_tmp.reduce).Sum(before);
+  before = block_sum<256>(before, s_part);
   if (threadIdx.x == 0u) s_base = before;
   __syncthreads();
   const uint32_t base = s_base;
   const uint32_t b0 = t * kUnstuffChunk;
   if (threadIdx.x == 0) s_len = 0u;
-  uint32_t lo = 0;
-  Scan(s_tmp.scan).ExclusiveSum(b0 < n ? kept[t] : 0u, lo);
+  uint32_t lo = block_exclusive_sum<256>(b0 < n ? kept[t] : 0u, s_part);
   __syncthreads();
   if (b0 < n) {
     const uint32_t len = n - b0 < kUnstuffChunk ? n - b0 : kUnstuffChunk;
@@ -694,10 +695,10 @@ struct DcPickBatch {   // the DC difference of block g of the concatenation, in 
     return r;
   }
 };
-typedef hipcub::CountingInputIterator<uint32_t> CountIt;
-typedef hipcub::TransformInputIterator<uint64_t, SubKeyBatch, CountIt> SubKeyIt;
-typedef hipcub::TransformInputIterator<uint64_t, BlkKeyBatch, CountIt> BlkKeyIt;
-typedef hipcub::TransformInputIterator<Dc3, DcPickBatch, CountIt> DcPickIt;
+typedef rocprim::counting_iterator<uint32_t> CountIt;
+typedef rocprim::transform_iterator<CountIt, SubKeyBatch, uint64_t> SubKeyIt;
+typedef rocprim::transform_iterator<CountIt, BlkKeyBatch, uint64_t> BlkKeyIt;
+typedef rocprim::transform_iterator<CountIt, DcPickBatch, Dc3> DcPickIt;
 
 // What depends on nothing but the uploaded jobs, in one launch (a launch and the gap behind it cost more than any of the three):
 // workgroups [0, gu) count the bytes each 64-byte chunk of the stuffed segment keeps, the next kLutBlocks build the first-level
@@ -792,9 +793,10 @@ static BatchLayout batch_layout(int n, const DecLayout l[]) {
   size_t t2 = 0, t3 = 0;
   const SegOf seg{nullptr, n};
   CountIt cnt(0u);
-  (void)hipcub::DeviceScan::ExclusiveSumByKey(nullptr, t2, SubKeyIt(cnt, SubKeyBatch{nullptr, seg}), (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)B.n_sub);
-  (void)hipcub::DeviceScan::InclusiveScanByKey(nullptr, t3, BlkKeyIt(cnt, BlkKeyBatch{nullptr, seg}), DcPickIt(cnt, DcPickBatch{nullptr, seg}), (Dc3*)nullptr,
-                                               Dc3Sum(), (int)(B.n_blk ? B.n_blk : 1u));
+  (void)rocprim::exclusive_scan_by_key(nullptr, t2, SubKeyIt(cnt, SubKeyBatch{nullptr, seg}), (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)B.n_sub,
+                                        rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>());
+  (void)rocprim::inclusive_scan_by_key(nullptr, t3, BlkKeyIt(cnt, BlkKeyBatch{nullptr, seg}), DcPickIt(cnt, DcPickBatch{nullptr, seg}), (Dc3*)nullptr,
+                                        (size_t)(B.n_blk ? B.n_blk : 1u), Dc3Sum(), rocprim::equal_to<uint64_t>());
   B.tmp_bytes = up(std::max(t2, t3) + 256);
   B.tmp = o; o += B.tmp_bytes;
   B.total = o;
@@ -937,14 +939,15 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
   }
   if (soff[n]) {   // blocks completed before each subsequence, counted from the start of its image (of its restart interval)
     size_t tmp = B.tmp_bytes;
-    JD_TRY(hipcub::DeviceScan::ExclusiveSumByKey(stmp, tmp, SubKeyIt(cnt0, SubKeyBatch{djobs, sseg}), reinterpret_cast<const uint32_t*>(batch_ws + B.nblocks),
-                                                 reinterpret_cast<uint32_t*>(batch_ws + B.first_block), (int)soff[n], hipcub::Equality(), s));
+    JD_TRY(rocprim::exclusive_scan_by_key(stmp, tmp, SubKeyIt(cnt0, SubKeyBatch{djobs, sseg}), reinterpret_cast<const uint32_t*>(batch_ws + B.nblocks),
+                                          reinterpret_cast<uint32_t*>(batch_ws + B.first_block), 0u, (size_t)soff[n], rocprim::plus<uint32_t>(),
+                                          rocprim::equal_to<uint64_t>(), s));
   }
   hipLaunchKernelGGL(k_jd_write_multi, dim3(gsync, ny), b256, 0, s, (const DecBatchJob*)djobs);
   if (boff[n]) {   // DC differences -> DC values: per component, image and restart interval
     size_t tmp = B.tmp_bytes;
-    JD_TRY(hipcub::DeviceScan::InclusiveScanByKey(stmp, tmp, BlkKeyIt(cnt0, BlkKeyBatch{djobs, bseg}), DcPickIt(cnt0, DcPickBatch{djobs, bseg}),
-                                                  reinterpret_cast<Dc3*>(batch_ws + B.dc), Dc3Sum(), (int)boff[n], hipcub::Equality(), s));
+    JD_TRY(rocprim::inclusive_scan_by_key(stmp, tmp, BlkKeyIt(cnt0, BlkKeyBatch{djobs, bseg}), DcPickIt(cnt0, DcPickBatch{djobs, bseg}),
+                                          reinterpret_cast<Dc3*>(batch_ws + B.dc), (size_t)boff[n], Dc3Sum(), rocprim::equal_to<uint64_t>(), s));
   }
   hipLaunchKernelGGL(k_jd_idct_multi, dim3(gidct, ny), dim3(128), 0, s, (const DecBatchJob*)djobs);
   JD_LAP("tail enqueued");

@@ -87,8 +87,8 @@ extern "C" {
 /* arithmetic mode of uhdr_hip_apply_gainmap*:
  *   FAST  : float transcendentals on the CDNA4 special-function unit; every 10-bit channel within
  *           1 LSB and every F16 channel within 1 half-ULP of the reference CPU path;
- *   EXACT : the reference's float/double promotion pattern replayed with double libm-grade
- *           pow/exp/log/exp2 (same bytes as the CPU path; several times slower).
+ *   EXACT : the same bytes as the reference CPU path: its float/double promotion pattern replayed with correctly
+ *           rounded pow/exp/log/exp2, on the pixels an f32 estimate cannot settle (HDR_PQ: on every pixel).
  * generate/tonemap/convert_yuv have a single, bit-exact mode. */
 #define UHDR_HIP_APPLY_FAST 0
 #define UHDR_HIP_APPLY_EXACT 1
@@ -100,6 +100,9 @@ extern "C" {
  * (gainmapmath.cpp:21-64); with them the LUT pipelines are pure float/integer work and BIT-EXACT against
  * the reference's LUT functions. */
 #define UHDR_HIP_APPLY_LUT 2
+/* EXACT without its f32 pre-filter: every pixel takes the double-precision path (what EXACT always does for HDR_PQ).  Same
+ * bytes as UHDR_HIP_APPLY_EXACT; kept as a verification switch for tests. */
+#define UHDR_HIP_APPLY_EXACT_UNFILTERED 3
 #define UHDR_HIP_GENERATE_EXACT 0
 #define UHDR_HIP_GENERATE_LUT 1
 /* EXACT without the f32 pre-filter: every pixel takes the double-precision path.  Same bytes and statistics as

@@ -24,7 +24,7 @@ ERROR_INVALID_DISPLAY_BOOST, ERROR_INVALID_OUTPUT_FORMAT = -10008, -10009
 ERROR_ENCODE_ERROR, ERROR_DECODE_ERROR, ERROR_GAIN_MAP_IMAGE_NOT_FOUND, ERROR_METADATA_ERROR = -20001, -20002, -20003, -20005
 ERROR_NO_IMAGES_FOUND, ERROR_MULTIPLE_EXIFS_RECEIVED = -20006, -20007
 MEM_HOST, MEM_DEVICE = 0, 1
-APPLY_FAST, APPLY_EXACT, APPLY_LUT = 0, 1, 2
+APPLY_FAST, APPLY_EXACT, APPLY_LUT, APPLY_EXACT_UNFILTERED = 0, 1, 2, 3
 GENERATE_EXACT, GENERATE_LUT, GENERATE_UNFILTERED = 0, 1, 2
 ABI_VERSION = 3
 FLT_MAX = 3.4028234663852886e38

@@ -55,6 +55,9 @@ struct DeviceState {
   // generate with statistics: the candidate lists of one launch (kStatWsBytes), one workspace per stream the caller has used --
   // launches of one stream follow each other, launches of different streams may overlap
   std::map<hipStream_t, uint32_t*> stat_ws;
+  // EXACT apply behind its pre-filter: the lists of pixels in doubt (uhdr_kernels.h: ex_ws_bytes), per stream, grown on demand
+  struct ExWs { uint32_t* p = nullptr; size_t bytes = 0; };
+  std::map<hipStream_t, ExWs> ex_ws;
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
 std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
@@ -442,6 +445,8 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
         for (int j = 0; j < 2; ++j)
           c.fast.wD[oy][pr][k - 1][j] = (float)((double)t[oy * 16 + (2 * pr + j) * 4 + k] * (c.log2_max_d - c.log2_min_d) * ratio / 255.0);
   c.tab = nullptr;
+  c.ex_ws = nullptr;
+  c.ex_cap = 0;
   c.cells_per_thread = 8;
   return c;
 }
@@ -595,6 +600,7 @@ int uhdr_hip_shutdown(void) {
     if (kv.second.lut) (void)hipFree(kv.second.lut);
     for (void* q : kv.second.pool) if (q) (void)hipFree(q);
     for (auto& w : kv.second.stat_ws) if (w.second) (void)hipFree(w.second);
+    for (auto& w : kv.second.ex_ws) if (w.second.p) (void)hipFree(w.second.p);
     for (int i = 0; i < 14; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
     if (kv.second.map_ready) (void)hipEventDestroy(kv.second.map_ready);
@@ -1756,7 +1762,8 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
     const int rc = validate_apply(&yuvs[i], &maps[i], metadata, &dests[i]);
     if (rc != UHDR_HIP_NO_ERROR) return rc;
   }
-  if (apply_mode != UHDR_HIP_APPLY_FAST && apply_mode != UHDR_HIP_APPLY_EXACT && apply_mode != UHDR_HIP_APPLY_LUT)
+  if (apply_mode != UHDR_HIP_APPLY_FAST && apply_mode != UHDR_HIP_APPLY_EXACT && apply_mode != UHDR_HIP_APPLY_LUT &&
+      apply_mode != UHDR_HIP_APPLY_EXACT_UNFILTERED)
     return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
   DeviceState* st = nullptr;
   int rc = current_state(&st);
@@ -1794,6 +1801,22 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
       else if (f != fast) break;
       fill_apply_dest(&y, &dests[i + m]);
       ++m;
+    }
+    // EXACT with an HLG / F16 / planar output: f32 estimate, then the exact path on the pixels it leaves in doubt
+    if (writes && apply_mode == UHDR_HIP_APPLY_EXACT && output_format != UHDR_HIP_OUTPUT_HDR_PQ &&
+        (uint64_t)c.width * c.height <= 0xFFFFFFFFull) {
+      const uint32_t cap = ex_list_cap((uint64_t)c.width * c.height);
+      const size_t need = ((size_t)kMaxChunk * kExHdrWords + (size_t)m * kExLists * cap) * 4u;
+      std::lock_guard<std::mutex> lk(g_mu);
+      DeviceState::ExWs& w = st->ex_ws[s];
+      if (w.bytes < need) {
+        if (w.p) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+        HIP_TRY(hipMalloc(&w.p, need));
+        w.bytes = need;
+        HIP_TRY(hipMemsetAsync(w.p, 0, (size_t)kMaxChunk * kExHdrWords * 4u, s));   // the headers: cleared once, left cleared by every launch
+      }
+      c.ex_ws = w.p;
+      c.ex_cap = cap;
     }
     if (writes) HIP_TRY(launch_apply(c, b, m, output_format, apply_mode, fast, s));
     i += m;

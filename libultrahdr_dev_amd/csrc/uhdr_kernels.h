@@ -106,8 +106,18 @@ struct AppConsts {
   const float* lut;               // device LUT buffer (LUT mode only)
   const float* tab;               // device: the LUT buffer (line-segment tables at kTabS1* / kTabS2*), FAST scale-4 kernel
   float lut_boost_factor;         // GainLUT(metadata, displayBoost): displayBoost > 0 ? displayBoost / max : 1 (gainmapmath.h:162)
+  uint32_t* ex_ws;                // EXACT mode behind the f32 pre-filter: the lists of pixels in doubt (layout below), or nullptr
+  uint32_t ex_cap;                // entries per list
   AppFast fast;
 };
+// EXACT apply's workspace, one per stream: kMaxChunk headers of kExHdrWords words (word 3: slices of k_apply_resolve that have
+// finished; words 8 ..: the lengths of the image's kExLists lists), then kMaxChunk x kExLists lists of ex_cap pixel indices.  The
+// headers sit in front so that their place does not depend on the image size: every launch leaves them cleared.
+constexpr uint32_t kExLists = 1024;
+constexpr uint32_t kExHdrWords = 8 + kExLists;
+inline size_t ex_ws_bytes(uint32_t cap) { return ((size_t)kMaxChunk * kExHdrWords + (size_t)kMaxChunk * kExLists * cap) * 4u; }
+// capacity for a sixteenth of the image's pixels (the filter leaves ~1 % in doubt), spread over the lists
+inline uint32_t ex_list_cap(uint64_t pixels) { return (uint32_t)(pixels / 16u / kExLists) + 64u; }
 struct AppImage {
   const uint8_t* y;
   const uint8_t* u;

@@ -3,6 +3,7 @@
 //   k_generate<TF,ALIGNED>   UltraHdr::generateGainMap hot loop   (ref lib/src/ultrahdr.cpp:308-338)
 //   k_apply_s4<FMT,MASK>     UltraHdr::applyGainMap hot loop, scale 4, FAST arithmetic (:427-496)
 //   k_apply_px<FMT,EXACT>    same loop, any integer scale / any alignment / EXACT arithmetic
+//   k_apply_s4_est, k_apply_px_est, k_apply_resolve   EXACT arithmetic as an f32 estimate + the exact path on the pixels in doubt
 //   k_tonemap_*              UltraHdr::toneMap                    (:517-558)
 //   k_convert_yuv<ALIGNED>   JpegR::convertYuv + transformYuv420  (lib/src/jpegr.cpp:1199-1203,
 //                                                                  lib/src/gainmapmath.cpp:483-520)
@@ -24,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include "uhdr_device_math.h"
+#include "uhdr_wave_scan.h"
 
 namespace uhdr {
 
@@ -1383,19 +1385,16 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
 
 // General path: one thread per pixel; any integer scale, any pointer/stride alignment, FAST or
 // EXACT arithmetic.  Mirrors ultrahdr.cpp:427-496 + gainmapmath.cpp:686-720 literally.
-template <int FMT, bool EXACT>
-__global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBatch b) {
-  const AppImage& im = b.img[blockIdx.y];
-  const size_t total = (size_t)c.width * c.height;
-  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
-  if (idx >= total) return;
+struct PxIn { float yf, u, v, gain; };
+// the loads of ultrahdr.cpp:431-438 and sampleMap (gainmapmath.cpp:686-720) for pixel idx
+__device__ __forceinline__ PxIn px_inputs(const AppConsts& c, const AppImage& im, size_t idx) {
   const uint32_t y = (uint32_t)(idx / c.width);
   const uint32_t x = (uint32_t)(idx - (size_t)y * c.width);
-
-  const float yf = (float)im.y[(size_t)y * im.y_stride + x] * k255;
+  PxIn in;
+  in.yf = (float)im.y[(size_t)y * im.y_stride + x] * k255;
   const size_t ci = (size_t)(y >> 1) * im.c_stride + (x >> 1);
-  const float u = (float)((int)im.u[ci] - 128) * k255;
-  const float v = (float)((int)im.v[ci] - 128) * k255;
+  in.u = (float)((int)im.u[ci] - 128) * k255;
+  in.v = (float)((int)im.v[ci] - 128) * k255;
 
   const uint32_t s = c.scale;
   uint32_t xl = x / s, yl = y / s;
@@ -1412,10 +1411,11 @@ __global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBa
   else if (xl == xu) tbl = 1;
   else if (yl == yu) tbl = 2;
   const float* w = c.idw + (size_t)tbl * s * s * 4u + (size_t)oy * s * 4u + ox * 4u;
-  const float gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
-
-  const F3 lin = recover_hdr<EXACT>(c, yf, kP3Cr * v, kP3GCb * u, kP3GCr * v, kP3Cb * u, gain);
-  const F3 e = hdr_oetf<FMT, EXACT>(lin);
+  in.gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
+  return in;
+}
+template <int FMT>
+__device__ __forceinline__ void px_store(const AppImage& im, size_t idx, size_t total, F3 e) {
   if (FMT == 2 || FMT == 3) {
     static_cast<uint32_t*>(im.dst)[idx] = pack_1010102(e.x, e.y, e.z);
   } else if (FMT == 1) {
@@ -1425,6 +1425,259 @@ __global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBa
     base[idx] = (uint16_t)(0x3ffu & (uint32_t)(e.x * 1023.0f));
     base[total + idx] = (uint16_t)(0x3ffu & (uint32_t)(e.y * 1023.0f));
     base[2 * total + idx] = (uint16_t)(0x3ffu & (uint32_t)(e.z * 1023.0f));
+  }
+}
+
+template <int FMT, bool EXACT>
+__global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBatch b) {
+  const AppImage& im = b.img[blockIdx.y];
+  const size_t total = (size_t)c.width * c.height;
+  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total) return;
+  const PxIn in = px_inputs(c, im, idx);
+  const F3 lin = recover_hdr<EXACT>(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
+  px_store<FMT>(im, idx, total, hdr_oetf<FMT, EXACT>(lin));
+}
+
+// ---- EXACT mode behind an f32 pre-filter (HLG, F16 and planar 10-bit outputs) ----------------------------------------------------
+// The bit-exact pixel costs ~40 f64 operations per channel; what it decides in the end is an integer code (or a half-precision
+// pattern).  k_apply_px_est evaluates the pixel on the f32 units -- the front end up to the exponent's argument exactly as the
+// reference rounds it, then v_exp_f32 / v_log_f32 forms whose distance from the exact functions is measured for every float
+// (tests/test_gpu_exact_filter.py) -- and writes that result.  A channel is IN DOUBT when the interval the exact value must lie in
+// straddles a code boundary; pixels with such a channel (~1 %) go to per-image lists and k_apply_resolve recomputes exactly them
+// with the exact path and overwrites.  Error budget, in the reference's own quantities:
+//   lin = (srgbInvOetf(c) * factor) / displayBoost: relative error of the estimate <= kEstRel (srgb_inv_oetf_fast 6e-7, v_exp_f32
+//     2e-7, the two roundings are the reference's own), so the 10-bit planar code floor(lin * 1023) and the half-precision pattern are
+//     settled when both ends of lin (1 +- kEstRel) give the same;
+//   hlgOetf: x h'(x) <= 1/4, so the input's error moves the code value by <= 1023 / 4 * kEstRel = 4e-4; hlg_oetf_fast itself is
+//     within 3e-7 (3e-4 codes) of the exact function up to 1 and within 3e-7 relative above: doubt when
+//     floor(v - d) != floor(v + d), d = kEstHlgAbs + v * kEstHlgRel.
+// PQ stays on the plain exact kernel: pq_oetf_fast is three digits short of deciding anything.
+constexpr float kEstRel = 2.0e-6f;
+constexpr float kEstHlgAbs = 8.0e-4f, kEstHlgRel = 6.0e-7f;
+constexpr uint32_t kExSlices = 256;   // blocks of k_apply_resolve per image
+
+__device__ __forceinline__ F3 recover_hdr_est(const AppConsts& c, float yf, float crv, float gcbu, float gcrv, float cbu, float gain) {
+  const float r = clamp01(yf + crv), g = clamp01(yf - gcbu - gcrv), b = clamp01(yf + cbu);
+  const float log_boost = (float)(c.log2_min_d * (double)(1.0f - gain) + c.log2_max_d * (double)gain);
+  const float factor = __builtin_amdgcn_exp2f(log_boost * c.display_boost / c.max_boost);   // the argument as the reference rounds it
+  F3 o;
+  o.x = (srgb_inv_oetf_fast(r) * factor) / c.display_boost;
+  o.y = (srgb_inv_oetf_fast(g) * factor) / c.display_boost;
+  o.z = (srgb_inv_oetf_fast(b) * factor) / c.display_boost;
+  return o;
+}
+template <int FMT>
+__device__ __forceinline__ bool est_in_doubt(float lin, float e) {
+  if (FMT == 3) {
+    const float v = e * 1023.0f, d = __builtin_fmaf(v, kEstHlgRel, kEstHlgAbs);
+    return floorf(fmaxf(v - d, 0.0f)) != floorf(v + d);
+  }
+  const float lo = lin * (1.0f - kEstRel), hi = lin * (1.0f + kEstRel);
+  if (FMT == 1) return float_to_half(lo) != float_to_half(hi);
+  return floorf(lo * 1023.0f) != floorf(hi * 1023.0f);
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(256) k_apply_px_est(const AppConsts c, const AppBatch b) {
+  const AppImage& im = b.img[blockIdx.y];
+  const size_t total = (size_t)c.width * c.height;
+  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+  bool doubt = false;
+  if (idx < total) {
+    const PxIn in = px_inputs(c, im, idx);
+    const F3 lin = recover_hdr_est(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
+    const F3 e = hdr_oetf<FMT, false>(lin);
+    doubt = est_in_doubt<FMT>(lin.x, e.x) || est_in_doubt<FMT>(lin.y, e.y) || est_in_doubt<FMT>(lin.z, e.z);
+    px_store<FMT>(im, idx, total, e);
+  }
+  // one append per block: the list is chosen by the block so that no two neighbouring blocks share a counter
+  __shared__ uint32_t s_cnt[4], s_base;
+  const uint64_t mask = __ballot(doubt);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  const uint32_t list = blockIdx.x % kExLists;
+  uint32_t* hdr = c.ex_ws + (size_t)blockIdx.y * kExHdrWords;
+  if (threadIdx.x == 0) {
+    const uint32_t t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    s_base = t ? atomicAdd(hdr + 8u + list, t) : 0u;
+  }
+  __syncthreads();
+  if (doubt) {
+    uint32_t pos = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) pos += s_cnt[w];
+    if (pos < c.ex_cap)
+      c.ex_ws[(size_t)kMaxChunk * kExHdrWords + ((size_t)blockIdx.y * kExLists + list) * c.ex_cap + pos] = (uint32_t)idx;
+  }
+}
+
+// The same estimate for the common geometry (scale 4, aligned planes: app_fast_s4): thread = one map cell = 4x4 pixels, as in
+// k_apply_s4 -- the taps, the chroma terms and the addresses are formed once per cell, rows leave as 16-byte stores, and every
+// operation of the front end is the reference's own (same order, no contraction) up to the exponent's argument.  Doubt, per channel,
+// with v the value whose integer part is the code: the distance of v from the nearest integer against d (v < 1 can only be code 0
+// from below, hence the max).  F16: the hardware conversion rounds ties to even where the reference rounds them up; a value the
+// interval of which holds a tie is in doubt anyway, and so is the half-precision subnormal range.
+template <int FMT>
+__device__ __forceinline__ void est_channel(float lin, float& out, float& doubt_min) {
+  if (FMT == 3 || FMT == 4) {
+    const float v = (FMT == 3 ? hlg_oetf_fast(lin) : lin) * 1023.0f;
+    const float d = FMT == 3 ? __builtin_fmaf(v, kEstHlgRel, kEstHlgAbs) : v * kEstRel;
+    const float f = __builtin_amdgcn_fractf(fmaxf(v, 0.5f));
+    doubt_min = fminf(doubt_min, fminf(f, 1.0f - f) - d);   // < 0: in doubt
+    out = v;
+  } else {
+    const _Float16 lo = (_Float16)(lin * (1.0f - kEstRel)), hi = (_Float16)(lin * (1.0f + kEstRel));
+    if (lo != hi || (lin != 0.0f && lin < 0x1p-13f)) doubt_min = -1.0f;
+    out = lin;
+  }
+}
+
+template <int FMT, bool INTERIOR>
+__device__ __forceinline__ uint32_t est_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, const ApplyCellIn& in, int tbl) {
+  const float e1 = map_to_float_fast(in.mb[0]), e2 = map_to_float_fast(in.mb[1]);   // == byte / 255.0f for every byte
+  const float e3 = map_to_float_fast(in.mb[2]), e4 = map_to_float_fast(in.mb[3]);
+  float crv[2][2], gcbu[2][2], gcrv[2][2], cbu[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float u = (float)((int)((in.uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      const float v = (float)((int)((in.vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      crv[r][k] = kP3Cr * v; gcbu[r][k] = kP3GCb * u; gcrv[r][k] = kP3GCr * v; cbu[r][k] = kP3Cb * u;
+    }
+  const float* wt = c_idw4 + (INTERIOR ? 0 : tbl * 64);
+  const bool min_is_one = c.log2_min_d == 0.0;   // log2(min) (1 - g) is then +-0 and leaves the sum as it is
+  uint32_t doubt = 0u;
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy) {
+    float o[4][3];
+#pragma unroll
+    for (int ox = 0; ox < 4; ++ox) {
+      const float* w = wt + oy * 16 + ox * 4;
+      const float gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
+      const float log_boost = min_is_one ? (float)(c.log2_max_d * (double)gain)
+                                         : (float)(c.log2_min_d * (double)(1.0f - gain) + c.log2_max_d * (double)gain);
+      const float factor = __builtin_amdgcn_exp2f(log_boost * c.display_boost / c.max_boost) * c.inv_display_boost;
+      const float yf = (float)((in.yrow[oy] >> (8 * ox)) & 0xffu) * k255;
+      const int r2 = oy >> 1, k2 = ox >> 1;
+      // clamp01 as one v_med3_f32 (the same value for every finite input but -0, which ends as code 0 either way)
+      const float r = __builtin_amdgcn_fmed3f(yf + crv[r2][k2], 0.0f, 1.0f), g = __builtin_amdgcn_fmed3f(yf - gcbu[r2][k2] - gcrv[r2][k2], 0.0f, 1.0f);
+      const float b = __builtin_amdgcn_fmed3f(yf + cbu[r2][k2], 0.0f, 1.0f);
+      float dm = 1.0f;
+      est_channel<FMT>(srgb_inv_oetf_fast(r) * factor, o[ox][0], dm);
+      est_channel<FMT>(srgb_inv_oetf_fast(g) * factor, o[ox][1], dm);
+      est_channel<FMT>(srgb_inv_oetf_fast(b) * factor, o[ox][2], dm);
+      if (dm < 0.0f) doubt |= 1u << (oy * 4 + ox);
+    }
+    const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;
+    if (FMT == 3) {
+      uint4 q;
+      uint32_t* qq = &q.x;
+#pragma unroll
+      for (int ox = 0; ox < 4; ++ox)
+        qq[ox] = (0x3ffu & (uint32_t)o[ox][0]) | ((0x3ffu & (uint32_t)o[ox][1]) << 10) | ((0x3ffu & (uint32_t)o[ox][2]) << 20) | (0x3u << 30);
+      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), q);
+    } else if (FMT == 1) {
+      const uint2 a = pack_f16_hw(o[0][0], o[0][1], o[0][2]), bb = pack_f16_hw(o[1][0], o[1][1], o[1][2]);
+      const uint2 cc = pack_f16_hw(o[2][0], o[2][1], o[2][2]), d = pack_f16_hw(o[3][0], o[3][1], o[3][2]);
+      uint4* dst = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+      st_stream(dst, make_uint4(a.x, a.y, bb.x, bb.y));
+      st_stream(dst + 1, make_uint4(cc.x, cc.y, d.x, d.y));
+    } else {
+      const size_t plane = (size_t)c.width * c.height;
+      uint16_t* base16 = static_cast<uint16_t*>(im.dst);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const uint32_t q0 = 0x3ffu & (uint32_t)o[0][p], q1 = 0x3ffu & (uint32_t)o[1][p];
+        const uint32_t q2 = 0x3ffu & (uint32_t)o[2][p], q3 = 0x3ffu & (uint32_t)o[3][p];
+        *reinterpret_cast<uint2*>(base16 + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+      }
+    }
+  }
+  return doubt;
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(256) k_apply_s4_est(const AppConsts c, const AppBatch b) {
+  const AppImage& im = b.img[blockIdx.y];
+  const uint32_t cells = c.map_w * c.map_h;
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  uint32_t doubt = 0u, cx = 0u, cy = 0u;
+  if (idx < cells) {
+    cy = idx / c.map_w;
+    cx = idx - cy * c.map_w;
+    ApplyCellIn in;
+    apply_load_cell(c, im, cx, cy, in);
+    const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
+    const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
+    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) doubt = est_cell<FMT, true>(c, im, cx, cy, in, 0);
+    else doubt = est_cell<FMT, false>(c, im, cx, cy, in, tbl);
+  }
+  // one append per block
+  __shared__ uint32_t s_part[4], s_base;
+  const uint32_t mine = (uint32_t)__popc(doubt);
+  const uint32_t before = block_exclusive_sum<256>(mine, s_part);
+  const uint32_t list = blockIdx.x % kExLists;
+  uint32_t* hdr = c.ex_ws + (size_t)blockIdx.y * kExHdrWords;
+  if (threadIdx.x == 255) s_base = (before + mine) ? atomicAdd(hdr + 8u + list, before + mine) : 0u;
+  __syncthreads();
+  uint32_t pos = s_base + before;
+  uint32_t* entries = c.ex_ws + (size_t)kMaxChunk * kExHdrWords + ((size_t)blockIdx.y * kExLists + list) * c.ex_cap;
+  while (doubt) {
+    const uint32_t k = (uint32_t)__builtin_ctz(doubt);
+    doubt &= doubt - 1u;
+    if (pos < c.ex_cap) entries[pos] = (4u * cy + (k >> 2)) * c.width + 4u * cx + (k & 3u);
+    ++pos;
+  }
+}
+
+// grid (images, kExSlices).  Every block forms the prefix sums of the image's list lengths, takes its share of the entries and
+// recomputes them with the exact path; a list that overflowed turns the image into a sweep of all pixels.  The block that
+// finishes last clears the header for the next launch.
+template <int FMT>
+__global__ void __launch_bounds__(256) k_apply_resolve(const AppConsts c, const AppBatch b) {
+  const AppImage& im = b.img[blockIdx.x];
+  uint32_t* hdr = c.ex_ws + (size_t)blockIdx.x * kExHdrWords;
+  const uint32_t* entries = c.ex_ws + (size_t)kMaxChunk * kExHdrWords + (size_t)blockIdx.x * kExLists * c.ex_cap;
+  const size_t total = (size_t)c.width * c.height;
+  static_assert(kExLists == 1024, "four lists per thread");
+  __shared__ uint32_t s_first[kExLists + 1];
+  __shared__ uint32_t s_over;
+  if (threadIdx.x == 0) s_over = 0u;
+  __syncthreads();
+  const uint4 n4 = *reinterpret_cast<const uint4*>(hdr + 8u + 4u * threadIdx.x);
+  if (max(max(n4.x, n4.y), max(n4.z, n4.w)) > c.ex_cap) s_over = 1u;
+  __shared__ uint32_t s_part[4];
+  const uint32_t mine = n4.x + n4.y + n4.z + n4.w;
+  const uint32_t before = block_exclusive_sum<256>(mine, s_part);
+  s_first[4u * threadIdx.x] = before;
+  s_first[4u * threadIdx.x + 1u] = before + n4.x;
+  s_first[4u * threadIdx.x + 2u] = before + n4.x + n4.y;
+  s_first[4u * threadIdx.x + 3u] = before + n4.x + n4.y + n4.z;
+  if (threadIdx.x == 255) s_first[kExLists] = before + mine;
+  __syncthreads();
+  const bool sweep = s_over != 0u;
+  const size_t count = sweep ? total : (size_t)s_first[kExLists];
+  for (size_t g = (size_t)blockIdx.y * 256u + threadIdx.x; g < count; g += (size_t)kExSlices * 256u) {
+    size_t idx = g;
+    if (!sweep) {
+      uint32_t lo = 0, hi = kExLists;   // the list with s_first[list] <= g < s_first[list + 1]
+      while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_first[mid] <= (uint32_t)g) lo = mid; else hi = mid; }
+      idx = entries[(size_t)lo * c.ex_cap + ((uint32_t)g - s_first[lo])];
+    }
+    const PxIn in = px_inputs(c, im, idx);
+    const F3 lin = recover_hdr<true>(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
+    px_store<FMT>(im, idx, total, hdr_oetf<FMT, true>(lin));
+  }
+  // the header is cleared by the slice that finishes last (every slice has read the counts by then)
+  __shared__ uint32_t s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(hdr + 3u, 1u) == kExSlices - 1u;
+  __syncthreads();
+  if (s_last) {
+    reinterpret_cast<uint4*>(hdr + 8u)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) hdr[3] = 0u;
   }
 }
 
@@ -1496,7 +1749,7 @@ template <int FMT>
 static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, int mode,
                                  bool fast_s4, hipStream_t s) {
   if (n == 0 || c.width == 0 || c.height == 0) return hipSuccess;
-  const bool exact = mode == 1;
+  const bool exact = mode == 1 || mode == 3;
   if (mode == 2) {
     if (c.lut == nullptr) return hipErrorInvalidValue;
     const size_t total = (size_t)c.width * c.height, per_block = 256u * (size_t)kLutPixelsPerThread;
@@ -1529,7 +1782,11 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
   } else {
     const size_t total = (size_t)c.width * c.height;
     const dim3 grid((unsigned)((total + 255u) / 256u), n);
-    if (exact) hipLaunchKernelGGL((k_apply_px<FMT, true>), grid, dim3(256), 0, s, c, b);
+    if (exact && FMT != 2 && c.ex_ws != nullptr) {
+      if (fast_s4) hipLaunchKernelGGL((k_apply_s4_est<FMT>), dim3((c.map_w * c.map_h + 255u) / 256u, n), dim3(256), 0, s, c, b);
+      else hipLaunchKernelGGL((k_apply_px_est<FMT>), grid, dim3(256), 0, s, c, b);
+      hipLaunchKernelGGL((k_apply_resolve<FMT>), dim3(n, kExSlices), dim3(256), 0, s, c, b);
+    } else if (exact) hipLaunchKernelGGL((k_apply_px<FMT, true>), grid, dim3(256), 0, s, c, b);
     else hipLaunchKernelGGL((k_apply_px<FMT, false>), grid, dim3(256), 0, s, c, b);
   }
   return hipGetLastError();
@@ -1879,6 +2136,7 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 14: y = hlg_oetf_exact(x); break;
     case 15: y = pq_oetf_exact(x); break;
     case 24: y = hlg_oetf_fast(x); break;
+    case 26: y = __builtin_amdgcn_exp2f(x); break;
     case 25: y = pq_oetf_fast(x); break;
     case 20: y = srgb_inv_oetf_fast(x); break;
     case 21: y = hlg_inv_oetf_fast(x); break;

@@ -9,8 +9,8 @@ m = torch.randint(0, 256, ((W // 4) * (H // 4),), dtype=torch.uint8, device="cud
 o = torch.zeros(W * H * 8, dtype=torch.uint8, device="cuda")
 yi, mi, oi = api.yuv420_image(y.data_ptr(), W, H, 0), api.mono_image(m.data_ptr(), W // 4, H // 4), api.out_image(o.data_ptr())
 md = api.metadata(float(np.float32(1000.0) / np.float32(203.0)))
-for mode, name in ((api.APPLY_FAST, "FAST"), (api.APPLY_EXACT, "EXACT")):
-    for fmt, fn in ((api.OUTPUT_HDR_HLG, "HLG"), (api.OUTPUT_HDR_PQ, "PQ"), (api.OUTPUT_HDR_LINEAR, "F16")):
+for mode, name in ((api.APPLY_FAST, "FAST"), (api.APPLY_EXACT, "EXACT"), (api.APPLY_EXACT_UNFILTERED, "EXACT, pre-filter off")):
+    for fmt, fn in ((api.OUTPUT_HDR_HLG, "HLG"), (api.OUTPUT_HDR_PQ, "PQ"), (api.OUTPUT_HDR_LINEAR, "F16"), (api.OUTPUT_HDR_LINEAR_RGB_10BIT, "planar 10-bit")):
         f = lambda: lib.uhdr_hip_apply_gainmap(C.byref(yi), C.byref(mi), C.byref(md), fmt, api.FLT_MAX, C.byref(oi), mode, api.MEM_DEVICE, None)
         for _ in range(2): f()
         torch.cuda.synchronize()

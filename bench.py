@@ -241,7 +241,12 @@ def other_configs(lib, stream):
     ms = timed(lambda: lib.uhdr_hip_apply_gainmap_batch(nb, ya, mia, C.byref(md), api.OUTPUT_HDR_HLG, api.FLT_MAX, loa, api.APPLY_EXACT, stream), 3)
     out["EXACT mode: 4K apply -> HLG RGBA1010102, 32-frame launch"] = {"ms": round(ms, 4), "MPix/s": round(nb * W * H / 1e6 / (ms * 1e-3), 1),
                                                                       "GB/s": round(nb * APP_BYTES / (ms * 1e-3) / 1e9, 1)}
-    del louts
+    l8 = torch.zeros(W * H * 8, dtype=torch.uint8, device="cuda")
+    l8a = api.image_array([api.out_image(l8.data_ptr())])
+    for fmt, fname in ((api.OUTPUT_HDR_HLG, "HLG"), (api.OUTPUT_HDR_PQ, "PQ"), (api.OUTPUT_HDR_LINEAR, "F16"), (api.OUTPUT_HDR_LINEAR_RGB_10BIT, "planar 10-bit")):
+        ms = timed(lambda: lib.uhdr_hip_apply_gainmap_batch(1, ya, mia, C.byref(md), fmt, api.FLT_MAX, l8a, api.APPLY_EXACT, stream), 10)
+        out["EXACT mode: one 4K apply -> %s (the reference's bytes)" % fname] = {"ms": round(ms, 4), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1)}
+    del louts, l8
     # the drop-in form a CPU caller uses: host planes in, host bytes out (PCIe Gen5 both ways; never `value`)
     hp, hy = p.cpu().numpy(), y.cpu().numpy()
     hmap = np.zeros((W // 4) * (H // 4), np.uint8)

@@ -1802,9 +1802,10 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
       fill_apply_dest(&y, &dests[i + m]);
       ++m;
     }
-    // EXACT with an HLG / F16 / planar output: f32 estimate, then the exact path on the pixels it leaves in doubt
-    if (writes && apply_mode == UHDR_HIP_APPLY_EXACT && output_format != UHDR_HIP_OUTPUT_HDR_PQ &&
-        (uint64_t)c.width * c.height <= 0xFFFFFFFFull) {
+    // EXACT: f32 estimate, then the exact path on the pixels it leaves in doubt.  The estimate's error bounds are measured for
+    // |log2 boost| <= 32 (tests/test_gpu_exact_filter.py); beyond that every pixel takes the exact path.
+    if (writes && apply_mode == UHDR_HIP_APPLY_EXACT && (uint64_t)c.width * c.height <= 0xFFFFFFFFull &&
+        std::fabs(c.log2_min_d) <= 32.0 && std::fabs(c.log2_max_d) <= 32.0) {
       const uint32_t cap = ex_list_cap((uint64_t)c.width * c.height);
       const size_t need = ((size_t)kMaxChunk * kExHdrWords + (size_t)m * kExLists * cap) * 4u;
       std::lock_guard<std::mutex> lk(g_mu);

@@ -1451,10 +1451,10 @@ __global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBa
 //     settled when both ends of lin (1 +- kEstRel) give the same;
 //   hlgOetf: x h'(x) <= 1/4, so the input's error moves the code value by <= 1023 / 4 * kEstRel = 4e-4; hlg_oetf_fast itself is
 //     within 3e-7 (3e-4 codes) of the exact function up to 1 and within 3e-7 relative above: doubt when
-//     floor(v - d) != floor(v + d), d = kEstHlgAbs + v * kEstHlgRel.
-// PQ stays on the plain exact kernel: pq_oetf_fast is three digits short of deciding anything.
+//     floor(v - d) != floor(v + d), d = kEstOetfAbs + v * kEstOetfRel;
+//   pqOetf: v S(x) <= 112 codes per unit of relative input error (2.2e-4), pq_oetf_est is within 2.5e-4 codes: the same d.
 constexpr float kEstRel = 2.0e-6f;
-constexpr float kEstHlgAbs = 8.0e-4f, kEstHlgRel = 6.0e-7f;
+constexpr float kEstOetfAbs = 8.0e-4f, kEstOetfRel = 6.0e-7f;
 constexpr uint32_t kExSlices = 256;   // blocks of k_apply_resolve per image
 
 __device__ __forceinline__ F3 recover_hdr_est(const AppConsts& c, float yf, float crv, float gcbu, float gcrv, float cbu, float gain) {
@@ -1467,15 +1467,20 @@ __device__ __forceinline__ F3 recover_hdr_est(const AppConsts& c, float yf, floa
   o.z = (srgb_inv_oetf_fast(b) * factor) / c.display_boost;
   return o;
 }
+// one channel: lin -> the value whose integer part is the code (the half-precision source for F16), and the doubt test (below)
 template <int FMT>
-__device__ __forceinline__ bool est_in_doubt(float lin, float e) {
-  if (FMT == 3) {
-    const float v = e * 1023.0f, d = __builtin_fmaf(v, kEstHlgRel, kEstHlgAbs);
-    return floorf(fmaxf(v - d, 0.0f)) != floorf(v + d);
+__device__ __forceinline__ void est_channel(float lin, float& out, float& doubt_min) {
+  if (FMT != 1) {
+    const float v = (FMT == 3 ? hlg_oetf_fast(lin) : FMT == 2 ? pq_oetf_est(lin) : lin) * 1023.0f;
+    const float d = FMT == 4 ? v * kEstRel : __builtin_fmaf(v, kEstOetfRel, kEstOetfAbs);
+    const float f = __builtin_amdgcn_fractf(fmaxf(v, 0.5f));
+    doubt_min = fminf(doubt_min, fminf(f, 1.0f - f) - d);   // < 0: in doubt
+    out = v;
+  } else {
+    const _Float16 lo = (_Float16)(lin * (1.0f - kEstRel)), hi = (_Float16)(lin * (1.0f + kEstRel));
+    if (lo != hi || (lin != 0.0f && lin < 0x1p-13f)) doubt_min = -1.0f;
+    out = lin;
   }
-  const float lo = lin * (1.0f - kEstRel), hi = lin * (1.0f + kEstRel);
-  if (FMT == 1) return float_to_half(lo) != float_to_half(hi);
-  return floorf(lo * 1023.0f) != floorf(hi * 1023.0f);
 }
 
 template <int FMT>
@@ -1487,9 +1492,21 @@ __global__ void __launch_bounds__(256) k_apply_px_est(const AppConsts c, const A
   if (idx < total) {
     const PxIn in = px_inputs(c, im, idx);
     const F3 lin = recover_hdr_est(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
-    const F3 e = hdr_oetf<FMT, false>(lin);
-    doubt = est_in_doubt<FMT>(lin.x, e.x) || est_in_doubt<FMT>(lin.y, e.y) || est_in_doubt<FMT>(lin.z, e.z);
-    px_store<FMT>(im, idx, total, e);
+    float o[3], dm = 1.0f;
+    est_channel<FMT>(lin.x, o[0], dm);
+    est_channel<FMT>(lin.y, o[1], dm);
+    est_channel<FMT>(lin.z, o[2], dm);
+    doubt = dm < 0.0f;
+    if (FMT == 2 || FMT == 3) {
+      static_cast<uint32_t*>(im.dst)[idx] = (0x3ffu & (uint32_t)o[0]) | ((0x3ffu & (uint32_t)o[1]) << 10) | ((0x3ffu & (uint32_t)o[2]) << 20) | (0x3u << 30);
+    } else if (FMT == 1) {
+      static_cast<uint2*>(im.dst)[idx] = pack_f16_hw(o[0], o[1], o[2]);
+    } else {
+      uint16_t* base = static_cast<uint16_t*>(im.dst);
+      base[idx] = (uint16_t)(0x3ffu & (uint32_t)o[0]);
+      base[total + idx] = (uint16_t)(0x3ffu & (uint32_t)o[1]);
+      base[2 * total + idx] = (uint16_t)(0x3ffu & (uint32_t)o[2]);
+    }
   }
   // one append per block: the list is chosen by the block so that no two neighbouring blocks share a counter
   __shared__ uint32_t s_cnt[4], s_base;
@@ -1518,21 +1535,6 @@ __global__ void __launch_bounds__(256) k_apply_px_est(const AppConsts c, const A
 // with v the value whose integer part is the code: the distance of v from the nearest integer against d (v < 1 can only be code 0
 // from below, hence the max).  F16: the hardware conversion rounds ties to even where the reference rounds them up; a value the
 // interval of which holds a tie is in doubt anyway, and so is the half-precision subnormal range.
-template <int FMT>
-__device__ __forceinline__ void est_channel(float lin, float& out, float& doubt_min) {
-  if (FMT == 3 || FMT == 4) {
-    const float v = (FMT == 3 ? hlg_oetf_fast(lin) : lin) * 1023.0f;
-    const float d = FMT == 3 ? __builtin_fmaf(v, kEstHlgRel, kEstHlgAbs) : v * kEstRel;
-    const float f = __builtin_amdgcn_fractf(fmaxf(v, 0.5f));
-    doubt_min = fminf(doubt_min, fminf(f, 1.0f - f) - d);   // < 0: in doubt
-    out = v;
-  } else {
-    const _Float16 lo = (_Float16)(lin * (1.0f - kEstRel)), hi = (_Float16)(lin * (1.0f + kEstRel));
-    if (lo != hi || (lin != 0.0f && lin < 0x1p-13f)) doubt_min = -1.0f;
-    out = lin;
-  }
-}
-
 template <int FMT, bool INTERIOR>
 __device__ __forceinline__ uint32_t est_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, const ApplyCellIn& in, int tbl) {
   const float e1 = map_to_float_fast(in.mb[0]), e2 = map_to_float_fast(in.mb[1]);   // == byte / 255.0f for every byte
@@ -1571,7 +1573,7 @@ __device__ __forceinline__ uint32_t est_cell(const AppConsts& c, const AppImage&
       if (dm < 0.0f) doubt |= 1u << (oy * 4 + ox);
     }
     const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;
-    if (FMT == 3) {
+    if (FMT == 2 || FMT == 3) {
       uint4 q;
       uint32_t* qq = &q.x;
 #pragma unroll
@@ -1782,7 +1784,7 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
   } else {
     const size_t total = (size_t)c.width * c.height;
     const dim3 grid((unsigned)((total + 255u) / 256u), n);
-    if (exact && FMT != 2 && c.ex_ws != nullptr) {
+    if (exact && c.ex_ws != nullptr) {
       if (fast_s4) hipLaunchKernelGGL((k_apply_s4_est<FMT>), dim3((c.map_w * c.map_h + 255u) / 256u, n), dim3(256), 0, s, c, b);
       else hipLaunchKernelGGL((k_apply_px_est<FMT>), grid, dim3(256), 0, s, c, b);
       hipLaunchKernelGGL((k_apply_resolve<FMT>), dim3(n, kExSlices), dim3(256), 0, s, c, b);
@@ -2137,6 +2139,7 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 15: y = pq_oetf_exact(x); break;
     case 24: y = hlg_oetf_fast(x); break;
     case 26: y = __builtin_amdgcn_exp2f(x); break;
+    case 27: y = pq_oetf_est(x); break;
     case 25: y = pq_oetf_fast(x); break;
     case 20: y = srgb_inv_oetf_fast(x); break;
     case 21: y = hlg_inv_oetf_fast(x); break;

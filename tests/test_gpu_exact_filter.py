@@ -1,9 +1,9 @@
 """-m gpu: EXACT apply behind its f32 pre-filter (csrc/uhdr_kernels.hip: k_apply_px_est / k_apply_resolve).
 
-For HLG, F16 and planar 10-bit outputs the EXACT mode first evaluates every pixel on the f32 units and sends only the pixels whose
+The EXACT mode first evaluates every pixel on the f32 units and sends only the pixels whose
 integer code (half-precision pattern) that estimate cannot settle to the double-precision path.  Bit-exactness then rests on
 
- (1) the error bounds the doubt test assumes (kEstRel, kEstHlgAbs / kEstHlgRel in the kernel source) -- measured here for EVERY float
+ (1) the error bounds the doubt test assumes (kEstRel, kEstOetfAbs / kEstOetfRel in the kernel source) -- measured here for EVERY float
      of each function's domain against the exact device functions (themselves pinned to glibc in test_gpu_transfer_exhaustive.py);
  (2) filtered == unfiltered on whole images: random frames at several scales and display boosts, a batch, and frames built so that
      every pixel is in doubt (the lists overflow and the resolve kernel sweeps the image).
@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 FLT_MAX = 3.4028234663852886e38
 # the budget of csrc/uhdr_kernels.hip, restated: the test fails if the measured errors do not fit into it
 EST_REL = 2.0e-6
-EST_HLG_ABS, EST_HLG_REL = 8.0e-4, 6.0e-7
+EST_OETF_ABS, EST_OETF_REL = 8.0e-4, 6.0e-7
 
 
 def _eval(lib, fn, x):
@@ -74,9 +74,25 @@ def test_estimate_error_budget(hip):
         xd = x.double()
         sens = torch.where(xd <= 1.0 / 12.0, 0.5 * b, 1023.0 * 0.17883277 * 12.0 * xd / (12.0 * xd - 0.28466892).clamp_min(0.7))
         need = err + sens * EST_REL
-        have = EST_HLG_ABS + a * EST_HLG_REL
+        have = EST_OETF_ABS + a * EST_OETF_REL
         worst_margin = max(worst_margin, float((need / have).max().item()))
     print("hlgOetf estimate: needs at most %.2f of the doubt interval" % worst_margin)
+    assert worst_margin <= 0.9, worst_margin
+
+    # pqOetf: pq_oetf_est against the exact function, plus the input's error through S(x) = d ln(code) / d ln(x)
+    m1, m2 = 2610.0 / 16384.0, 2523.0 / 4096.0 * 128.0
+    c1, c2, c3 = 3424.0 / 4096.0, 2413.0 / 4096.0 * 32.0, 2392.0 / 4096.0 * 32.0
+    worst_margin = worst_err = 0.0
+    for x in _all_floats(0, 0x42800000):
+        a, b = _eval(lib, 27, x).double() * 1023.0, _eval(lib, 15, x).double() * 1023.0
+        err = (a - b).abs() + 2.0 ** -24 * b
+        p = x.double().clamp_min(1e-300).pow(m1)
+        sens = b * m2 * m1 * p * (c2 / (c1 + c2 * p) - c3 / (1.0 + c3 * p))
+        need = err + sens * EST_REL
+        have = EST_OETF_ABS + a * EST_OETF_REL
+        worst_margin = max(worst_margin, float((need / have).max().item()))
+        worst_err = max(worst_err, float((a - b).abs().max().item()))
+    print("pqOetf estimate: within %.3g codes of the exact function; needs at most %.2f of the doubt interval" % (worst_err, worst_margin))
     assert worst_margin <= 0.9, worst_margin
 
 
@@ -89,7 +105,7 @@ def _apply(lib, hip, yuv, w, h, gmap, md, fmt, boost, mode):
     return out
 
 
-@pytest.mark.parametrize("fmt", [1, 3, 4])
+@pytest.mark.parametrize("fmt", [1, 2, 3, 4])
 @pytest.mark.parametrize("scale,boost", [(4, FLT_MAX), (4, 2.0), (1, FLT_MAX), (3, 1.0), (8, FLT_MAX)])
 def test_filtered_equals_unfiltered(hip, orc, fmt, scale, boost):
     lib = hip.load()
@@ -108,7 +124,7 @@ def test_filtered_equals_unfiltered(hip, orc, fmt, scale, boost):
     assert np.array_equal(a2, b)
 
 
-@pytest.mark.parametrize("fmt", [3, 4])
+@pytest.mark.parametrize("fmt", [2, 3, 4])
 def test_every_pixel_in_doubt_overflows_into_a_sweep(hip, orc, fmt):
     """white with gain 1 and display boost == content boost is linear 1.0: code value 1023.0 to within the estimate's error, in
     doubt for every pixel -- far more than the lists hold"""
@@ -130,6 +146,19 @@ def test_every_pixel_in_doubt_overflows_into_a_sweep(hip, orc, fmt):
     _, yuv3 = orc.lcg_frame(w, h, 77)
     ref3 = _oracle_apply(orc, yuv3, w, h, gmap, maxb, fmt, FLT_MAX)
     assert np.array_equal(_apply(lib, hip, yuv3, w, h, gmap, md, fmt, FLT_MAX, hip.APPLY_EXACT), ref3)
+
+
+def test_boosts_beyond_the_measured_range_take_the_exact_path(hip, orc):
+    """|log2 boost| > 32 is outside what the estimate's bounds were measured for: the call runs unfiltered (and still equals the oracle)"""
+    from tests.test_gpu_parity import _oracle_apply
+    lib = hip.load()
+    w, h = 64, 32
+    _, yuv = orc.lcg_frame(w, h, 3)
+    gmap = np.random.RandomState(4).randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    minb, maxb = np.float32(2.0 ** -40), np.float32(2.0 ** 36)
+    md = hip.metadata(maxb, minb)
+    ref = _oracle_apply(orc, yuv, w, h, gmap, maxb, hip.OUTPUT_HDR_HLG, 8.0, minb)
+    assert np.array_equal(_apply(lib, hip, yuv, w, h, gmap, md, hip.OUTPUT_HDR_HLG, 8.0, hip.APPLY_EXACT), ref)
 
 
 def test_batch_of_frames_and_a_second_stream(hip, orc):

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -39,13 +40,20 @@ void set_err(const char* where, hipError_t e) {
   } while (0)
 
 // ---- per-device state --------------------------------------------------------------------------
-struct DeviceState {
+// grow-only device staging buffers of one UHDR_HIP_MEM_HOST call.  The four pixel-path entry points (generate, apply, toneMap,
+// convertYuv) lease a set of their own for the duration of a call, so host callers on different streams overlap their copies and
+// kernels; the codec entry points use the device's own set (the DeviceState itself) under g_host_mu / g_jpegr_mu.
+struct StageSet {
+  void* stage[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+struct DeviceState : StageSet {
   bool ready = false;
   std::map<int, float*> idw;  // scale -> device tables (4 * scale*scale*4 floats)
   float* lut = nullptr;       // the five static transfer-function tables (kLutTotal floats), built at init
-  // grow-only staging buffers for UHDR_HIP_MEM_HOST calls
-  void* stage[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t stage_bytes[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<std::unique_ptr<StageSet>> sets;   // every set ever leased ...
+  std::vector<StageSet*> free_sets;              // ... and those not in use (both under g_mu)
+  std::vector<void*> retired;                    // workspaces that were outgrown while a launch may still have named them
   // uhdr_hip_jpegr_decode[_batch]: per-file decoder workspaces and planes
   std::vector<void*> pool;
   std::vector<size_t> pool_bytes;
@@ -60,7 +68,7 @@ struct DeviceState {
   std::map<hipStream_t, ExWs> ex_ws;
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
-std::mutex g_host_mu;               // serialises host-staged calls (they share the staging buffers)
+std::mutex g_host_mu;               // serialises the codec's host-staged calls (they share the device's own staging set)
 std::mutex g_jpegr_mu;              // serialises uhdr_hip_jpegr_decode (slots 8-10), which calls the entry points above
 std::map<int, DeviceState> g_dev;
 
@@ -474,7 +482,7 @@ void fill_apply_dest(const uhdr_hip_image_t* yuv, uhdr_hip_image_t* dest) {  // 
 }
 
 // ---- host staging ----------------------------------------------------------------------------------
-int stage_reserve(DeviceState* st, int slot, size_t bytes) {
+int stage_reserve(StageSet* st, int slot, size_t bytes) {
   if (bytes == 0) bytes = 256;
   if (st->stage_bytes[slot] >= bytes) return UHDR_HIP_NO_ERROR;
   if (st->stage[slot]) HIP_TRY(hipFree(st->stage[slot]));
@@ -485,6 +493,31 @@ int stage_reserve(DeviceState* st, int slot, size_t bytes) {
   return UHDR_HIP_NO_ERROR;
 }
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// one staging set for the duration of a host-memory call
+class StageLease {
+ public:
+  explicit StageLease(DeviceState* st) : st_(st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (st_->free_sets.empty()) {
+      st_->sets.emplace_back(new StageSet());
+      set_ = st_->sets.back().get();
+    } else {
+      set_ = st_->free_sets.back();
+      st_->free_sets.pop_back();
+    }
+  }
+  ~StageLease() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    st_->free_sets.push_back(set_);
+  }
+  StageLease(const StageLease&) = delete;
+  StageLease& operator=(const StageLease&) = delete;
+  StageSet* get() const { return set_; }
+ private:
+  DeviceState* st_;
+  StageSet* set_;
+};
 
 // copy `rows` rows of `row_elems` elements of `esz` bytes from a strided host plane into a device
 // plane with pitch dpitch_elems.  Only bytes the reference itself would touch are read.
@@ -507,7 +540,7 @@ int d2h_plane(void* h, size_t hstride_elems, const void* d, size_t dpitch_elems,
 }
 
 // device copy of a host YUV420 image in slots [slot, slot+1]: Y then U|V (pitch = 64-aligned)
-int stage_yuv420_in(DeviceState* st, int slot, const uhdr_hip_image_t& h, uhdr_hip_image_t* d, hipStream_t s) {
+int stage_yuv420_in(StageSet* st, int slot, const uhdr_hip_image_t& h, uhdr_hip_image_t* d, hipStream_t s) {
   const size_t w = h.width, hh = h.height, cw = (w + 1) / 2, ch = (hh + 1) / 2;
   const size_t lp = round_up(w ? w : 1, 64), cp = round_up(cw ? cw : 1, 64);
   // the V plane must sit at u + cp*(hh/2) for the kernels (gainmapmath.cpp:568)
@@ -527,7 +560,7 @@ int stage_yuv420_in(DeviceState* st, int slot, const uhdr_hip_image_t& h, uhdr_h
   if ((rc = h2d_plane(du + cp * (hh / 2), cp, hv, h.chroma_stride, cw, ch, 1, s)) != 0) return rc;
   return UHDR_HIP_NO_ERROR;
 }
-int stage_p010_in(DeviceState* st, int slot, const uhdr_hip_image_t& h, uhdr_hip_image_t* d, hipStream_t s) {
+int stage_p010_in(StageSet* st, int slot, const uhdr_hip_image_t& h, uhdr_hip_image_t* d, hipStream_t s) {
   const size_t w = h.width, hh = h.height, cw2 = ((w + 1) / 2) * 2, ch = (hh + 1) / 2;
   const size_t lp = round_up(w ? w : 1, 64), cp = round_up(cw2 ? cw2 : 2, 64);
   int rc;
@@ -603,6 +636,10 @@ int uhdr_hip_shutdown(void) {
     for (auto& w : kv.second.ex_ws) if (w.second.p) (void)hipFree(w.second.p);
     for (int i = 0; i < 14; ++i)
       if (kv.second.stage[i]) (void)hipFree(kv.second.stage[i]);
+    for (auto& set : kv.second.sets)
+      for (int i = 0; i < 14; ++i)
+        if (set->stage[i]) (void)hipFree(set->stage[i]);
+    for (void* q : kv.second.retired) (void)hipFree(q);
     if (kv.second.map_ready) (void)hipEventDestroy(kv.second.map_ready);
     if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
   }
@@ -1811,9 +1848,12 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
       std::lock_guard<std::mutex> lk(g_mu);
       DeviceState::ExWs& w = st->ex_ws[s];
       if (w.bytes < need) {
-        if (w.p) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
-        HIP_TRY(hipMalloc(&w.p, need));
-        w.bytes = need;
+        // another caller of this stream may be about to launch with the old one: it stays allocated (sizes at least double)
+        if (w.p) { st->retired.push_back(w.p); w.p = nullptr; }
+        const size_t grown = std::max(need, 2 * w.bytes);
+        w.bytes = 0;
+        HIP_TRY(hipMalloc(&w.p, grown));
+        w.bytes = grown;
         HIP_TRY(hipMemsetAsync(w.p, 0, (size_t)kMaxChunk * kExHdrWords * 4u, s));   // the headers: cleared once, left cleared by every launch
       }
       c.ex_ws = w.p;
@@ -1843,14 +1883,15 @@ int uhdr_hip_generate_gainmap_ex(const uhdr_hip_image_t* yuv, const uhdr_hip_ima
 
   DeviceState* st = nullptr;
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
-  std::lock_guard<std::mutex> lk(g_host_mu);
+  StageLease lease(st);
+  StageSet* ss = lease.get();
   hipStream_t s = static_cast<hipStream_t>(stream);
   uhdr_hip_image_t dy, dp, dm = *dest;
-  if ((rc = stage_yuv420_in(st, 0, *yuv, &dy, s)) != 0) return rc;
-  if ((rc = stage_p010_in(st, 2, *p010, &dp, s)) != 0) return rc;
+  if ((rc = stage_yuv420_in(ss, 0, *yuv, &dy, s)) != 0) return rc;
+  if ((rc = stage_p010_in(ss, 2, *p010, &dp, s)) != 0) return rc;
   const size_t mw = yuv->width / 4, mh = yuv->height / 4;
-  if ((rc = stage_reserve(st, 4, mw * mh)) != 0) return rc;
-  dm.data = st->stage[4];
+  if ((rc = stage_reserve(ss, 4, mw * mh)) != 0) return rc;
+  dm.data = ss->stage[4];
   rc = uhdr_hip_generate_gainmap_batch_ex(1, &dy, &dp, hdr_tf, metadata, &dm, sdr_is_601, generate_mode, nullptr, stream);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   if (mw * mh) HIP_TRY(hipMemcpyAsync(dest->data, dm.data, mw * mh, hipMemcpyDeviceToHost, s));
@@ -1871,17 +1912,18 @@ int uhdr_hip_apply_gainmap(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* 
   if (writes && dest->data == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   DeviceState* st = nullptr;
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
-  std::lock_guard<std::mutex> lk(g_host_mu);
+  StageLease lease(st);
+  StageSet* ss = lease.get();
   hipStream_t s = static_cast<hipStream_t>(stream);
   uhdr_hip_image_t dy, dm = *map, dd = *dest;
-  if ((rc = stage_yuv420_in(st, 0, *yuv, &dy, s)) != 0) return rc;
+  if ((rc = stage_yuv420_in(ss, 0, *yuv, &dy, s)) != 0) return rc;
   const size_t map_bytes = map->width * map->height;  // the reference reads the map with stride == width
-  if ((rc = stage_reserve(st, 4, map_bytes)) != 0) return rc;
-  HIP_TRY(hipMemcpyAsync(st->stage[4], map->data, map_bytes, hipMemcpyHostToDevice, s));
-  dm.data = st->stage[4];
+  if ((rc = stage_reserve(ss, 4, map_bytes)) != 0) return rc;
+  HIP_TRY(hipMemcpyAsync(ss->stage[4], map->data, map_bytes, hipMemcpyHostToDevice, s));
+  dm.data = ss->stage[4];
   const size_t out_bytes = writes ? yuv->width * yuv->height * apply_bpp(output_format) : 0;
-  if ((rc = stage_reserve(st, 5, out_bytes)) != 0) return rc;
-  dd.data = st->stage[5];
+  if ((rc = stage_reserve(ss, 5, out_bytes)) != 0) return rc;
+  dd.data = ss->stage[5];
   rc = uhdr_hip_apply_gainmap_batch(1, &dy, &dm, metadata, output_format, max_display_boost, &dd, apply_mode, stream);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   if (out_bytes) HIP_TRY(hipMemcpyAsync(dest->data, dd.data, out_bytes, hipMemcpyDeviceToHost, s));
@@ -1961,14 +2003,15 @@ int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int me
     return UHDR_HIP_NO_ERROR;
   };
 
-  std::lock_guard<std::mutex> lk(g_host_mu);
+  StageLease lease(st);
+  StageSet* ss = lease.get();
   uhdr_hip_image_t ds, dd = *dest;
-  if ((rc = stage_p010_in(st, 2, *src, &ds, s)) != 0) return rc;
+  if ((rc = stage_p010_in(ss, 2, *src, &ds, s)) != 0) return rc;
   const size_t h = dest->height, ls = dest->luma_stride, cs = dest->chroma_stride;
-  if ((rc = stage_reserve(st, 0, ls * h)) != 0) return rc;
-  if ((rc = stage_reserve(st, 1, cs * h + cs)) != 0) return rc;
-  dd.data = st->stage[0];
-  dd.chroma_data = st->stage[1];
+  if ((rc = stage_reserve(ss, 0, ls * h)) != 0) return rc;
+  if ((rc = stage_reserve(ss, 1, cs * h + cs)) != 0) return rc;
+  dd.data = ss->stage[0];
+  dd.chroma_data = ss->stage[1];
   if ((rc = run(ds, dd)) != 0) return rc;
   // the reference writes luma_stride bytes per luma row and chroma_stride bytes per chroma row
   if (ls * h) HIP_TRY(hipMemcpyAsync(dest->data, dd.data, ls * h, hipMemcpyDeviceToHost, s));
@@ -2036,9 +2079,9 @@ int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_enc
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto run = [&](const uhdr_hip_image_t& d) -> int { return convert_yuv_into(d, d, m, s); };
-  std::lock_guard<std::mutex> lk(g_host_mu);
+  StageLease lease(st);
   uhdr_hip_image_t d;
-  if ((rc = stage_yuv420_in(st, 0, *image, &d, s)) != 0) return rc;
+  if ((rc = stage_yuv420_in(lease.get(), 0, *image, &d, s)) != 0) return rc;
   if ((rc = run(d)) != 0) return rc;
   const size_t w = image->width, h = image->height, cw = w / 2, ch = h / 2;
   if ((rc = d2h_plane(image->data, image->luma_stride, d.data, d.luma_stride, cw * 2, ch * 2, 1, s)) != 0) return rc;

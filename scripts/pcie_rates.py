@@ -40,6 +40,23 @@ def both():
 
 
 out["duplex_pinned_GBs_each_way"] = n / wall(both) / 1e9
+# one direction split over k streams (k copy engines), pinned and pageable
+for k in (2, 4, 8):
+    streams = [torch.cuda.Stream() for _ in range(k)]
+    c = n // k
+    for name, host in (("pinned", pin), ("pageable", pag)):
+        def h2d():
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    dev[i * c:(i + 1) * c].copy_(host[i * c:(i + 1) * c], non_blocking=True)
+
+        def d2h():
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    host[i * c:(i + 1) * c].copy_(dev[i * c:(i + 1) * c], non_blocking=True)
+
+        out["h2d_%s_%d_streams_GBs" % (name, k)] = n / wall(h2d) / 1e9
+        out["d2h_%s_%d_streams_GBs" % (name, k)] = n / wall(d2h) / 1e9
 t0 = time.perf_counter()
 for _ in range(5):
     pin.copy_(pag)

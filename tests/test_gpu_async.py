@@ -99,3 +99,71 @@ def test_two_host_threads_two_streams(hip, orc):
     md = hip.metadata(float(np.float32(1000.0) / np.float32(203.0)))
     for t in range(2):
         _check(hip, orc, sets[t][5], w, h, md)
+
+
+def test_host_memory_callers_on_their_own_streams_do_not_share_staging(hip, orc):
+    """UHDR_HIP_MEM_HOST calls lease a staging set each (uhdr_capi.hip: StageLease): four threads with different image sizes, each on
+    its own stream, run generate / apply (FAST and EXACT) / toneMap / convertYuv on host buffers concurrently; every result equals
+    the oracle's"""
+    lib = hip.load()
+    sizes = [(192, 96), (256, 128), (64, 64), (320, 64)]
+    errs = []
+    results = {}
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            s = C.c_void_p(st.cuda_stream)
+            w, h = sizes[t]
+            for it in range(4):
+                p010, yuv = orc.lcg_frame(w, h, 900 + 10 * t + it)
+                p010, yuv = p010.copy(), yuv.copy()
+                gmap = np.zeros((h // 4) * (w // 4), np.uint8)
+                yi = hip.yuv420_image(yuv.ctypes.data, w, h, hip.CG_BT709)
+                pi = hip.p010_image(p010.ctypes.data, w, h, hip.CG_BT2100)
+                mi = hip.out_image(gmap.ctypes.data)
+                md = hip.Metadata()
+                assert lib.uhdr_hip_generate_gainmap(C.byref(yi), C.byref(pi), hip.TF_HLG, C.byref(md), C.byref(mi), 0, hip.MEM_HOST, s) == 0
+                outs = {}
+                for mode in (hip.APPLY_FAST, hip.APPLY_EXACT):
+                    out = np.zeros(w * h, np.uint32)
+                    oi = hip.out_image(out.ctypes.data)
+                    mimg = hip.mono_image(gmap.ctypes.data, w // 4, h // 4)
+                    assert lib.uhdr_hip_apply_gainmap(C.byref(yi), C.byref(mimg), C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX, C.byref(oi), mode,
+                                                      hip.MEM_HOST, s) == 0
+                    outs[mode] = out
+                sdr = np.zeros(w * h * 3 // 2, np.uint8)
+                si = hip.yuv420_image(sdr.ctypes.data, w, h, hip.CG_UNSPECIFIED)
+                assert lib.uhdr_hip_tonemap(C.byref(pi), C.byref(si), hip.MEM_HOST, s) == 0
+                cv = yuv.copy()
+                ci = hip.yuv420_image(cv.ctypes.data, w, h, hip.CG_BT709)
+                assert lib.uhdr_hip_convert_yuv(C.byref(ci), hip.CG_BT709, hip.CG_P3, hip.MEM_HOST, s) == 0
+                results[(t, it)] = (p010, yuv, gmap.copy(), outs, sdr, cv, md.maxContentBoost)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(len(sizes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    from tests.gpu_util import diff_1010102
+    for (t, it), (p010, yuv, gmap, outs, sdr, cv, maxb) in results.items():
+        w, h = sizes[t]
+        st, omap, omd = orc.generate("orc_", orc.yuv420_image(yuv, w, h, 0), orc.p010_image(p010, w, h, 2), 1)
+        assert np.array_equal(gmap.reshape(omap.shape), omap)
+        st, ref, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, 0), omap, omd, orc.OUT_HDR_HLG, FLT_MAX)
+        assert np.array_equal(outs[hip.APPLY_EXACT], ref.view(np.uint32).ravel())
+        worst, frac, ok = diff_1010102(outs[hip.APPLY_FAST], ref.view(np.uint32).ravel())
+        assert ok and worst <= 1
+        olib = orc.load()
+        osdr = np.zeros(w * h * 3 // 2, np.uint8)
+        osrc, odst = orc.p010_image(p010, w, h, 2), orc.yuv420_image(osdr, w, h, -1)
+        assert olib.orc_toneMap(C.byref(osrc), C.byref(odst)) == 0
+        assert np.array_equal(sdr, osdr)
+        ocv = yuv.copy()
+        oimg = orc.yuv420_image(ocv, w, h, 0)
+        assert olib.orc_convertYuv(C.byref(oimg), 0, 1) == 0
+        assert np.array_equal(cv, ocv)

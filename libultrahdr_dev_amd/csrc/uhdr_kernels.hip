@@ -420,6 +420,13 @@ __device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
   *p = v;
 #endif
 }
+__device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
+#if UHDR_NT & 2
+  __builtin_nontemporal_store((u32x2){v.x, v.y}, reinterpret_cast<u32x2*>(p));
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
 __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *p; }
 
@@ -1056,30 +1063,6 @@ __device__ __forceinline__ f2 oetf2_scaled(f2 e) {
 
 struct PairOut { f2 r, g, b; };
 
-// two horizontally adjacent pixels sharing one chroma sample.  yraw: the two luma bytes as floats; crv2 / ngs2 / cbu2: the chroma
-// terms of this and the neighbouring pair, of which half HI is ours.  E: log2 of applyGain's factor / displayBoost -- times g, plus
-// 1, where a stage-2 table follows (launch_apply scales the constants).  With a stage-2 table the results are the bit patterns
-// 0xC0000000 | code (as floats).
-template <int FMT, bool MASK, int HI>
-__device__ __forceinline__ PairOut apply_pair(f2 yraw, f2 crv2, f2 ngs2, f2 cbu2, f2 E, uint32_t slot8, const char* lut) {
-  typedef ApplyTab<FMT, MASK> T;
-  // p3YuvToRgb (gainmapmath.cpp:198-202): y / 255 + chroma term in one packed fma, the clamp rides on it
-  const f2 r = pk_fma_sat_bc<HI>(yraw, splat(k255), crv2);
-  const f2 g = pk_fma_sat_bc<HI>(yraw, splat(k255), ngs2);
-  const f2 b = pk_fma_sat_bc<HI>(yraw, splat(k255), cbu2);
-  const f2 factor = exp2_2(E);  // applyGain's 2^(logBoost*displayBoost/max) / displayBoost  [^g, doubled]
-  const f2 lr = tab_eval2<0>(r, lut), lg = tab_eval2<0>(g, lut), lb = tab_eval2<0>(b, lut);
-  PairOut o;
-  if (T::kOetf) {   // (not reached: HLG / PQ output within [0, 1] runs apply_cell_piped)
-    o.r = lr; o.g = lg; o.b = lb;
-  } else {
-    o.r = oetf2_scaled<FMT>(lr * factor);
-    o.g = oetf2_scaled<FMT>(lg * factor);
-    o.b = oetf2_scaled<FMT>(lb * factor);
-  }
-  return o;
-}
-
 // inputs already *1023.  The reference's `& 0x3ff` (gainmapmath.cpp:723-725) can only bite when a channel
 // reaches 1024, i.e. when max_display_boost < maxContentBoost lets values exceed 1.0; MASK is a per-call
 // (wave-uniform) property, so the common case packs with two v_lshl_or_b32 and one v_or_b32.
@@ -1105,78 +1088,8 @@ __device__ __forceinline__ uint32_t pack10_bits(float r, float g, float b) {
 template <int K>
 __device__ __forceinline__ float cvt_byte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
 
-template <int FMT, bool INTERIOR, bool MASK>
-__device__ __forceinline__ void apply_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
-                                           const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
-                                           float m1, float m2, float m3, float m4, int tbl, uint32_t slot8, const char* lut) {
-  // chroma terms of the cell's 2x2 samples, one packed register per row of two: kCr * (V - 128) / 255 etc. as one fma each on the
-  // byte values (constants pre-multiplied; within an ulp of the reference's two-step rounding, which FAST mode does not promise)
-  constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
-  f2 crv2[2], ngs2[2], cbu2[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const f2 uf = (f2){cvt_byte<0>(uu[r]), cvt_byte<1>(uu[r])};
-    const f2 vf = (f2){cvt_byte<0>(vv[r]), cvt_byte<1>(vv[r])};
-    crv2[r] = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
-    cbu2[r] = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
-    ngs2[r] = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
-  }
-  // sampleMap (gainmapmath.cpp:705-719) folded into the exponent: the weights of a position sum to 1, so
-  // E = B + A/255 m1 + sum_k (m_k - m1) w_k A/255: three packed fmas per pixel pair
-  const float base = __builtin_fmaf(m1, c.fast.A255, c.fast.B);
-  const float d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
-  const float* wt = c_idw4 + tbl * 64;  // border cells only: per-lane table (gainmapmath.cpp:710-716)
-#pragma unroll
-  for (int oy = 0; oy < 4; ++oy) {
-    PairOut po[2];
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      f2 w1, w2, w3;
-      if (INTERIOR) {
-        w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}; w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
-        w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
-      } else {
-        const float* p0 = wt + oy * 16 + pr * 8;
-        w1 = (f2){p0[1], p0[5]} * splat(c.fast.A255); w2 = (f2){p0[2], p0[6]} * splat(c.fast.A255);
-        w3 = (f2){p0[3], p0[7]} * splat(c.fast.A255);
-      }
-      const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
-      const f2 yraw = pr ? (f2){cvt_byte<2>(yrow[oy]), cvt_byte<3>(yrow[oy])} : (f2){cvt_byte<0>(yrow[oy]), cvt_byte<1>(yrow[oy])};
-      po[pr] = pr ? apply_pair<FMT, MASK, 1>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, slot8, lut)
-                  : apply_pair<FMT, MASK, 0>(yraw, crv2[oy >> 1], ngs2[oy >> 1], cbu2[oy >> 1], E, slot8, lut);
-    }
-    const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
-    if (FMT == 2 || FMT == 3) {
-      uint4 o;
-      if (ApplyTab<FMT, MASK>::kOetf) {
-        o.x = pack10_bits(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_bits(po[0].r.y, po[0].g.y, po[0].b.y);
-        o.z = pack10_bits(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_bits(po[1].r.y, po[1].g.y, po[1].b.y);
-      } else {
-        o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
-        o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
-      }
-      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), o);
-    } else if (FMT == 1) {
-      const uint2 a = pack_f16_hw(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16_hw(po[0].r.y, po[0].g.y, po[0].b.y);
-      const uint2 cc = pack_f16_hw(po[1].r.x, po[1].g.x, po[1].b.x), d = pack_f16_hw(po[1].r.y, po[1].g.y, po[1].b.y);
-      uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
-      o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
-      o[1] = make_uint4(cc.x, cc.y, d.x, d.y);
-    } else {  // FMT == 4: planar R,G,B uint16 (ultrahdr.cpp:460-468)
-      const size_t plane = (size_t)c.width * c.height;
-      uint16_t* base16 = static_cast<uint16_t*>(im.dst);
-      const f2 ch[3][2] = {{po[0].r, po[1].r}, {po[0].g, po[1].g}, {po[0].b, po[1].b}};
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const uint32_t q0 = 0x3ffu & (uint32_t)ch[p][0].x, q1 = 0x3ffu & (uint32_t)ch[p][0].y;
-        const uint32_t q2 = 0x3ffu & (uint32_t)ch[p][1].x, q3 = 0x3ffu & (uint32_t)ch[p][1].y;
-        *reinterpret_cast<uint2*>(base16 + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
-      }
-    }
-  }
-}
-
-// The same cell for HLG / PQ output through both tables, as a software pipeline over its 8 pixel pairs.  A pair needs two LDS round
+// One map cell (4x4 pixels) for HLG / PQ output through both tables, as a software pipeline over its 8 pixel pairs (two
+// horizontally adjacent pixels share one chroma sample and run as one packed float2).  A pair needs two LDS round
 // trips (stage 1, stage 2), and the compiler, left alone, waits for each pair of reads right after issuing it (a SIMD's four waves
 // then spend 60 % of their time parked at s_waitcnt).  Here every iteration runs three stages of three different pairs,
 //   F(k):   E, factor, r g b of pair k, their cells; issues the 6 stage-1 reads of pair k
@@ -1271,6 +1184,117 @@ __device__ __forceinline__ void apply_cell_piped(const AppConsts& c, void* dst, 
   }
 }
 
+// The cell for the outputs without a stage-2 table (the two linear formats; HLG / PQ of a call whose values may exceed 1.0) in the
+// same manner, two stages: F(k) as above on the g = 1 table, B(k-1) = the 6 fmas on its entries, the factor, the special-function
+// OETF where there is one, the pack.
+constexpr uint32_t kXchSecond = 72;    // in uint4: the second halves start 1152 bytes into the wave's exchange area ...
+constexpr uint32_t kXchPerWave = 136;  // ... of 2176 bytes
+template <int FMT, bool INTERIOR, bool MASK>
+__device__ __forceinline__ void apply_cell_piped1(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
+                                                  const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
+                                                  float m1, float m2, float m3, float m4, int tbl, const char* lut, uint4* xch) {
+  constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
+  f2 crv2[2], ngs2[2], cbu2[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const f2 uf = (f2){cvt_byte<0>(uu[r]), cvt_byte<1>(uu[r])};
+    const f2 vf = (f2){cvt_byte<0>(vv[r]), cvt_byte<1>(vv[r])};
+    crv2[r] = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
+    cbu2[r] = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
+    ngs2[r] = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
+  }
+  const float a255 = c.fast.A255;
+  const float base = __builtin_fmaf(m1, a255, c.fast.B);
+  const float d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
+  const float* wt = c_idw4 + tbl * 64;
+  PairF pf[2];
+  PairOut po[2];
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    if (k < 8) {  // ---- F(k)
+      const int oy = k >> 1, pr = k & 1;
+      f2 w1, w2, w3;
+      if (INTERIOR) {
+        w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}; w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
+        w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
+      } else {
+        const float* p0 = wt + oy * 16 + pr * 8;
+        w1 = (f2){p0[1], p0[5]} * splat(a255); w2 = (f2){p0[2], p0[6]} * splat(a255); w3 = (f2){p0[3], p0[7]} * splat(a255);
+      }
+      PairF& f = pf[k & 1];
+      const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
+      const f2 yraw = pr ? (f2){cvt_byte<2>(yrow[oy]), cvt_byte<3>(yrow[oy])} : (f2){cvt_byte<0>(yrow[oy]), cvt_byte<1>(yrow[oy])};
+      if (pr) {
+        f.c[0] = pk_fma_sat_bc<1>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<1>(yraw, splat(k255), ngs2[oy >> 1]);
+        f.c[2] = pk_fma_sat_bc<1>(yraw, splat(k255), cbu2[oy >> 1]);
+      } else {
+        f.c[0] = pk_fma_sat_bc<0>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<0>(yraw, splat(k255), ngs2[oy >> 1]);
+        f.c[2] = pk_fma_sat_bc<0>(yraw, splat(k255), cbu2[oy >> 1]);
+      }
+      f.factor = exp2_2(E);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) tab_pair<0>(f.c[ch], lut, f.e[2 * ch], f.e[2 * ch + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k >= 1) {  // ---- B(k-1)
+      const int q = k - 1, oy = q >> 1, pr = q & 1;
+      PairF& f = pf[q & 1];
+      f2 lin[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        f2 t;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(f.e[2 * ch].y), "v"(f.c[ch].x), "v"(f.e[2 * ch].x));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(f.e[2 * ch + 1].y), "v"(f.c[ch].y), "v"(f.e[2 * ch + 1].x));
+        lin[ch] = oetf2_scaled<FMT>(t * f.factor);
+      }
+      po[pr].r = lin[0]; po[pr].g = lin[1]; po[pr].b = lin[2];
+      if (pr) {
+        const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
+        if (FMT == 2 || FMT == 3) {
+          uint4 o;
+          o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
+          o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
+          st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), o);
+        } else if (FMT == 1) {
+          const uint2 a = pack_f16_hw(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16_hw(po[0].r.y, po[0].g.y, po[0].b.y);
+          const uint2 cc = pack_f16_hw(po[1].r.x, po[1].g.x, po[1].b.x), d = pack_f16_hw(po[1].r.y, po[1].g.y, po[1].b.y);
+          if (xch != nullptr) {
+            // A lane's row is 32 bytes: stored as it stands, every store instruction would fill half of each line it touches
+            // (measured: 2.0 instead of 5.6 TB/s, scripts/ab/store_pattern).  The wave's 64 rows pass through LDS so that each of
+            // the two instructions writes 1 KiB contiguous: lane L stores half (L & 1) of the row of lane L / 2 (then of lane
+            // 32 + L / 2).  First halves at 16 L, second halves at 1152 + 16 L: no bank conflict either way.
+            xch[lane] = make_uint4(a.x, a.y, bb.x, bb.y);
+            xch[kXchSecond + lane] = make_uint4(cc.x, cc.y, d.x, d.y);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t from = (lane & 1u) * kXchSecond + (lane >> 1);
+            const uint4 s0 = xch[from], s1 = xch[from + 32u];
+            __builtin_amdgcn_wave_barrier();
+            uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + (uint32_t)__builtin_amdgcn_readfirstlane((int)pix0));
+            st_stream(o + lane, s0);
+            st_stream(o + 64u + lane, s1);
+          } else {
+            uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+            o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+            o[1] = make_uint4(cc.x, cc.y, d.x, d.y);
+          }
+        } else {  // FMT == 4: planar R,G,B uint16 (ultrahdr.cpp:460-468)
+          const size_t plane = (size_t)c.width * c.height;
+          uint16_t* base16 = static_cast<uint16_t*>(im.dst);
+          const f2 ch[3][2] = {{po[0].r, po[1].r}, {po[0].g, po[1].g}, {po[0].b, po[1].b}};
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const uint32_t q0 = 0x3ffu & (uint32_t)ch[p][0].x, q1 = 0x3ffu & (uint32_t)ch[p][0].y;
+            const uint32_t q2 = 0x3ffu & (uint32_t)ch[p][1].x, q3 = 0x3ffu & (uint32_t)ch[p][1].y;
+            st_stream(reinterpret_cast<uint2*>(base16 + p * plane + pix0), make_uint2(q0 | (q1 << 16), q2 | (q3 << 16)));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // the bytes of one map cell's 4x4 pixels: four luma words, two rows of two chroma samples per plane, the four sampleMap taps
 // (gainmapmath.cpp:690-703: the reference indexes the map with map->width).  The taps stay bytes: the / 255 of gainmapmath.cpp:632
 // is folded into the weights.  32-bit offsets (an image plane is < 4 GiB): one 64-bit add per address.
@@ -1310,6 +1334,7 @@ template <int FMT, bool MASK>
 __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_apply_s4(const AppConsts c, const AppBatch b) {
   typedef ApplyTab<FMT, MASK> T;
   __shared__ uint4 s_tab[T::kBytes / 16u];
+  __shared__ uint4 s_xch[FMT == 1 ? (UHDR_APPLY_BLOCK / 64) * kXchPerWave : 1];   // F16: the waves' exchange areas
   const AppImage& im = b.img[blockIdx.y];
   void* const dst = im.dst;
   const uint32_t total = c.map_w * c.map_h;
@@ -1372,10 +1397,14 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
   if (T::kOetf) {
     if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) apply_cell_piped<FMT, true>(c, dst, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, 0, slot8, lut);
     else apply_cell_piped<FMT, false>(c, dst, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, tbl, slot8, lut);
-  } else if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) {
-    apply_cell<FMT, true, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, 0, slot8, lut);
   } else {
-    apply_cell<FMT, false, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, tbl, slot8, lut);
+    // F16: a full wave on one row of cells stores through the exchange area (apply_cell_piped1)
+    uint4* xch = nullptr;
+    if (FMT == 1 && __builtin_amdgcn_ballot_w64(true) == ~0ull &&
+        __builtin_amdgcn_ballot_w64(cy != (uint32_t)__builtin_amdgcn_readfirstlane((int)cy)) == 0ull)
+      xch = s_xch + (threadIdx.x >> 6) * kXchPerWave;
+    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) apply_cell_piped1<FMT, true, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, 0, lut, xch);
+    else apply_cell_piped1<FMT, false, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, tbl, lut, xch);
   }
 #endif
   if (!more) return;

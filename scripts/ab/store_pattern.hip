@@ -53,6 +53,23 @@ template <int MODE> __global__ void __launch_bounds__(512) k_cells_mode(uint32_t
     for (int oy = 0; oy < 4; ++oy) st_mode<MODE>(reinterpret_cast<uint4*>(img + (4u * cy + oy) * W + 4u * cx), make_uint4(idx, oy, 2, 3));
   }
 }
+// F16 output of apply: 8 B per pixel, a cell row = 32 B per lane.  PAIR 0: the kernel's pattern, two 16 B stores per lane at a 32 B
+// stride (each instruction fills half of every line it touches); PAIR 1: each instruction writes 1 KiB contiguous per wave (what a
+// lane exchange in front of the stores would give)
+template <int PAIR> __global__ void __launch_bounds__(512) k_cells_f16(uint2* out, uint32_t cpt) {
+  uint2* img = out + (size_t)blockIdx.y * W * H;
+  const uint32_t total = MW * MH, lane = threadIdx.x & 63u;
+  for (uint32_t it = 0; it < cpt; ++it) {
+    const uint32_t idx = (blockIdx.x * cpt + it) * 512u + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t cy = idx / MW, cx = idx - cy * MW;
+    for (int oy = 0; oy < 4; ++oy) {
+      uint4* p = reinterpret_cast<uint4*>(img + (4u * cy + oy) * W + 4u * cx);
+      if (PAIR == 0) { st<true>(p, make_uint4(idx, oy, 2, 3)); st<true>(p + 1, make_uint4(idx, oy, 4, 5)); }
+      else { uint4* q = p - 2 * lane + lane; st<true>(q, make_uint4(idx, oy, 2, 3)); st<true>(q + 64, make_uint4(idx, oy, 4, 5)); }
+    }
+  }
+}
 // 2: thread = 4 pixels of one row (a wave = 1 KiB of one row), rows in order: the image written strictly linearly
 // 3: read pattern of apply (Y 4 x 4 B, U/V 2 x 2 B each, 4 map bytes), result folded into one rare store
 __global__ void __launch_bounds__(512) k_cells_read(const uint8_t* y, const uint8_t* u, const uint8_t* map, uint32_t* sink, uint32_t cpt, int mode) {
@@ -137,6 +154,14 @@ int main() {
     c[5] = timed([&] { hipLaunchKernelGGL(k_cells_mode<5>, grid, dim3(512), 0, 0, out, 32u); });
     c[6] = timed([&] { hipLaunchKernelGGL(k_cells_mode<6>, grid, dim3(512), 0, 0, out, 32u); });
     for (int m = 0; m < 7; ++m) printf("cells cpt 32 %-11s %.3f ms %.0f GB/s\n", names[m], c[m], gb / c[m] * 1e3);
+  }
+  {
+    uint2* o8; CK(hipMalloc(&o8, (size_t)N * W * H * 8));
+    const dim3 grid((MW * MH + 512 * 32 - 1) / (512 * 32), N);
+    const double gb8 = (double)N * W * H * 8 / 1e9;
+    t = timed([&] { hipLaunchKernelGGL(k_cells_f16<0>, grid, dim3(512), 0, 0, o8, 32u); }); printf("F16 cells, 2 x 16 B per lane at 32 B stride   %.3f ms %.0f GB/s\n", t, gb8 / t * 1e3);
+    t = timed([&] { hipLaunchKernelGGL(k_cells_f16<1>, grid, dim3(512), 0, 0, o8, 32u); }); printf("F16 cells, each store 1 KiB contiguous per wave %.3f ms %.0f GB/s\n", t, gb8 / t * 1e3);
+    CK(hipFree(o8));
   }
   {
     uint16_t *hy, *huv; CK(hipMalloc(&hy, (size_t)N * W * H * 2)); CK(hipMalloc(&huv, (size_t)N * W * H)); CK(hipMemset(hy, 1, (size_t)N * W * H * 2)); CK(hipMemset(huv, 1, (size_t)N * W * H));

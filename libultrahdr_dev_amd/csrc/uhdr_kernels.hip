@@ -1612,9 +1612,11 @@ __device__ __forceinline__ uint32_t est_cell(const AppConsts& c, const AppImage&
     } else if (FMT == 1) {
       const uint2 a = pack_f16_hw(o[0][0], o[0][1], o[0][2]), bb = pack_f16_hw(o[1][0], o[1][1], o[1][2]);
       const uint2 cc = pack_f16_hw(o[2][0], o[2][1], o[2][2]), d = pack_f16_hw(o[3][0], o[3][1], o[3][2]);
+      // (plain stores: a lane's 32 bytes leave as two instructions, each filling half of every line it touches -- L2 merges them,
+      // a non-temporal store would send the halves on their own)
       uint4* dst = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
-      st_stream(dst, make_uint4(a.x, a.y, bb.x, bb.y));
-      st_stream(dst + 1, make_uint4(cc.x, cc.y, d.x, d.y));
+      dst[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+      dst[1] = make_uint4(cc.x, cc.y, d.x, d.y);
     } else {
       const size_t plane = (size_t)c.width * c.height;
       uint16_t* base16 = static_cast<uint16_t*>(im.dst);

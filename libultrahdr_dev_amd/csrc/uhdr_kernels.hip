@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "uhdr_device_math.h"
 #include "uhdr_wave_scan.h"
 
@@ -1800,9 +1802,12 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     while (cpt > 1u && blocks(cpt) < 448u) cpt >>= 1;   // (a single 4K image: 507 blocks of 2 cells per thread, all resident at once)
     cc.cells_per_thread = cpt;
     const dim3 grid((unsigned)((total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt)), n);
-    // channels can only reach 1024 (and wrap through the reference's & 0x3ff) when the display boost is
-    // capped below the content boost
-    if (c.display_boost < c.max_boost) hipLaunchKernelGGL((k_apply_s4<FMT, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
+    // Channels can only exceed 1.0 (reach code 1024 and wrap through the reference's & 0x3ff; leave the stage-2 table) when the
+    // display boost is capped below the content boost -- and then only if the largest factor the call can produce,
+    // max(minBoost, maxBoost)^(display / max) / display, is above 1: a display boost of 2 under a content boost of 4.9 stays
+    // below (0.955), a display boost of 1 does not (1.38).
+    const double top = std::exp2(std::fmax(c.log2_min_d, c.log2_max_d) * (double)c.display_boost / (double)c.max_boost) / (double)c.display_boost;
+    if (c.display_boost < c.max_boost && top > 1.0 + 1e-6) hipLaunchKernelGGL((k_apply_s4<FMT, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
     else {
       if (ApplyTab<FMT, false>::kOetf) {
         // u = T(c) * 2^(g E), handed to stage 2 as 2 + 2u: the exponent's constants times g (1/2 for HLG: sqrt; m1 for PQ), plus 1

@@ -96,3 +96,37 @@ def test_stage2_code_table_for_every_float_in_0_1(hip, fn, code, name):
     print("%s stage 2: %d of %d floats give another code (%.2e), worst %d, farthest from an integer %.4f"
           % (name, ndiff, total, ndiff / total, worst, far))
     assert worst <= 1 and far <= 0.06, (worst, far)
+
+
+@pytest.mark.parametrize("fmt", [2, 3])
+def test_capped_display_boost_on_either_side_of_1(hip, orc, fmt):
+    """max_display_boost < maxContentBoost: the table path serves the call as long as the largest factor it can produce,
+    maxBoost^(display / max) / display, stays at or below 1 (launch_apply_t); above, channels pass 1.0, wrap through the reference's
+    & 0x3ff and the special-function form runs.  For maxContentBoost 4.926 the two meet at a display boost of ~1.78: white pixels
+    under gain 1 sit exactly on that maximum, on both sides of it"""
+    from tests.gpu_util import gpu_apply, to_dev, diff_1010102
+    from tests.test_gpu_parity import _oracle_apply
+    lib = hip.load()
+    w, h = 256, 64
+    _, yuv = orc.lcg_frame(w, h, 21)
+    yuv = yuv.copy()
+    yuv[: w * 16] = 255                                   # 16 white rows ...
+    yuv[w * h: w * h + (w // 2) * 4] = 128                # ... with neutral chroma
+    yuv[w * h + (w // 2) * (h // 2): w * h + (w // 2) * (h // 2) + (w // 2) * 4] = 128
+    gmap = np.random.RandomState(5).randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    gmap[:6] = 255
+    maxb = np.float32(1000.0 / 203.0)
+    dy, dmap = to_dev(yuv), to_dev(gmap)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    md = hip.metadata(maxb)
+    for boost in (1.0, 1.3, 1.7, 1.77, 1.78, 1.785, 1.79, 1.8, 1.9, 2.5, 4.0, 4.9):
+        ref = _oracle_apply(orc, yuv, w, h, gmap, maxb, fmt, boost)
+        st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, boost, hip.APPLY_FAST)
+        assert st == 0
+        worst, frac, ok = diff_1010102(fast.view(np.uint32), ref.view(np.uint32), wrap=True)
+        assert ok and worst <= 1, (boost, worst)
+        # and without the wrap allowance wherever the reference itself stays below 1024: no channel may differ by more than 1
+        top = float(maxb) ** (boost / float(maxb)) / boost
+        if top <= 1.0:
+            worst, frac, ok = diff_1010102(fast.view(np.uint32), ref.view(np.uint32), wrap=False)
+            assert worst <= 1, (boost, worst)

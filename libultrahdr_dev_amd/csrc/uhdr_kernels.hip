@@ -1991,18 +1991,30 @@ __device__ __forceinline__ uint32_t round_u8(float x) {  // (uint8_t)CLIP3(x, 0,
   x = (x < 0.0f) ? 0.0f : (x > 255.0f) ? 255.0f : x;
   return (uint32_t)x;
 }
-// one 2x2 block; y00..y11 luma bytes, ub/vb chroma bytes
+// one 2x2 block; y00..y11 luma bytes, ub/vb chroma bytes.  The kernel is bound by VALU issue, not by its 3 bytes per pixel, so
+// the four pixels run as two packed pairs: every float operation below is the reference's own (the products and sums of its yuvXToY
+// matrices in their order, gainmapmath.cpp:447-481; the chroma average and the +0.5 / CLIP3 of transformYuv420, :483-520), two at a
+// time; the products of the block's single (u, v) with the matrix are formed once.
 __device__ __forceinline__ void cvt_block(const float (&m)[9], uint32_t (&yb)[4], uint32_t& ub, uint32_t& vb) {
   const float u = (float)((int)ub - 128) * k255, v = (float)((int)vb - 128) * k255;
-  Yuv p[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) p[i] = yuv_mat(m, (float)yb[i] * k255, u, v);
-  const float nu = (((p[0].u + p[1].u) + p[2].u) + p[3].u) / 4.0f;
-  const float nv = (((p[0].v + p[1].v) + p[2].v) + p[3].v) / 4.0f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) yb[i] = round_u8(p[i].y * 255.0f + 0.5f);
-  ub = round_u8(nu * 255.0f + 128.0f + 0.5f);
-  vb = round_u8(nv * 255.0f + 128.0f + 0.5f);
+  const f2 y01 = (f2){(float)yb[0], (float)yb[1]} * splat(k255), y23 = (f2){(float)yb[2], (float)yb[3]} * splat(k255);
+  const float yu = m[1] * u, yv = m[2] * v, uu = m[4] * u, uv = m[5] * v, vu = m[7] * u, vv = m[8] * v;
+  const f2 py01 = (splat(m[0]) * y01 + splat(yu)) + splat(yv), py23 = (splat(m[0]) * y23 + splat(yu)) + splat(yv);
+  const f2 pu01 = (splat(m[3]) * y01 + splat(uu)) + splat(uv), pu23 = (splat(m[3]) * y23 + splat(uu)) + splat(uv);
+  const f2 pv01 = (splat(m[6]) * y01 + splat(vu)) + splat(vv), pv23 = (splat(m[6]) * y23 + splat(vu)) + splat(vv);
+  // (((p0 + p1) + p2) + p3) / 4 for u and v side by side
+  f2 c = (f2){pu01.x, pv01.x} + (f2){pu01.y, pv01.y};
+  c = c + (f2){pu23.x, pv23.x};
+  c = c + (f2){pu23.y, pv23.y};
+  c = c * splat(0.25f);                                    // == / 4.0f
+  c = (c * splat(255.0f) + splat(128.0f)) + splat(0.5f);
+  const f2 o01 = py01 * splat(255.0f) + splat(0.5f), o23 = py23 * splat(255.0f) + splat(0.5f);
+  // (uint8_t)CLIP3(x, 0, 255): one v_med3_f32 (the same value as the reference's compare chain for every x but NaN, which
+  // bytes times a finite matrix cannot produce) and a truncating conversion
+  yb[0] = (uint32_t)__builtin_amdgcn_fmed3f(o01.x, 0.0f, 255.0f); yb[1] = (uint32_t)__builtin_amdgcn_fmed3f(o01.y, 0.0f, 255.0f);
+  yb[2] = (uint32_t)__builtin_amdgcn_fmed3f(o23.x, 0.0f, 255.0f); yb[3] = (uint32_t)__builtin_amdgcn_fmed3f(o23.y, 0.0f, 255.0f);
+  ub = (uint32_t)__builtin_amdgcn_fmed3f(c.x, 0.0f, 255.0f);
+  vb = (uint32_t)__builtin_amdgcn_fmed3f(c.y, 0.0f, 255.0f);
 }
 
 template <bool ALIGNED>

@@ -405,6 +405,11 @@ int uhdr_hip_gain_lut(const uhdr_hip_metadata_t* metadata, int with_display_boos
 int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float min_boost, float max_boost,
                            void* stream);
 
+/* Bench / test support: the deterministic synthetic frame pair of SURVEY.md 8(d) (an LCG; tests/ and bench.py compare it with the
+ * oracle's serial loop), written into device memory: p010 = width*height*3/2 uint16 (luma, then interleaved UV, values in the
+ * legal 10-bit ranges << 6), yuv = width*height*3/2 bytes (Y, U, V).  width and height even; enqueued on `stream`. */
+int uhdr_hip_synth_lcg_frame(size_t width, size_t height, unsigned int seed, void* p010, void* yuv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

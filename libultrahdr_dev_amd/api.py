@@ -104,6 +104,7 @@ SIGNATURES = {
     "uhdr_hip_gain_lut": (C.c_int, [_MP, C.c_int, C.c_float, C.POINTER(C.c_float)]),
     "uhdr_hip_idw_tables": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "uhdr_hip_eval_transfer": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]),
+    "uhdr_hip_synth_lcg_frame": (C.c_int, [C.c_size_t, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -648,6 +648,19 @@ int uhdr_hip_shutdown(void) {
   return UHDR_HIP_NO_ERROR;
 }
 
+int uhdr_hip_synth_lcg_frame(size_t width, size_t height, unsigned int seed, void* p010, void* yuv, void* stream) {
+  if (p010 == nullptr || yuv == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  if ((width | height) & 1u) return UHDR_HIP_ERROR_UNSUPPORTED_WIDTH_HEIGHT;
+  const uint64_t n_luma = (uint64_t)width * height, n = n_luma + n_luma / 2u;
+  if (n >= (1ull << 31)) return UHDR_HIP_ERROR_UNSUPPORTED_WIDTH_HEIGHT;   // state indices 2 i + 2 stay below 2^32
+  DeviceState* st = nullptr;
+  const int rc = current_state(&st);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  HIP_TRY(launch_synth_lcg(static_cast<uint16_t*>(p010), static_cast<uint8_t*>(yuv), (uint32_t)n_luma, (uint32_t)n, seed,
+                           static_cast<hipStream_t>(stream)));
+  return UHDR_HIP_NO_ERROR;
+}
+
 int uhdr_hip_eval_transfer(int fn, const float* in, float* out, size_t n, float min_boost, float max_boost,
                            void* stream) {
   if (in == nullptr || out == nullptr) return UHDR_HIP_ERROR_BAD_PTR;

@@ -202,5 +202,6 @@ hipError_t launch_ycc420_to_rgba(const uint8_t* y, const uint8_t* cb, const uint
 hipError_t upload_idw4(const float* tables /* 4*64 floats */);
 hipError_t launch_effect(const FxJobs& j, hipStream_t s);
 hipError_t launch_eval_transfer(int fn, const float* in, float* out, size_t n, const EvalConsts& ec, hipStream_t s);
+hipError_t launch_synth_lcg(uint16_t* p010, uint8_t* yuv, uint32_t n_luma, uint32_t n, uint32_t seed, hipStream_t s);
 
 }  // namespace uhdr

@@ -2229,6 +2229,32 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
   out[i] = y;
 }
 
+// The deterministic frame pair of SURVEY.md section 8(d), written straight into HBM: s <- s * 1664525 + 1013904223 (mod 2^32),
+// draw = s >> 8, draws alternating between the P010 word and the 8-bit sample of element i.  Thread i jumps to state 2 i + 1 by
+// composing the affine map with itself (binary exponentiation on (a, c)), so the elements are independent.
+__global__ void __launch_bounds__(256) k_synth_lcg(uint16_t* p010, uint8_t* yuv, uint32_t n_luma, uint32_t n, uint32_t seed) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint32_t ar = 1u, cr = 0u, ap = 1664525u, cp = 1013904223u;
+  for (uint32_t k = 2u * i + 1u; k != 0u; k >>= 1) {
+    if (k & 1u) { ar *= ap; cr = cr * ap + cp; }
+    cp = cp * ap + cp;
+    ap *= ap;
+  }
+  const uint32_t s1 = ar * seed + cr, s2 = s1 * 1664525u + 1013904223u;
+  // Both remainders by constant divisors (multiply-high forms).  With a divisor chosen at run time hipcc, knowing the draw to be
+  // below 2^24, expands the division through v_rcp_iflag_f32 + one upward correction, which returns quotient + 1 where the true
+  // quotient lies within 2^-23 below an integer (15172754 / 897 = 16914.9989 -> 16915: 18 wrong words in a 640x480 frame).
+  const uint32_t d = s1 >> 8, r = i < n_luma ? d % 877u : d % 897u;
+  p010[i] = (uint16_t)((64u + r) << 6);
+  yuv[i] = (uint8_t)(s2 >> 8);
+}
+hipError_t launch_synth_lcg(uint16_t* p010, uint8_t* yuv, uint32_t n_luma, uint32_t n, uint32_t seed, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_synth_lcg, dim3((n + 255u) / 256u), dim3(256), 0, s, p010, yuv, n_luma, n, seed);
+  return hipGetLastError();
+}
+
 hipError_t launch_eval_transfer(int fn, const float* in, float* out, size_t n, const EvalConsts& ec, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(k_eval_transfer, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, in, out, n, ec);

@@ -27,8 +27,30 @@ def _lcg_states(seed, k):
     return (ar * (seed & _MASK) + cr) & _MASK
 
 
-def lcg_frame(w, h, seed, device="cuda"):
-    """-> (p010_bytes uint8[w*h*3], yuv uint8[w*h*3/2]) on `device`; p010 is little-endian uint16"""
+def lcg_frame(w, h, seed, device="cuda", out=None):
+    """-> (p010_bytes uint8[w*h*3], yuv uint8[w*h*3/2]) on `device`; p010 is little-endian uint16.  On a GPU the frame is written
+    by the library's own kernel (uhdr_hip_synth_lcg_frame); the torch form below serves CPU tensors (and is what the CPU tests
+    compare with the oracle's serial loop)."""
+    import os
+    if str(device).startswith("cuda") and not os.environ.get("UHDR_SYNTH_TORCH"):
+        import ctypes as C
+
+        from . import api
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        lib = api.init(idx)
+        with torch.cuda.device(idx):
+            if out is not None:   # (uint8 tensors of w*h*3 and w*h*3/2 bytes the caller placed)
+                p010, yuv = out
+                assert p010.numel() == w * h * 3 and yuv.numel() == w * h * 3 // 2 and p010.is_contiguous() and yuv.is_contiguous()
+            else:
+                p010 = torch.empty(w * h * 3, dtype=torch.uint8, device=dev)
+                yuv = torch.empty(w * h * 3 // 2, dtype=torch.uint8, device=dev)
+            rc = lib.uhdr_hip_synth_lcg_frame(w, h, seed & _MASK, C.c_void_p(p010.data_ptr()), C.c_void_p(yuv.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError("uhdr_hip_synth_lcg_frame failed: %d" % rc)
+        return p010, yuv
     n_l, n_c = w * h, w * h // 2
     n = n_l + n_c
     i = torch.arange(n, dtype=torch.int64, device=device)
@@ -38,6 +60,10 @@ def lcg_frame(w, h, seed, device="cuda"):
     p = ((64 + d_p % mod) << 6).to(torch.int32)
     p010 = torch.stack([(p & 0xFF).to(torch.uint8), (p >> 8).to(torch.uint8)], dim=1).reshape(-1)
     yuv = (d_y & 255).to(torch.uint8)
+    if out is not None:
+        out[0].copy_(p010)
+        out[1].copy_(yuv)
+        return out
     return p010.contiguous(), yuv.contiguous()
 
 

@@ -267,12 +267,12 @@ def other_configs(lib, stream):
         assert lib.uhdr_hip_apply_gainmap(C.byref(hyi), C.byref(hmi), C.byref(hmd), api.OUTPUT_HDR_HLG, api.FLT_MAX, C.byref(hoi),
                                           api.APPLY_FAST, api.MEM_HOST, None) == 0
 
-    for _ in range(2):
+    for _ in range(3):
         host_pair()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(15):
         host_pair()
-    ms = (time.perf_counter() - t0) / 5 * 1e3
+    ms = (time.perf_counter() - t0) / 15 * 1e3
     out["host-staged 4K pair (UHDR_HIP_MEM_HOST, pageable memory, PCIe both ways)"] = {
         "ms": round(ms, 3), "MPix/s": round(W * H / 1e6 / (ms * 1e-3), 1)}
     # editorhelper effects on one 4K YUV420 frame: byte gathers, read + write 12.4 MB each

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=/tmp/ktimes_$$
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-configs "$@" > $OUT/log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 6 --warmup 2 --ramp-ms 0 --no-cpu-baseline --no-other-configs "$@" > $OUT/log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):

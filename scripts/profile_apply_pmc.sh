@@ -5,7 +5,7 @@ TAG=${1:-run}
 OUT=/tmp/pmc_apply_$TAG
 rm -rf $OUT; mkdir -p $OUT $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs"
+ARGS="$R/bench.py --steps 4 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-other-configs"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT --output-format csv -d $OUT/b -- python3 $ARGS > $OUT/b.log 2>&1
 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/c -- python3 $ARGS > $OUT/c.log 2>&1

@@ -81,12 +81,18 @@ extern "C" {
 #define UHDR_HIP_ERROR_UNSUPPORTED_MAP_SCALE_FACTOR (-20008)
 #define UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE (-20009)
 
+/* where the planes of a call live.  DEVICE: the call only enqueues kernels on `stream` (asynchronous, graph-capturable).  HOST
+ * (what a caller of the reference binds): the call copies the planes in, runs, copies the result out and returns when it is there.
+ * Threads: every entry point may be called from several host threads.  Device-memory calls on different streams overlap; the
+ * host-memory forms of generate / apply / tonemap / convert_yuv lease a staging set per call, so callers on their own streams
+ * overlap their copies and kernels as well (one thread moves 0.54, eight 0.94 4K pairs per ms over the host link); the codec entry
+ * points (jpeg_*, jpegr_*) serialise on the device's codec workspace. */
 #define UHDR_HIP_MEM_HOST 0
 #define UHDR_HIP_MEM_DEVICE 1
 
 /* arithmetic mode of uhdr_hip_apply_gainmap*:
- *   FAST  : float transcendentals on the CDNA4 special-function unit; every 10-bit channel within
- *           1 LSB and every F16 channel within 1 half-ULP of the reference CPU path;
+ *   FAST  : transfer functions from line-segment tables in LDS (special-function unit where a call can exceed 1.0); every
+ *           10-bit channel within 1 LSB and every F16 channel within 1 half-ULP of the reference CPU path;
  *   EXACT : the same bytes as the reference CPU path: its float/double promotion pattern replayed with correctly
  *           rounded pow/exp/log/exp2, on the pixels an f32 estimate cannot settle (HDR_PQ: on every pixel).
  * generate/tonemap/convert_yuv have a single, bit-exact mode. */

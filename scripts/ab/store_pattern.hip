@@ -25,6 +25,55 @@ template <bool NT> __global__ void __launch_bounds__(512) k_cells(uint32_t* out,
     for (int oy = 0; oy < 4; ++oy) st<NT>(reinterpret_cast<uint4*>(img + (4u * cy + oy) * W + 4u * cx), make_uint4(idx, oy, 2, 3));
   }
 }
+// apply's pattern with a chip-wide stride: G long-lived blocks, block b takes the 512-cell chunks b, b + G, b + 2G, ... of the whole
+// batch (image-major), so that the chunks in flight at any time are neighbours -- what short-lived blocks get for free
+template <bool NT> __global__ void __launch_bounds__(512) k_cells_chip(uint32_t* out) {
+  const uint32_t per_img = (MW * MH + 511u) / 512u, total = per_img * N;
+  for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+    const uint32_t im = id / per_img, idx = (id - im * per_img) * 512u + threadIdx.x;
+    if (idx >= MW * MH) continue;
+    uint32_t* img = out + (size_t)im * W * H;
+    const uint32_t cy = idx / MW, cx = idx - cy * MW;
+    for (int oy = 0; oy < 4; ++oy) st<NT>(reinterpret_cast<uint4*>(img + (4u * cy + oy) * W + 4u * cx), make_uint4(idx, oy, 2, 3));
+  }
+}
+// the same with a thread per cell ROW (a wave = 1 KiB of one image row, 16 waves = a row and a bit): blocks of 1024, chip-wide stride
+template <bool NT> __global__ void __launch_bounds__(1024) k_rows_chip(uint32_t* out) {
+  const uint32_t per_row = W / 4u, per_img = (per_row * H + 1023u) / 1024u, total = per_img * N;
+  for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+    const uint32_t im = id / per_img, idx = (id - im * per_img) * 1024u + threadIdx.x;
+    if (idx >= per_row * H) continue;
+    st<NT>(reinterpret_cast<uint4*>(out + (size_t)im * W * H) + idx, make_uint4(idx, 1, 2, 3));
+  }
+}
+// long-lived blocks that take the next chunk of U x 4 KiB from one counter when they are ready for it (in-flight chunks stay
+// neighbours whatever the blocks' speeds); SCOPE 0: device-scope atomic, 1: workgroup-scope (executes in the XCD's L2 -- not a
+// correct queue across XCDs, timing only)
+template <int U, int SCOPE> __global__ void __launch_bounds__(256) k_fill_dyn(uint4* out, size_t n16, uint32_t* counter) {
+  __shared__ uint32_t s_id;
+  const uint32_t chunks = (uint32_t)((n16 + 256u * U - 1) / (256u * U));
+  for (;;) {
+    if (threadIdx.x == 0)
+      s_id = SCOPE == 0 ? atomicAdd(counter, 1u) : __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const uint32_t id = s_id;
+    __syncthreads();
+    if (id >= chunks) return;
+    const size_t base = (size_t)id * U * 256u + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < U; ++j) { const size_t i = base + (size_t)j * 256u; if (i < n16) st<false>(out + i, make_uint4((uint32_t)i, 1, 2, 3)); }
+  }
+}
+// linear order, long-lived blocks, at most K stores of a wave in flight (s_waitcnt vmcnt): does the depth of a wave's store queue
+// -- how far a fast wave runs ahead of its neighbours -- decide the rate?
+template <int K> __global__ void __launch_bounds__(256) k_rows_wait(uint4* out, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) {
+    st<false>(out + i, make_uint4((uint32_t)i, 1, 2, 3));
+    if (K == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (K == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  }
+}
 // block-contiguous linear fill: each block writes one chunk of `per` x 8 KiB, U stores in flight per thread
 template <int MODE> __device__ __forceinline__ void st_mode(uint4* p, uint4 vv) {
   const u32x4 v = {vv.x, vv.y, vv.z, vv.w};
@@ -51,6 +100,16 @@ template <int MODE> __global__ void __launch_bounds__(512) k_cells_mode(uint32_t
     if (idx >= total) return;
     const uint32_t cy = idx / MW, cx = idx - cy * MW;
     for (int oy = 0; oy < 4; ++oy) st_mode<MODE>(reinterpret_cast<uint4*>(img + (4u * cy + oy) * W + 4u * cx), make_uint4(idx, oy, 2, 3));
+  }
+}
+// torch's fill reaches 6.9 TB/s on this chip where every pattern above stops at 5.6: what is different?  BLOCK threads, each
+// thread writes U consecutive-by-block 16 B words (word j of thread t at (blk * U + j) * BLOCK + t); CONST: every word the same
+template <int BLOCK, int U, bool CONST, bool NT> __global__ void __launch_bounds__(BLOCK) k_fill(uint4* out, size_t n16) {
+  const size_t base = (size_t)blockIdx.x * U * BLOCK + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < U; ++j) {
+    const size_t i = base + (size_t)j * BLOCK;
+    if (i < n16) st<NT>(out + i, CONST ? make_uint4(0x40000000u, 0x40000000u, 0x40000000u, 0x40000000u) : make_uint4((uint32_t)i, 1, 2, 3));
   }
 }
 // F16 output of apply: 8 B per pixel, a cell row = 32 B per lane.  PAIR 0: the kernel's pattern, two 16 B stores per lane at a 32 B
@@ -119,6 +178,10 @@ template <class F> float timed(F f) {
   hipEventRecord(a); for (int i = 0; i < 20; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); return ms / 20;
 }
+template <int BLOCK, int U, bool CONST, bool NT> float run_fill(uint4* out, size_t n16) {
+  const unsigned grid = (unsigned)((n16 + (size_t)BLOCK * U - 1) / ((size_t)BLOCK * U));
+  return timed([&] { hipLaunchKernelGGL((k_fill<BLOCK, U, CONST, NT>), dim3(grid), dim3(BLOCK), 0, 0, out, n16); });
+}
 int main() {
   const size_t obytes = (size_t)N * W * H * 4;
   uint32_t* out; CK(hipMalloc(&out, obytes));
@@ -126,6 +189,19 @@ int main() {
   CK(hipMemset(y, 1, (size_t)N * W * H)); CK(hipMemset(u, 2, (size_t)N * W * H / 2)); CK(hipMemset(map, 3, (size_t)N * MW * MH));
   const double gb = obytes / 1e9, rgb = ((double)N * W * H * 1.5 + (double)N * MW * MH) / 1e9;
   float t;
+  {
+    const size_t n16 = obytes / 16;
+    printf("fill  64 thr x 4, varying, plain  %.0f GB/s\n", gb / run_fill<64, 4, false, false>((uint4*)out, n16) * 1e3);
+    printf("fill 128 thr x 4, varying, plain  %.0f GB/s\n", gb / run_fill<128, 4, false, false>((uint4*)out, n16) * 1e3);
+    printf("fill 256 thr x 1, varying, plain  %.0f GB/s\n", gb / run_fill<256, 1, false, false>((uint4*)out, n16) * 1e3);
+    printf("fill 256 thr x 4, varying, plain  %.0f GB/s\n", gb / run_fill<256, 4, false, false>((uint4*)out, n16) * 1e3);
+    printf("fill 256 thr x 4, constant, plain %.0f GB/s\n", gb / run_fill<256, 4, true, false>((uint4*)out, n16) * 1e3);
+    printf("fill 256 thr x 4, varying, nt     %.0f GB/s\n", gb / run_fill<256, 4, false, true>((uint4*)out, n16) * 1e3);
+    printf("fill 256 thr x 4, constant, nt    %.0f GB/s\n", gb / run_fill<256, 4, true, true>((uint4*)out, n16) * 1e3);
+    printf("fill 256 thr x 16, varying, plain %.0f GB/s\n", gb / run_fill<256, 16, false, false>((uint4*)out, n16) * 1e3);
+    printf("fill 512 thr x 8, varying, plain  %.0f GB/s\n", gb / run_fill<512, 8, false, false>((uint4*)out, n16) * 1e3);
+    printf("fill 1024 thr x 4, varying, plain %.0f GB/s\n", gb / run_fill<1024, 4, false, false>((uint4*)out, n16) * 1e3);
+  }
   t = timed([&] { hipLaunchKernelGGL(k_linear<true>, dim3(2048), dim3(512), 0, 0, (uint4*)out, obytes / 16); }); printf("linear nt, 2048 blocks          %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
   t = timed([&] { hipLaunchKernelGGL(k_linear<false>, dim3(2048), dim3(512), 0, 0, (uint4*)out, obytes / 16); }); printf("linear plain, 2048 blocks       %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
   t = timed([&] { hipLaunchKernelGGL(k_linear<true>, dim3(512), dim3(512), 0, 0, (uint4*)out, obytes / 16); }); printf("linear nt, 512 blocks           %.3f ms %.0f GB/s\n", t, gb / t * 1e3);
@@ -178,11 +254,42 @@ int main() {
         printf("generate reads plain, block 256, tiles %2u, %s  %.3f ms %.0f GB/s\n", tiles, im ? "image-major" : "interleaved", t, ggb / t * 1e3);
       }
   }
-  for (uint32_t cpt : {32u})
+  {
+    uint32_t* ctr; CK(hipMalloc(&ctr, 4));
+    const size_t n16 = obytes / 16;
+    for (unsigned g : {1024u, 2048u}) {
+      t = timed([&] { hipMemsetAsync(ctr, 0, 4, 0); hipLaunchKernelGGL((k_fill_dyn<4, 0>), dim3(g), dim3(256), 0, 0, (uint4*)out, n16, ctr); });
+      printf("fill, chunks of 16 KiB from a counter (device scope), %u blocks  %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+      t = timed([&] { hipMemsetAsync(ctr, 0, 4, 0); hipLaunchKernelGGL((k_fill_dyn<16, 0>), dim3(g), dim3(256), 0, 0, (uint4*)out, n16, ctr); });
+      printf("fill, chunks of 64 KiB from a counter (device scope), %u blocks  %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+      t = timed([&] { hipMemsetAsync(ctr, 0, 4, 0); hipLaunchKernelGGL((k_fill_dyn<4, 1>), dim3(g), dim3(256), 0, 0, (uint4*)out, n16, ctr); });
+      printf("fill, chunks of 16 KiB from a counter (L2 scope), %u blocks      %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+    }
+  }
+  for (unsigned g : {2048u, 4096u, 8192u}) {
+    const size_t n16 = obytes / 16;
+    t = timed([&] { hipLaunchKernelGGL(k_rows_wait<0>, dim3(g), dim3(256), 0, 0, (uint4*)out, n16); }); printf("linear loop, %u blocks, vmcnt(0) after each store  %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+    t = timed([&] { hipLaunchKernelGGL(k_rows_wait<1>, dim3(g), dim3(256), 0, 0, (uint4*)out, n16); }); printf("linear loop, %u blocks, vmcnt(1)                   %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+    t = timed([&] { hipLaunchKernelGGL(k_rows_wait<3>, dim3(g), dim3(256), 0, 0, (uint4*)out, n16); }); printf("linear loop, %u blocks, vmcnt(3)                   %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+    t = timed([&] { hipLaunchKernelGGL(k_rows_wait<99>, dim3(g), dim3(256), 0, 0, (uint4*)out, n16); }); printf("linear loop, %u blocks, no wait                    %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+  }
+  for (unsigned g : {256u, 512u, 1024u, 2048u, 4096u}) {
+    t = timed([&] { hipLaunchKernelGGL(k_cells_chip<true>, dim3(g), dim3(512), 0, 0, out); });
+    printf("cells, chip-wide stride, %4u blocks, nt    %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+    t = timed([&] { hipLaunchKernelGGL(k_cells_chip<false>, dim3(g), dim3(512), 0, 0, out); });
+    printf("cells, chip-wide stride, %4u blocks, plain %.3f ms %.0f GB/s\n", g, t, gb / t * 1e3);
+    t = timed([&] { hipLaunchKernelGGL(k_rows_chip<true>, dim3(g / 2), dim3(1024), 0, 0, out); });
+    printf("rows,  chip-wide stride, %4u blocks of 1024, nt    %.3f ms %.0f GB/s\n", g / 2, t, gb / t * 1e3);
+    t = timed([&] { hipLaunchKernelGGL(k_rows_chip<false>, dim3(g / 2), dim3(1024), 0, 0, out); });
+    printf("rows,  chip-wide stride, %4u blocks of 1024, plain %.3f ms %.0f GB/s\n", g / 2, t, gb / t * 1e3);
+  }
+  for (uint32_t cpt : {1u, 2u, 4u, 8u, 32u})
     for (int mode = 0; mode < 2; ++mode) {
       const dim3 grid((MW * MH + 512 * cpt - 1) / (512 * cpt), N);
       t = timed([&] { hipLaunchKernelGGL(k_cells<true>, grid, dim3(512), 0, 0, out, cpt, mode); });
       printf("cells nt, cpt %3u, %s   %.3f ms %.0f GB/s\n", cpt, mode ? "grid-stride " : "block-chunks", t, gb / t * 1e3);
+      t = timed([&] { hipLaunchKernelGGL(k_cells<false>, grid, dim3(512), 0, 0, out, cpt, mode); });
+      printf("cells plain, cpt %3u, %s   %.3f ms %.0f GB/s\n", cpt, mode ? "grid-stride " : "block-chunks", t, gb / t * 1e3);
       t = timed([&] { hipLaunchKernelGGL(k_cells_read, grid, dim3(512), 0, 0, y, u, map, out, cpt, mode); });
       printf("cells read, cpt %3u, %s %.3f ms %.0f GB/s\n", cpt, mode ? "grid-stride " : "block-chunks", t, rgb / t * 1e3);
     }

@@ -334,11 +334,12 @@ void f16_cell(uint32_t j, double* lo, double* hi) {
   *lo = std::ldexp(1.0 + m / 128.0, (int)e - 15);
   *hi = std::ldexp(1.0 + (m + 1u) / 128.0, (int)e - 15);
 }
-// ... and for g < 1 the arguments whose own bits 30..19 are j: e = j >> 4, m = j & 15: [2^(e-127) (1 + m/16), 2^(e-127) (1 + (m+1)/16))
-// for e >= 1, the subnormal slots [m, m+1) 2^-130 for e = 0.
+// ... and for g < 1 cell j = (e & 31) << 4 | m with e the biased exponent and m the top four mantissa bits:
+// [2^(e-127) (1 + m/16), 2^(e-127) (1 + (m+1)/16)), e = 96 .. 127.  Five exponent bits are enough: a channel is y / 255 plus chroma
+// terms, operands of magnitude >= 2^-8, so a non-zero result is a multiple of 2^-31 -- the kernel's inputs are 0 or lie in
+// [2^-31, 1].  Cell 0 serves the input 0 (and the sliver above 2^-31): a line through the origin.
 void f32_cell16(uint32_t j, double* lo, double* hi) {
-  const uint32_t e = j >> 4, m = j & 15u;
-  if (e == 0) { *lo = std::ldexp((double)m, -130); *hi = std::ldexp((double)(m + 1u), -130); return; }
+  const uint32_t e = 96u + (j >> 4), m = j & 15u;
   *lo = std::ldexp(1.0 + m / 16.0, (int)e - 127);
   *hi = std::ldexp(1.0 + (m + 1u) / 16.0, (int)e - 127);
 }

@@ -33,7 +33,7 @@ constexpr uint32_t kLutSrgbInv = 0, kLutHlgInv = kLutSrgbInv + kLutSrgbInvN, kLu
 //                      0xC0000000 | n: red as it stands (alpha included), green and blue after a shift that drops the upper bits.
 // Appended to the LUT buffer by uhdr_hip_init; byte sizes are multiples of 16.
 constexpr uint32_t kTabS1Bytes = 0x3C00 + 16;                    // g = 1, half-precision cells up to 1.0
-constexpr uint32_t kTabS1PowBytes = 127u * 128u + 16u;           // g < 1, float cells up to 1.0 (exponent 127, mantissa 0)
+constexpr uint32_t kTabS1PowBytes = 512u * 8u;                   // g < 1: cell = (exponent & 31) << 4 | top 4 mantissa bits (inputs are 0 or in [2^-31, 1])
 constexpr uint32_t kTabS2Cells = 129, kTabS2Floats = 260;        // 129 x (c0, c1), padded
 constexpr uint32_t kTabS2LdsBytes = kTabS2Cells * 256u;          // replicated
 constexpr uint32_t kTabS1Lin = kLutTotal, kTabS1Hlg = kTabS1Lin + kTabS1Bytes / 4, kTabS1Pq = kTabS1Hlg + kTabS1PowBytes / 4,

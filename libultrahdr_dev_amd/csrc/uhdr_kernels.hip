@@ -986,10 +986,12 @@ __device__ __forceinline__ uint32_t tab_offset(float x) {
   const h2 q = __builtin_amdgcn_cvt_pkrtz(x, 0.0f);
   return __builtin_bit_cast(uint32_t, q) & 0x7FF8u;
 }
-// stage-1 tables for g < 1: the byte offset of a value's cell is its own bits 30..19, in place: one SDWA v_and
+// stage-1 tables for g < 1: the byte offset of a value's cell is its own bits 27..19 (the low five exponent bits -- the kernel's
+// inputs are 0 or lie in [2^-31, 1], exponents 96..127: build_stage1 in uhdr_capi.hip -- and the top four of the mantissa), in
+// place: one SDWA v_and on the upper half.  4 KiB per table; offset 0 is the entry of the input 0.
 __device__ __forceinline__ uint32_t pow_offset(float x) {
   uint32_t off;
-  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(0x7FF8u), "v"(x));
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(0x0FF8u), "v"(x));
   return off;
 }
 __device__ __forceinline__ void pow_pair(f2 x, const char* lut, float2& a, float2& b) {

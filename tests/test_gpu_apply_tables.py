@@ -44,11 +44,14 @@ def _all_floats(lo_bits, hi_bits, chunk=1 << 26):
 def test_stage1_table_for_every_float_in_0_1(hip, fn, g, name, tol):
     lib = hip.load()
     worst_rel = worst_abs = worst_sub = 0.0
-    # below 2^-17 the kernel only ever sees 0 ((y + k dv) / 255 has no smaller positive value); 0 itself is checked apart.
-    # Below 2^-14 the cells are the half-precision subnormals (uniform, 2^-21 wide): a power law is held to ~1/(16 k^2)
-    # there, k >= 16 -- on values whose codes are below 2 (HLG) / 20 (PQ).
+    # g = 1 (cells = half-precision patterns): below 2^-17 the red and blue channels only ever see 0 ((y + k dv) / 255 has no
+    # smaller positive value) and what green can see there is worth less than 0.01 code; below 2^-14 the cells are the half-precision
+    # subnormals (uniform, 2^-21 wide).  g < 1 (cells = the value's own exponent and mantissa bits): every input the kernel can see,
+    # i.e. from 2^-31 up (a channel is a sum of operands of magnitude >= 2^-8: a non-zero result is a multiple of 2^-31); the cell
+    # of 0 doubles as the first sixteenth of that octave and is a line through the origin there.  0 itself is checked apart.
     sub = int(np.float32(2.0 ** -14).view(np.uint32))
-    for x in _all_floats(int(np.float32(2.0 ** -17).view(np.uint32)), 0x3F800000):
+    first = 2.0 ** -17 if g == 1.0 else 2.0 ** -31 * (1.0 + 1.0 / 16.0)
+    for x in _all_floats(int(np.float32(first).view(np.uint32)), 0x3F800000):
         t = _eval(lib, fn, x).double()
         e = _eval(lib, 10, x).double().pow(g)
         d = (t - e).abs()

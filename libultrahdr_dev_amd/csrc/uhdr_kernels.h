@@ -23,8 +23,8 @@ constexpr uint32_t kLutSrgbInv = 0, kLutHlgInv = kLutSrgbInv + kLutSrgbInvN, kLu
 // function) -- so the path is  u = T(c) * 2^(g E),  T = EOTF^g  (g = 1/2 for HLG, m1 for PQ, 1 for the linear formats):
 //   stage 1  T(c):     cell = the float's own exponent and top 4 mantissa bits (16 cells per octave: the sRGB toe makes T
 //                      singular at 0, cells that follow the exponent hold a power law to a constant relative error, 6e-5 here);
-//                      `(bits >> 16) & 0x7FF8` -- one SDWA v_and -- is the byte offset of the entry as it stands.  Every octave
-//                      from the subnormals up to 1.0 has its cells (16 KiB), the pixels use the top few: 1-2 entries per bank.
+//                      `(bits >> 16) & 0x0FF8` -- one SDWA v_and -- is the byte offset of the entry as it stands: five exponent
+//                      bits (inputs are 0 or lie in [2^-31, 1]), 4 KiB; the pixels use the top few octaves: 1-2 entries per bank.
 //                      For g = 1 (linear output formats, calls whose values may pass 1.0) 16 cells per octave are too coarse:
 //                      that table takes its cell from the HALF-PRECISION bit pattern of c (bits 14..3: 128 cells per octave).
 //   stage 2  code(u):  129 UNIFORM cells over 2 + 2u in [2, 4] -- the cell is byte 2 of the float itself -- each entry

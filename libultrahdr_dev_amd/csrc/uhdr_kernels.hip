@@ -1318,8 +1318,8 @@ __device__ __forceinline__ void apply_load_cell(const AppConsts& c, const AppIma
   o.mb[0] = im.map[m0 + cx]; o.mb[1] = im.map[m1 + cx]; o.mb[2] = im.map[m0 + xu]; o.mb[3] = im.map[m1 + xu];
 }
 
-// Each block copies its tables into LDS once (15 KiB, + 32 KiB for the replicated stage-2 table of HLG / PQ output: two blocks
-// of 512 threads per CU) and then walks c.cells_per_thread map cells per thread.
+// Each block copies its tables into LDS once (4 KiB + 32 KiB for the replicated stage-2 table of HLG / PQ output, 15 KiB for the
+// other outputs: two blocks of 512 threads per CU) and then walks c.cells_per_thread map cells per thread.
 #ifndef UHDR_APPLY_EXPERIMENT
 #define UHDR_APPLY_EXPERIMENT 0
 #endif
@@ -1805,7 +1805,7 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
   }
   if (fast_s4 && !exact) {
     const uint32_t total = c.map_w * c.map_h;
-    // Cells per thread: a block copies 39-47 KB of tables into LDS before its first pixel, so it should walk many cells -- but a
+    // Cells per thread: a block copies 15-37 KB of tables into LDS before its first pixel, so it should walk many cells -- but a
     // launch also has to fill 256 CUs x 4 resident blocks, or a single 4K image (2025 blocks of 256 cells) would leave three
     // quarters of the chip idle with 8 cells per thread.
     AppConsts cc = c;

@@ -120,7 +120,9 @@ bool parse_float(const std::string& s, float* v) {
 }  // namespace
 
 // getMetadataFromXMP: Version, GainMapMax and HDRCapacityMax are required; the others default (min 1, gamma 1, offsets 1/64,
-// capacity min 1); GainMap* and HDRCapacity* are stored as log2; BaseRenditionIsHDR = "True" is refused.
+// capacity min 1); GainMap* and HDRCapacity* are stored as log2; BaseRenditionIsHDR = "True" is refused.  The reference reads a
+// float and calls exp2 on it (jpegrutils.cpp:225-229): the float overload, exp2f -- checked against its object code,
+// tests/test_ref_container.py.
 bool metadata_from_xmp(const uint8_t* payload, size_t len, uhdr_hip_metadata_t* md) {
   static const char kNs[] = "http://ns.adobe.com/xap/1.0/";
   if (len < sizeof(kNs) + 2 || memcmp(payload, kNs, sizeof(kNs) - 1) != 0) return false;
@@ -131,11 +133,11 @@ bool metadata_from_xmp(const uint8_t* payload, size_t len, uhdr_hip_metadata_t* 
   if (!xmp_attribute(xml, "hdrgm:Version", &v)) return false;
   strncpy(md->version, v.c_str(), sizeof(md->version) - 1);
   if (!xmp_attribute(xml, "hdrgm:GainMapMax", &v) || !parse_float(v, &f)) return false;
-  md->maxContentBoost = (float)exp2((double)f);
+  md->maxContentBoost = exp2f(f);
   if (!xmp_attribute(xml, "hdrgm:HDRCapacityMax", &v) || !parse_float(v, &f)) return false;
-  md->hdrCapacityMax = (float)exp2((double)f);
+  md->hdrCapacityMax = exp2f(f);
   md->minContentBoost = 1.0f;
-  if (xmp_attribute(xml, "hdrgm:GainMapMin", &v)) { if (!parse_float(v, &f)) return false; md->minContentBoost = (float)exp2((double)f); }
+  if (xmp_attribute(xml, "hdrgm:GainMapMin", &v)) { if (!parse_float(v, &f)) return false; md->minContentBoost = exp2f(f); }
   md->gamma = 1.0f;
   if (xmp_attribute(xml, "hdrgm:Gamma", &v)) { if (!parse_float(v, &f)) return false; md->gamma = f; }
   md->offsetSdr = 1.0f / 64.0f;
@@ -143,7 +145,7 @@ bool metadata_from_xmp(const uint8_t* payload, size_t len, uhdr_hip_metadata_t* 
   md->offsetHdr = 1.0f / 64.0f;
   if (xmp_attribute(xml, "hdrgm:OffsetHDR", &v)) { if (!parse_float(v, &f)) return false; md->offsetHdr = f; }
   md->hdrCapacityMin = 1.0f;
-  if (xmp_attribute(xml, "hdrgm:HDRCapacityMin", &v)) { if (!parse_float(v, &f)) return false; md->hdrCapacityMin = (float)exp2((double)f); }
+  if (xmp_attribute(xml, "hdrgm:HDRCapacityMin", &v)) { if (!parse_float(v, &f)) return false; md->hdrCapacityMin = exp2f(f); }
   if (xmp_attribute(xml, "hdrgm:BaseRenditionIsHDR", &v)) {
     if (v == "True") return false;        // "Base rendition of HDR is not supported" (:537-540)
     if (v != "False") return false;       // a present but unparsable field is an error (:531-534)
@@ -225,13 +227,13 @@ std::string xmp_secondary(const uhdr_hip_metadata_t& md) {
   std::string s = kXmpHead;
   s += "      xmlns:hdrgm=\"http://ns.adobe.com/hdr-gain-map/1.0/\"\n";
   s += std::string("      hdrgm:Version=\"") + md.version + "\"\n";
-  s += "      hdrgm:GainMapMin=\"" + num(log2((double)md.minContentBoost)) + "\"\n";      // log2(float) binds to the double function
-  s += "      hdrgm:GainMapMax=\"" + num(log2((double)md.maxContentBoost)) + "\"\n";
+  s += "      hdrgm:GainMapMin=\"" + num((double)log2f(md.minContentBoost)) + "\"\n";      // log2(float): the float overload (jpegrutils.cpp:598)
+  s += "      hdrgm:GainMapMax=\"" + num((double)log2f(md.maxContentBoost)) + "\"\n";
   s += "      hdrgm:Gamma=\"" + num((double)md.gamma) + "\"\n";
   s += "      hdrgm:OffsetSDR=\"" + num((double)md.offsetSdr) + "\"\n";
   s += "      hdrgm:OffsetHDR=\"" + num((double)md.offsetHdr) + "\"\n";
-  s += "      hdrgm:HDRCapacityMin=\"" + num(log2((double)md.hdrCapacityMin)) + "\"\n";
-  s += "      hdrgm:HDRCapacityMax=\"" + num(log2((double)md.hdrCapacityMax)) + "\"\n";
+  s += "      hdrgm:HDRCapacityMin=\"" + num((double)log2f(md.hdrCapacityMin)) + "\"\n";
+  s += "      hdrgm:HDRCapacityMax=\"" + num((double)log2f(md.hdrCapacityMax)) + "\"\n";
   s += "      hdrgm:BaseRenditionIsHDR=\"False\"/>\n  </rdf:RDF>\n</x:xmpmeta>\n";
   return s;
 }

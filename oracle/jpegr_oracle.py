@@ -6,6 +6,7 @@ hundred bytes of bookkeeping); the pixels go through the C checkers (orc_jpeg_de
 own.  Parity status of the CONTAINER level: unpinned -- the reference's decodeJPEGR cannot be built here (jpegr.cpp needs
 libjpeg-turbo headers and the un-vendored libheif fork) and its tests hold no decoded output for tests/data/sample_jpegr.jpeg;
 what is pinned is every stage below it and the file's own metadata (hdrgm:GainMapMax = 3.32193 -> 10.0)."""
+import ctypes
 import math
 import re
 import struct
@@ -82,6 +83,21 @@ def app_segment(jpg, marker, prefix):
     return None
 
 
+# glibc's log2f / exp2f: what the reference's `log2(metadata.maxContentBoost)` / `exp2(val)` on float operands bind to (pinned
+# against its object code, tests/test_ref_container.py)
+_libm = ctypes.CDLL("libm.so.6")
+_libm.log2f.restype = _libm.exp2f.restype = ctypes.c_float
+_libm.log2f.argtypes = _libm.exp2f.argtypes = [ctypes.c_float]
+
+
+def _log2f(v):
+    return float(np.float32(_libm.log2f(float(np.float32(v)))))
+
+
+def _exp2f(v):
+    return np.float32(_libm.exp2f(float(np.float32(v))))
+
+
 def _attr(xml, name):
     m = re.search(r"(?<![\w:\-])" + re.escape(name) + r"\s*=\s*(?:\"([^\"]*)\"|'([^']*)')", xml)
     return None if m is None else (m.group(1) if m.group(1) is not None else m.group(2))
@@ -102,7 +118,7 @@ def metadata_from_xmp(payload):
     req = {k: _attr(xml, "hdrgm:" + k) for k in ("GainMapMax", "HDRCapacityMax")}
     if any(v is None or _float(v) is None for v in req.values()):
         return None
-    ex = lambda v: np.float32(math.pow(2.0, float(v)))      # (float)exp2((double)val)
+    ex = _exp2f                                               # exp2(float val): the float overload (jpegrutils.cpp:225-229)
     md["max"], md["capmax"] = ex(_float(req["GainMapMax"])), ex(_float(req["HDRCapacityMax"]))
     for key, name, default, log in (("min", "GainMapMin", 1.0, True), ("gamma", "Gamma", 1.0, False), ("off_sdr", "OffsetSDR", 1 / 64, False),
                                     ("off_hdr", "OffsetHDR", 1 / 64, False), ("capmin", "HDRCapacityMin", 1.0, True)):
@@ -207,7 +223,7 @@ def xmp_primary(secondary_length, version="1.0"):
 
 
 def xmp_secondary(md):
-    l2 = lambda v: _g(math.log2(float(np.float32(v))))
+    l2 = lambda v: _g(_log2f(v))                              # log2(float): the float overload (jpegrutils.cpp:598-604)
     rows = [("Version", md["version"]), ("GainMapMin", l2(md["min"])), ("GainMapMax", l2(md["max"])), ("Gamma", _g(np.float32(md["gamma"]))),
             ("OffsetSDR", _g(np.float32(md["off_sdr"]))), ("OffsetHDR", _g(np.float32(md["off_hdr"]))), ("HDRCapacityMin", l2(md["capmin"])),
             ("HDRCapacityMax", l2(md["capmax"])), ("BaseRenditionIsHDR", "False")]

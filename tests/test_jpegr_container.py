@@ -2,9 +2,10 @@
 
 CPU part: the Python restatement (oracle/jpegr_oracle.py) on the reference's own sample file (tests/data/sample_jpegr.jpeg,
 committed as a fixture) -- properties the file itself fixes.  GPU part: uhdr_hip_jpegr_decode against that restatement, on the
-sample and on JPEG/R files assembled here from the device encoder's output.  The container level has no reference output to pin
-against (the reference's decodeJPEGR is not buildable here and its tests keep no decoded bytes): parity of this level is
-*unpinned*; every stage underneath (JPEG decoding, applyGainMap) is pinned on its own."""
+sample and on JPEG/R files assembled here from the device encoder's output.  The reference's decodeJPEGR / encodeJPEGR API-0..3
+are not buildable here (ultrahdr.cpp) and its tests keep no decoded bytes; what IS pinned against the reference's own object code:
+the container writers and parsers and whole API-4 files (tests/test_ref_container.py), and every stage underneath (JPEG coding,
+generateGainMap, applyGainMap) on its own."""
 import ctypes as C
 import os
 import struct

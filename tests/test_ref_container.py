@@ -1,0 +1,193 @@
+"""The JPEG/R container level against the REFERENCE's own object code (CPU only; skipped where oracle/_ref/libuhdr_refc.so has not
+been built, i.e. wherever /root/reference does not exist).
+
+oracle/_ref/libuhdr_refc.so = the reference's jpegr.cpp, jpegrutils.cpp, multipictureformat.cpp, icc.cpp, jpegdecoderhelper.cpp and
+the vendored image_io compiled in place (oracle/Makefile, oracle/ref_container_harness.cpp; ultrahdr.cpp and jpegencoderhelper.cpp are
+not buildable here and the entry points used do not reach them).  Compared with it, byte for byte:
+
+  * the restatement oracle/jpegr_oracle.py (what the GPU tests of encodeJPEGR / decodeJPEGR compare the product with), and
+  * the product's host-side container code through the C-ABI (uhdr_hip_jpegr_encode_api4, uhdr_hip_jpegr_info, uhdr_hip_icc_profile)
+
+on: the XMP packets of both images for a sweep of metadata, the MPF segment, the ICC profiles of the three gamuts, XMP parsing,
+whole files assembled by encodeJPEGR API-4 (jpegr.cpp:608-653, appendGainMap :951-1130) from the reference's own JPEG fixtures with
+and without EXIF / ICC, and getJPEGRInfo / extractPrimaryImageAndGainMap on those files and on the reference's sample file.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+LIB = os.path.join(ROOT, "oracle", "_ref", "libuhdr_refc.so")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libuhdr_refc.so not built (needs /root/reference)")
+
+
+@pytest.fixture(scope="module")
+def refc():
+    lib = C.CDLL(LIB, mode=os.RTLD_LAZY)     # lazily: the symbols of the two files left out stay unresolved and are never called
+    lib.refc_encode_api4.restype = C.c_long
+    lib.refc_encode_api4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_void_p, C.c_int]
+    lib.refc_extract.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_long)]
+    lib.refc_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)] + [C.c_void_p] * 6 + [C.c_long]
+    for name in ("refc_xmp_primary", "refc_xmp_secondary", "refc_mpf", "refc_icc_write"):
+        getattr(lib, name).restype = C.c_long
+    lib.refc_xmp_primary.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_long]
+    lib.refc_xmp_secondary.argtypes = [C.c_float] * 7 + [C.c_void_p, C.c_long]
+    lib.refc_parse_xmp.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_float), C.c_char_p]
+    lib.refc_mpf.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_long]
+    lib.refc_icc_write.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long]
+    lib.refc_icc_read_gamut.argtypes = [C.c_void_p, C.c_long]
+    return lib
+
+
+def _out(fn, *args, cap=1 << 16):
+    buf = np.zeros(cap, np.uint8)
+    n = fn(*args, C.c_void_p(buf.ctypes.data), cap)
+    assert 0 <= n <= cap, n
+    return buf[:n].tobytes()
+
+
+def _read(name):
+    with open(os.path.join(GOLD, name), "rb") as f:
+        return f.read()
+
+
+MDS = [dict(max=m, min=n, gamma=1.0, off_sdr=0.0, off_hdr=0.0) for m, n in
+       ((4.0, 1.0), (1000.0 / 203.0, 1.0), (10000.0 / 203.0, 1.0), (10.0, 0.5), (1.5, 0.75), (64.0, 0.015625), (2.0 ** 0.5, 1.0), (7.123456, 0.987654))]
+
+
+def _full(md):
+    f = lambda v: float(np.float32(v))
+    return dict(version="1.0", max=f(md["max"]), min=f(md["min"]), gamma=f(md["gamma"]), off_sdr=f(md["off_sdr"]), off_hdr=f(md["off_hdr"]),
+                capmin=f(md["min"]), capmax=f(md["max"]))
+
+
+def test_xmp_mpf_icc_writers_equal_the_reference(refc):
+    from oracle import jpegr_oracle as J
+    for md in map(_full, MDS):
+        got = _out(refc.refc_xmp_secondary, md["max"], md["min"], md["gamma"], md["off_sdr"], md["off_hdr"], md["capmin"], md["capmax"])
+        assert got.decode() == J.xmp_secondary(md), md
+        for ln in (0, 1, 999, 3727, 123456789):
+            assert _out(refc.refc_xmp_primary, ln, md["max"], md["min"]).decode() == J.xmp_primary(ln)
+    for args in ((42326, 0, 3727, 42300), (1, 0, 1, 1), (0x7FFFFFFF, 0, 0x01020304, 0x7FFFFFF0), (1694524, 0, 348850, 1345000)):
+        assert _out(refc.refc_mpf, *args) == J.mpf(*args), args
+    for gamut in (0, 1, 2):
+        ref = _out(refc.refc_icc_write, 3, gamut)            # ULTRAHDR_TF_SRGB = 3: the profile the codec writes (jpegr.cpp:220,298,555,599)
+        assert ref == J.icc_profile_srgb_transfer(gamut), gamut
+        assert refc.refc_icc_read_gamut(ref, len(ref)) == gamut == J.gamut_from_icc(ref)
+
+
+def test_product_icc_profile_equals_the_reference(refc):
+    from libultrahdr_dev_amd import api
+    lib = api.load()
+    for gamut in (0, 1, 2):
+        ref = _out(refc.refc_icc_write, 3, gamut)
+        out, n = np.zeros(4096, np.uint8), C.c_size_t()
+        assert lib.uhdr_hip_icc_profile(3, gamut, C.c_void_p(out.ctypes.data), out.size, C.byref(n)) == 0
+        assert out[:n.value].tobytes() == ref, gamut
+
+
+def test_xmp_parsing_equals_the_reference(refc):
+    from oracle import jpegr_oracle as J
+    md7, ver = (C.c_float * 7)(), C.create_string_buffer(16)
+    for md in map(_full, MDS):
+        packet = J.XMP_NS + J.xmp_secondary(md).encode()
+        assert refc.refc_parse_xmp(packet, len(packet), md7, ver) == 1
+        mine = J.metadata_from_xmp(packet)
+        assert mine is not None and ver.value.decode() == mine["version"] == "1.0"
+        for k, name in enumerate(("max", "min", "gamma", "off_sdr", "off_hdr", "capmin", "capmax")):
+            assert np.float32(mine[name]) == np.float32(md7[k]), (name, mine[name], md7[k])
+    # packets the reference refuses: so does the restatement
+    good = (J.XMP_NS + J.xmp_secondary(_full(MDS[0])).encode())
+    for bad in (good.replace(b'hdrgm:Version="1.0"', b'hdrgm:Version="2.0"'), good.replace(b"hdrgm:GainMapMax", b"hdrgm:GainMapMux"),
+                good.replace(b'BaseRenditionIsHDR="False"', b'BaseRenditionIsHDR="True"'), good[:len(J.XMP_NS) + 40], J.XMP_NS):
+        assert (refc.refc_parse_xmp(bad, len(bad), md7, ver) == 1) == (J.metadata_from_xmp(bad) is not None), bad[-60:]
+
+
+def _streams():
+    from oracle import jpegr_oracle as J
+    sample = _read("sample_jpegr.jpeg")
+    imgs = J.find_images(sample)
+    primary, gainmap = sample[imgs[0][0]:imgs[0][0] + imgs[0][1]], sample[imgs[1][0]:imgs[1][0] + imgs[1][1]]
+    i = primary.find(b"ICC_PROFILE\0")
+    seg_len = (primary[i - 2] << 8) | primary[i - 1]
+    no_icc = primary[:i - 4] + primary[i - 2 + seg_len:]
+    return sample, primary, gainmap, no_icc
+
+
+def test_api4_files_equal_the_reference_byte_for_byte(refc):
+    """primary streams: the sample's (ICC inside), the same without its ICC segment, the reference's jpeg_image.jpg (JFIF + EXIF, no
+    ICC), its minnie files (plain; progressive with EXIF + XMP + ICC); gain-map streams: the sample's and a grey fixture"""
+    from libultrahdr_dev_amd import api
+    from oracle import jpegr_oracle as J
+    lib = api.load()
+    sample, primary, gainmap, no_icc = _streams()
+    prims = [("sample primary", primary), ("sample primary without ICC", no_icc), ("jpeg_image.jpg", _read("jpeg_image.jpg")),
+             ("minnie yuv", _read("minnie-320x240-yuv.jpg")), ("minnie progressive icc", _read("minnie-320x240-yuv-icc.jpg"))]
+    gms = [("sample gain map", gainmap), ("minnie grey", _read("minnie-320x240-y.jpg"))]
+    n_files = 0
+    for pname, p in prims:
+        for gname, g in gms:
+            for md in map(_full, MDS[:4]):
+                for gamut in (-1, 0, 1, 2):
+                    cap = len(p) + len(g) + 8192
+                    out = np.zeros(cap, np.uint8)
+                    n = refc.refc_encode_api4(p, len(p), gamut, g, len(g), md["max"], md["min"], md["gamma"], md["off_sdr"], md["off_hdr"],
+                                              md["capmin"], md["capmax"], C.c_void_p(out.ctypes.data), cap)
+                    mine = J.encode_api4(p, gamut, g, md)
+                    hmd = api.metadata(md["max"], md["min"])
+                    pb, gb = np.frombuffer(p, np.uint8), np.frombuffer(g, np.uint8)
+                    pout, pn = np.zeros(cap, np.uint8), C.c_size_t()
+                    prc = lib.uhdr_hip_jpegr_encode_api4(C.c_void_p(pb.ctypes.data), pb.size, gamut, C.c_void_p(gb.ctypes.data), gb.size, C.byref(hmd),
+                                                         C.c_void_p(pout.ctypes.data), pout.size, C.byref(pn))
+                    if n < 0:
+                        assert mine == n == prc, (pname, gname, gamut, n, mine, prc)
+                        continue
+                    ref = out[:n].tobytes()
+                    assert mine == ref, (pname, gname, gamut, md)
+                    assert prc == 0 and pout[:pn.value].tobytes() == ref, (pname, gname, gamut, md, prc)
+                    n_files += 1
+    assert n_files >= 100
+
+
+def test_info_and_extract_equal_the_reference(refc):
+    from libultrahdr_dev_amd import api
+    from oracle import jpegr_oracle as J
+    lib = api.load()
+    sample, primary, gainmap, no_icc = _streams()
+    md = _full(MDS[1])
+    files = [sample, J.encode_api4(no_icc, 1, gainmap, md), J.encode_api4(_read("jpeg_image.jpg"), 0, _read("minnie-320x240-y.jpg"), md),
+             J.encode_api4(_read("minnie-320x240-yuv-icc.jpg"), -1, gainmap, md)]
+    for blob in files:
+        assert isinstance(blob, bytes)
+        o4 = (C.c_long * 4)()
+        assert refc.refc_extract(blob, len(blob), o4) == 0
+        mine = J.info(blob)
+        assert (mine[0]["offset"], mine[0]["size"], mine[1]["offset"], mine[1]["size"]) == tuple(o4)
+        dims, sizes = (C.c_long * 4)(), (C.c_long * 6)()
+        bufs = [np.zeros(1 << 16, np.uint8) for _ in range(6)]
+        assert refc.refc_info(blob, len(blob), dims, sizes, *[C.c_void_p(b.ctypes.data) for b in bufs], 1 << 16) == 0
+        assert tuple(dims) == (mine[0]["width"], mine[0]["height"], mine[1]["width"], mine[1]["height"])
+        # the reference hands out copies of the payloads whose ranges the restatement reports (the XMP copy carries one more byte, a
+        # terminating 0: jpegdecoderhelper.cpp:235 -- the C++ shim's getJPEGRInfo appends it too)
+        k = 0
+        for img in (0, 1):
+            for key in ("icc", "exif", "xmp"):
+                off, n = mine[img][key]
+                ref_bytes = bufs[k][:sizes[k]].tobytes()
+                assert ref_bytes == (blob[off:off + n] + (b"\0" if key == "xmp" else b"") if n else b""), (img, key, n, sizes[k])
+                k += 1
+        # and the product's uhdr_hip_jpegr_info reports the same ranges as the restatement (tests/test_jpegr_container.py) -- here: same sizes
+        b = np.frombuffer(blob, np.uint8)
+        a, g = api.JpegInfo(), api.JpegInfo()
+        assert lib.uhdr_hip_jpegr_info(C.c_void_p(b.ctypes.data), b.size, C.byref(a), C.byref(g)) == 0
+        assert (a.offset, a.size, g.offset, g.size, a.width, a.height, g.width, g.height) == tuple(o4) + tuple(dims)
+    # files the reference refuses
+    for bad in (primary, b"\0" * 64, sample[:1000]):
+        o4 = (C.c_long * 4)()
+        rc = refc.refc_extract(bad, len(bad), o4)
+        mine = J.info(bad)
+        assert rc != 0 and isinstance(mine, int), (rc, mine)

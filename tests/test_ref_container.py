@@ -80,6 +80,55 @@ def test_xmp_mpf_icc_writers_equal_the_reference(refc):
         assert refc.refc_icc_read_gamut(ref, len(ref)) == gamut == J.gamut_from_icc(ref)
 
 
+def test_xmp_numbers_over_a_random_sweep(refc):
+    """the formatted log2 of 2000 random boosts (writer) and the exp2 of 2000 random packet values (parser): float arithmetic and
+    ostream formatting are where a restatement goes wrong unnoticed"""
+    from libultrahdr_dev_amd import api
+    from oracle import jpegr_oracle as J
+    lib = api.load()
+    prim, gm = _read("minnie-320x240-yuv.jpg"), _read("minnie-320x240-y.jpg")
+    pb, gb = np.frombuffer(prim, np.uint8), np.frombuffer(gm, np.uint8)
+    rng = np.random.RandomState(7)
+    md7, ver = (C.c_float * 7)(), C.create_string_buffer(16)
+    for _ in range(2000):
+        mx = float(np.float32(2.0 ** rng.uniform(0, 8)))
+        mn = float(np.float32(2.0 ** rng.uniform(-4, 0)))
+        md = dict(version="1.0", max=mx, min=mn, gamma=float(np.float32(rng.uniform(0.5, 2))), off_sdr=float(np.float32(rng.uniform(0, 0.1))),
+                  off_hdr=float(np.float32(rng.uniform(0, 0.1))), capmin=mn, capmax=mx)
+        got = _out(refc.refc_xmp_secondary, md["max"], md["min"], md["gamma"], md["off_sdr"], md["off_hdr"], md["capmin"], md["capmax"])
+        mine = J.xmp_secondary(md)
+        assert got.decode() == mine, md
+        packet = J.XMP_NS + mine.encode()
+        assert refc.refc_parse_xmp(packet, len(packet), md7, ver) == 1
+        back = J.metadata_from_xmp(packet)
+        for k, name in enumerate(("max", "min", "gamma", "off_sdr", "off_hdr", "capmin", "capmax")):
+            assert np.float32(back[name]) == np.float32(md7[k]), (name, md)
+        # the product's writer and parser on the same boosts: the API-4 file, and the metadata read back from it (API-4 refuses a
+        # gamma other than 1 and offsets other than 0 -- reference and product alike)
+        if _ % 4 == 0:
+            for v in (dict(md, gamma=1.0, off_sdr=0.0, off_hdr=0.0), md):
+                hmd = api.Metadata()
+                hmd.version = b"1.0"
+                hmd.maxContentBoost, hmd.minContentBoost, hmd.gamma = v["max"], v["min"], v["gamma"]
+                hmd.offsetSdr, hmd.offsetHdr, hmd.hdrCapacityMin, hmd.hdrCapacityMax = v["off_sdr"], v["off_hdr"], v["capmin"], v["capmax"]
+                cap = len(prim) + len(gm) + 8192
+                out, pout, pn = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), C.c_size_t()
+                n = refc.refc_encode_api4(prim, len(prim), 0, gm, len(gm), v["max"], v["min"], v["gamma"], v["off_sdr"], v["off_hdr"],
+                                          v["capmin"], v["capmax"], C.c_void_p(out.ctypes.data), cap)
+                rc = lib.uhdr_hip_jpegr_encode_api4(C.c_void_p(pb.ctypes.data), pb.size, 0, C.c_void_p(gb.ctypes.data), gb.size, C.byref(hmd),
+                                                    C.c_void_p(pout.ctypes.data), pout.size, C.byref(pn))
+                if n < 0:
+                    assert rc == n == -10010, (rc, n, v)
+                    continue
+                assert rc == 0 and pout[:pn.value].tobytes() == out[:n].tobytes(), v
+                rmd = api.Metadata()
+                assert lib.uhdr_hip_jpegr_metadata(C.c_void_p(pout.ctypes.data), pn.value, C.byref(rmd)) == 0
+                packet = J.XMP_NS + J.xmp_secondary(v).encode()
+                assert refc.refc_parse_xmp(packet, len(packet), md7, ver) == 1
+                got7 = (rmd.maxContentBoost, rmd.minContentBoost, rmd.gamma, rmd.offsetSdr, rmd.offsetHdr, rmd.hdrCapacityMin, rmd.hdrCapacityMax)
+                assert all(np.float32(a) == np.float32(b) for a, b in zip(got7, md7)), (got7, list(md7))
+
+
 def test_product_icc_profile_equals_the_reference(refc):
     from libultrahdr_dev_amd import api
     lib = api.load()

@@ -128,3 +128,24 @@ int refc_icc_read_gamut(const void* icc, long n) {
 }
 
 }  // extern "C"
+
+/* JpegDecoderHelper (lib/src/jpegdecoderhelper.cpp, the reference's own object code on the image's libjpeg):
+ * decompressImage(DECODE_TO_YCBCR) -> bytes written (> cap: nothing copied), -1 when the reference's call fails; whg[3] = width,
+ * height, 1 for a single-plane image (size == width * height) */
+extern "C" long refc_jpeg_decode(const void* jpeg, int len, void* out, long cap, long* whg) {
+  JpegDecoderHelper dec;
+  if (!dec.decompressImage(jpeg, len, DECODE_TO_YCBCR)) return -1;
+  whg[0] = (long)dec.getDecompressedImageWidth();
+  whg[1] = (long)dec.getDecompressedImageHeight();
+  const size_t n = dec.getDecompressedImageSize();
+  whg[2] = n == (size_t)whg[0] * (size_t)whg[1] ? 1 : 0;
+  return put(dec.getDecompressedImagePtr(), n, out, (size_t)cap);
+}
+/* getCompressedImageParameters: out5 = width, height, icc size, exif size, xmp size; 0 when the call fails */
+extern "C" int refc_jpeg_params(const void* jpeg, int len, long* out5) {
+  JpegDecoderHelper dec;
+  if (!dec.getCompressedImageParameters(jpeg, len)) return 0;
+  out5[0] = (long)dec.getDecompressedImageWidth(); out5[1] = (long)dec.getDecompressedImageHeight();
+  out5[2] = (long)dec.getICCSize(); out5[3] = (long)dec.getEXIFSize(); out5[4] = (long)dec.getXMPSize();
+  return 1;
+}

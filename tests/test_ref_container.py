@@ -240,3 +240,41 @@ def test_info_and_extract_equal_the_reference(refc):
         rc = refc.refc_extract(bad, len(bad), o4)
         mine = J.info(bad)
         assert rc != 0 and isinstance(mine, int), (rc, mine)
+
+
+def test_decoder_helper_of_the_reference_equals_the_checkers(refc, orc, tmp_path):
+    """JpegDecoderHelper::decompressImage(DECODE_TO_YCBCR) and getCompressedImageParameters -- the reference's object code on the
+    image's libjpeg -- against oracle "lj" (this repo's harness around the same libjpeg, restating the helper's call sequence; it is
+    what the GPU decoder is compared with) and, for baseline files, the C restatement "orc": the reference's fixtures and the
+    synthetic corpus (sizes, qualities, optimised tables, restart intervals, a progressive file, a 4:4:4 file it refuses)"""
+    from tests.test_jpeg_oracle import jpeg_corpus
+    refc.refc_jpeg_decode.restype = C.c_long
+    refc.refc_jpeg_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_long)]
+    refc.refc_jpeg_params.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_long)]
+    corpus, extra = jpeg_corpus(orc, tmp_path)
+    files = [(n, _read(n)) for n in ("minnie-320x240-yuv.jpg", "minnie-320x240-yuv-icc.jpg", "minnie-320x240-y.jpg", "jpeg_image.jpg")]
+    files += list(corpus) + [(k, v) for k, v in extra.items()]
+    n_ok = 0
+    for name, data in files:
+        data = bytes(data)
+        whg = (C.c_long * 3)()
+        out = np.zeros(1 << 24, np.uint8)
+        n = refc.refc_jpeg_decode(data, len(data), C.c_void_p(out.ctypes.data), out.size, whg)
+        st, want, w, h, gray = orc.jpeg_decode("lj", data)
+        if n < 0:
+            assert st <= 0, (name, st)
+            continue
+        assert st > 0 and (w, h, int(bool(gray))) == tuple(whg), (name, tuple(whg), w, h, gray)
+        assert n == want.size and np.array_equal(out[:n], want), name
+        st2, got2, w2, h2, g2 = orc.jpeg_decode("orc", data)
+        if st2 != -2:                                   # (-2: a progressive file, outside the baseline restatement)
+            assert st2 > 0 and np.array_equal(got2, want), name
+        p5 = (C.c_long * 5)()
+        assert refc.refc_jpeg_params(data, len(data), p5) == 1 and (p5[0], p5[1]) == (w, h), name
+        n_ok += 1
+    assert n_ok >= 12
+    p5 = (C.c_long * 5)()
+    icc = _read("minnie-320x240-yuv-icc.jpg")
+    assert refc.refc_jpeg_params(icc, len(icc), p5) == 1 and p5[2] > 0 and p5[3] > 0 and p5[4] > 0      # jpegdecoderhelper_test.cpp:125-137
+    plain = _read("minnie-320x240-yuv.jpg")
+    assert refc.refc_jpeg_params(plain, len(plain), p5) == 1 and (p5[2], p5[3]) == (0, 0)                 # :112-123

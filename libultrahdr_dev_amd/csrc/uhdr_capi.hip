@@ -501,20 +501,25 @@ class StageLease {
   explicit StageLease(DeviceState* st) : st_(st) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (st_->free_sets.empty()) {
-      st_->sets.emplace_back(new StageSet());
-      set_ = st_->sets.back().get();
+      try {
+        st_->sets.emplace_back(new StageSet());
+        set_ = st_->sets.back().get();
+      } catch (const std::bad_alloc&) {
+        set_ = nullptr;   // (the caller returns INSUFFICIENT_RESOURCE: nothing may throw through the C boundary)
+      }
     } else {
       set_ = st_->free_sets.back();
       st_->free_sets.pop_back();
     }
   }
   ~StageLease() {
+    if (set_ == nullptr) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    st_->free_sets.push_back(set_);
+    try { st_->free_sets.push_back(set_); } catch (const std::bad_alloc&) {}   // (the set stays owned by st_->sets)
   }
   StageLease(const StageLease&) = delete;
   StageLease& operator=(const StageLease&) = delete;
-  StageSet* get() const { return set_; }
+  StageSet* get() const { return set_; }   // nullptr: out of host memory
  private:
   DeviceState* st_;
   StageSet* set_;
@@ -1784,7 +1789,9 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
     const bool resolve = filter && aligned && !lut && !small;
     if (resolve) {
       std::lock_guard<std::mutex> lk(g_mu);
-      uint32_t*& w = st->stat_ws[s];
+      uint32_t** wp = nullptr;
+      try { wp = &st->stat_ws[s]; } catch (const std::bad_alloc&) { return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE; }
+      uint32_t*& w = *wp;
       if (w == nullptr) {   // cleared once: every launch leaves the headers cleared behind it
         HIP_TRY(hipMalloc(&w, kStatWsBytes));
         HIP_TRY(hipMemset(w, 0, kStatWsBytes));
@@ -1860,7 +1867,14 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
       const uint32_t cap = ex_list_cap((uint64_t)c.width * c.height);
       const size_t need = ((size_t)kMaxChunk * kExHdrWords + (size_t)m * kExLists * cap) * 4u;
       std::lock_guard<std::mutex> lk(g_mu);
-      DeviceState::ExWs& w = st->ex_ws[s];
+      DeviceState::ExWs* wp = nullptr;
+      try {
+        wp = &st->ex_ws[s];
+        if (wp->bytes < need && wp->p) st->retired.reserve(st->retired.size() + 1);
+      } catch (const std::bad_alloc&) {
+        return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+      }
+      DeviceState::ExWs& w = *wp;
       if (w.bytes < need) {
         // another caller of this stream may be about to launch with the old one: it stays allocated (sizes at least double)
         if (w.p) { st->retired.push_back(w.p); w.p = nullptr; }
@@ -1899,6 +1913,7 @@ int uhdr_hip_generate_gainmap_ex(const uhdr_hip_image_t* yuv, const uhdr_hip_ima
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
   StageLease lease(st);
   StageSet* ss = lease.get();
+  if (ss == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   uhdr_hip_image_t dy, dp, dm = *dest;
   if ((rc = stage_yuv420_in(ss, 0, *yuv, &dy, s)) != 0) return rc;
@@ -1928,6 +1943,7 @@ int uhdr_hip_apply_gainmap(const uhdr_hip_image_t* yuv, const uhdr_hip_image_t* 
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
   StageLease lease(st);
   StageSet* ss = lease.get();
+  if (ss == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   uhdr_hip_image_t dy, dm = *map, dd = *dest;
   if ((rc = stage_yuv420_in(ss, 0, *yuv, &dy, s)) != 0) return rc;
@@ -2019,6 +2035,7 @@ int uhdr_hip_tonemap(const uhdr_hip_image_t* src, uhdr_hip_image_t* dest, int me
 
   StageLease lease(st);
   StageSet* ss = lease.get();
+  if (ss == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   uhdr_hip_image_t ds, dd = *dest;
   if ((rc = stage_p010_in(ss, 2, *src, &ds, s)) != 0) return rc;
   const size_t h = dest->height, ls = dest->luma_stride, cs = dest->chroma_stride;
@@ -2094,6 +2111,7 @@ int uhdr_hip_convert_yuv(uhdr_hip_image_t* image, int src_encoding, int dest_enc
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto run = [&](const uhdr_hip_image_t& d) -> int { return convert_yuv_into(d, d, m, s); };
   StageLease lease(st);
+  if (lease.get() == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   uhdr_hip_image_t d;
   if ((rc = stage_yuv420_in(lease.get(), 0, *image, &d, s)) != 0) return rc;
   if ((rc = run(d)) != 0) return rc;

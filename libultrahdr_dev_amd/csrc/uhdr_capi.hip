@@ -388,7 +388,7 @@ void build_stage2(F code_of_u, float* out) {
   }
 }
 void build_line_tables(std::vector<float>& tab) {
-  tab.assign(kLutBufferFloats - kTabS1Lin, 0.0f);
+  tab.assign(kTabEnd - kTabS1Lin, 0.0f);
   const double m1 = (double)(2610.0f / 16384.0f), m2 = (double)(2523.0f / 4096.0f * 128.0f);
   const double k1 = (double)(3424.0f / 4096.0f), k2 = (double)(2413.0f / 4096.0f * 32.0f), k3 = (double)(2392.0f / 4096.0f * 32.0f);
   build_stage1(1.0, tab.data() + (kTabS1Lin - kTabS1Lin));
@@ -621,6 +621,7 @@ int uhdr_hip_init(int device) {
       build_line_tables(tab);
       HIP_TRY(hipMemcpy(st.lut + kTabS1Lin, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    HIP_TRY(launch_build_lut_codes(st.lut, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(jpeg::upload_tables());
     st.ready = true;

@@ -37,8 +37,11 @@ constexpr uint32_t kTabS1PowBytes = 512u * 8u;                   // g < 1: cell 
 constexpr uint32_t kTabS2Cells = 129, kTabS2Floats = 260;        // 129 x (c0, c1), padded
 constexpr uint32_t kTabS2LdsBytes = kTabS2Cells * 256u;          // replicated
 constexpr uint32_t kTabS1Lin = kLutTotal, kTabS1Hlg = kTabS1Lin + kTabS1Bytes / 4, kTabS1Pq = kTabS1Hlg + kTabS1PowBytes / 4,
-                   kTabS2Hlg = kTabS1Pq + kTabS1PowBytes / 4, kTabS2Pq = kTabS2Hlg + kTabS2Floats,
-                   kLutBufferFloats = kTabS2Pq + kTabS2Floats;
+                   kTabS2Hlg = kTabS1Pq + kTabS1PowBytes / 4, kTabS2Pq = kTabS2Hlg + kTabS2Floats, kTabEnd = kTabS2Pq + kTabS2Floats;
+// LUT-mode apply, scale 4: what becomes of an OETF table entry is its 10-bit code, (uint32_t)(table[i] * 1023.0f) & 0x3ff
+// (gainmapmath.cpp:722-727) -- the 65536 codes of a table are 128 KiB of uint16 and fit into a workgroup's LDS where the 256 KiB of
+// floats do not.  Built once per device behind the float tables (k_build_lut_codes).
+constexpr uint32_t kCodeHlg = kTabEnd, kCodePq = kCodeHlg + kLutHlgN / 2, kLutBufferFloats = kCodePq + kLutPqN / 2;
 constexpr uint32_t kGainLutN = 1024;  // kGainFactorNumEntries, gainmapmath.h:149-150
 
 // ---- generate ----------------------------------------------------------------------------------
@@ -191,6 +194,7 @@ hipError_t launch_stats_finalize(uint32_t* keys, int n, hipStream_t s);
 hipError_t launch_apply(const AppConsts& c, const AppBatch& b, int n, int fmt, int mode,
                         bool fast_s4, hipStream_t s);
 hipError_t launch_build_luts(float* lut /* kLutTotal floats */, hipStream_t s);
+hipError_t launch_build_lut_codes(float* lut /* the whole buffer: reads the two OETF tables, writes kCodeHlg / kCodePq */, hipStream_t s);
 // GainLUT table (kGainLutN floats, device) for (log2 min, log2 max, boost factor)
 hipError_t launch_build_gain_lut(float* table, double log2_min, double log2_max, float boost_factor, hipStream_t s);
 hipError_t launch_tonemap(const ToneBatch& b, int n, bool aligned, hipStream_t s);      // n <= kToneChunk images of equal width / height

@@ -140,6 +140,16 @@ hipError_t launch_build_luts(float* lut, hipStream_t s) {
   hipLaunchKernelGGL(k_build_luts, dim3((kLutTotal + 255u) / 256u), dim3(256), 0, s, lut);
   return hipGetLastError();
 }
+__global__ void __launch_bounds__(256) k_build_lut_codes(float* lut) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;   // 2 x 65536 entries
+  const uint32_t t = i >> 16, k = i & 0xFFFFu;
+  uint16_t* codes = reinterpret_cast<uint16_t*>(lut + (t ? kCodePq : kCodeHlg));
+  codes[k] = (uint16_t)(0x3ffu & (uint32_t)(lut[(t ? kLutPq : kLutHlg) + k] * 1023.0f));
+}
+hipError_t launch_build_lut_codes(float* lut, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_lut_codes, dim3(2u * 65536u / 256u), dim3(256), 0, s, lut);
+  return hipGetLastError();
+}
 __global__ void __launch_bounds__(256) k_build_gain_lut(float* table, double log2_min, double log2_max, float boost_factor) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < kGainLutN) table[i] = gain_lut_entry(i, log2_min, log2_max, boost_factor);
@@ -1792,6 +1802,106 @@ __global__ void __launch_bounds__(256) k_apply_lut(const AppConsts c, const AppB
   }
 }
 
+// LUT mode for the common geometry (scale 4, aligned planes: app_fast_s4).  Thread = one map cell; 1024-thread blocks, one per CU,
+// that live for the whole launch (block b takes the 1024-cell chunks b, b + G, ... of the batch): what makes them expensive to
+// start is what makes them fast -- the OETF table sits in LDS as its 65536 10-bit codes (128 KiB; uhdr_kernels.h), next to the
+// sRGB table and GainLUT(metadata, display_boost), so no lookup leaves the CU.  The arithmetic is k_apply_lut's, operation for
+// operation (the taps' / 255 through the constant division that is proven equal, the weights from the scale-4 table).
+template <int FMT, bool INTERIOR>
+__device__ __forceinline__ void lut_cell(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, const ApplyCellIn& in, int tbl,
+                                         const float* s_srgb, const float* s_gain, const uint16_t* s_code) {
+  const float e1 = map_to_float_fast(in.mb[0]), e2 = map_to_float_fast(in.mb[1]);
+  const float e3 = map_to_float_fast(in.mb[2]), e4 = map_to_float_fast(in.mb[3]);
+  float crv[2][2], gcbu[2][2], gcrv[2][2], cbu[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float u = (float)((int)((in.uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      const float v = (float)((int)((in.vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      crv[r][k] = kP3Cr * v; gcbu[r][k] = kP3GCb * u; gcrv[r][k] = kP3GCr * v; cbu[r][k] = kP3Cb * u;
+    }
+  const float* wt = c_idw4 + (INTERIOR ? 0 : tbl * 64);
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy) {
+    float o[4][3];
+#pragma unroll
+    for (int ox = 0; ox < 4; ++ox) {
+      const float* w = wt + oy * 16 + ox * 4;
+      const float gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
+      const float factor = s_gain[lut_index(gain, kGainLutN)];
+      const float yf = (float)((in.yrow[oy] >> (8 * ox)) & 0xffu) * k255;
+      const int r2 = oy >> 1, k2 = ox >> 1;
+      const float r = s_srgb[lut_index(clamp01(yf + crv[r2][k2]), kLutSrgbInvN)];
+      const float g = s_srgb[lut_index(clamp01(yf - gcbu[r2][k2] - gcrv[r2][k2]), kLutSrgbInvN)];
+      const float bl = s_srgb[lut_index(clamp01(yf + cbu[r2][k2]), kLutSrgbInvN)];
+      o[ox][0] = (r * factor) / c.display_boost;
+      o[ox][1] = (g * factor) / c.display_boost;
+      o[ox][2] = (bl * factor) / c.display_boost;
+    }
+    const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;
+    if (FMT == 2 || FMT == 3) {
+      uint4 q;
+      uint32_t* qq = &q.x;
+#pragma unroll
+      for (int ox = 0; ox < 4; ++ox)
+        qq[ox] = (uint32_t)s_code[lut_index(o[ox][0], kLutHlgN)] | ((uint32_t)s_code[lut_index(o[ox][1], kLutHlgN)] << 10) |
+                 ((uint32_t)s_code[lut_index(o[ox][2], kLutHlgN)] << 20) | (0x3u << 30);
+      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), q);
+    } else if (FMT == 1) {
+      const uint2 a = pack_f16(o[0][0], o[0][1], o[0][2]), bb = pack_f16(o[1][0], o[1][1], o[1][2]);
+      const uint2 cc = pack_f16(o[2][0], o[2][1], o[2][2]), d = pack_f16(o[3][0], o[3][1], o[3][2]);
+      uint4* dst = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+      dst[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+      dst[1] = make_uint4(cc.x, cc.y, d.x, d.y);
+    } else {
+      const size_t plane = (size_t)c.width * c.height;
+      uint16_t* base16 = static_cast<uint16_t*>(im.dst);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const uint32_t q0 = 0x3ffu & (uint32_t)(o[0][p] * 1023.0f), q1 = 0x3ffu & (uint32_t)(o[1][p] * 1023.0f);
+        const uint32_t q2 = 0x3ffu & (uint32_t)(o[2][p] * 1023.0f), q3 = 0x3ffu & (uint32_t)(o[3][p] * 1023.0f);
+        *reinterpret_cast<uint2*>(base16 + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+      }
+    }
+  }
+}
+
+constexpr uint32_t kLutS4Block = 1024;
+template <int FMT>
+__global__ void __launch_bounds__(1024) k_apply_lut_s4(const AppConsts c, const AppBatch b, uint32_t n) {
+  constexpr bool kOetf = FMT == 2 || FMT == 3;
+  extern __shared__ uint4 s_dyn[];                       // [codes 128 KiB (HLG / PQ output only)] [sRGB 4 KiB] [gain 4 KiB]
+  uint16_t* s_code = reinterpret_cast<uint16_t*>(s_dyn);
+  float* s_srgb = reinterpret_cast<float*>(reinterpret_cast<char*>(s_dyn) + (kOetf ? kLutHlgN * 2u : 0u));
+  float* s_gain = s_srgb + kLutSrgbInvN;
+  static_assert(kLutSrgbInvN == kLutS4Block && kGainLutN == kLutS4Block, "one table entry per thread");
+  s_srgb[threadIdx.x] = c.lut[kLutSrgbInv + threadIdx.x];
+  s_gain[threadIdx.x] = gain_lut_entry(threadIdx.x, c.log2_min_d, c.log2_max_d, c.lut_boost_factor);
+  if (kOetf) {
+    const uint4* src = reinterpret_cast<const uint4*>(c.lut + (FMT == 3 ? kCodeHlg : kCodePq));
+    uint4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = src[k * kLutS4Block + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_dyn[k * kLutS4Block + threadIdx.x] = t[k];
+  }
+  __syncthreads();
+  const uint32_t cells = c.map_w * c.map_h, per_img = (cells + kLutS4Block - 1u) / kLutS4Block, total = per_img * n;
+  for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+    const uint32_t img = id / per_img, idx = (id - img * per_img) * kLutS4Block + threadIdx.x;
+    if (idx >= cells) continue;
+    const AppImage& im = b.img[img];
+    const uint32_t cy = idx / c.map_w, cx = idx - cy * c.map_w;
+    ApplyCellIn in;
+    apply_load_cell(c, im, cx, cy, in);
+    const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
+    const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
+    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) lut_cell<FMT, true>(c, im, cx, cy, in, 0, s_srgb, s_gain, s_code);
+    else lut_cell<FMT, false>(c, im, cx, cy, in, tbl, s_srgb, s_gain, s_code);
+  }
+}
+
 template <int FMT>
 static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, int mode,
                                  bool fast_s4, hipStream_t s) {
@@ -1799,6 +1909,16 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
   const bool exact = mode == 1 || mode == 3;
   if (mode == 2) {
     if (c.lut == nullptr) return hipErrorInvalidValue;
+    if (fast_s4) {
+      constexpr bool kOetf = FMT == 2 || FMT == 3;
+      const uint32_t lds = (kOetf ? kLutHlgN * 2u : 0u) + (kLutSrgbInvN + kGainLutN) * 4u;
+      const uint32_t chunks = (c.map_w * c.map_h + kLutS4Block - 1u) / kLutS4Block * (uint32_t)n;
+      // more than 64 KiB of LDS has to be allowed per function (and per device: set on every launch, it is a host-side flag)
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply_lut_s4<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_apply_lut_s4<FMT>), dim3(chunks < 256u ? chunks : 256u), dim3(kLutS4Block), lds, s, c, b, (uint32_t)n);
+      return hipGetLastError();
+    }
     const size_t total = (size_t)c.width * c.height, per_block = 256u * (size_t)kLutPixelsPerThread;
     hipLaunchKernelGGL((k_apply_lut<FMT>), dim3((unsigned)((total + per_block - 1u) / per_block), n), dim3(256), 0, s, c, b);
     return hipGetLastError();

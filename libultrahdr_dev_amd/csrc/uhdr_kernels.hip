@@ -1440,9 +1440,7 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
 // EXACT arithmetic.  Mirrors ultrahdr.cpp:427-496 + gainmapmath.cpp:686-720 literally.
 struct PxIn { float yf, u, v, gain; };
 // the loads of ultrahdr.cpp:431-438 and sampleMap (gainmapmath.cpp:686-720) for pixel idx
-__device__ __forceinline__ PxIn px_inputs(const AppConsts& c, const AppImage& im, size_t idx) {
-  const uint32_t y = (uint32_t)(idx / c.width);
-  const uint32_t x = (uint32_t)(idx - (size_t)y * c.width);
+__device__ __forceinline__ PxIn px_inputs(const AppConsts& c, const AppImage& im, uint32_t x, uint32_t y) {
   PxIn in;
   in.yf = (float)im.y[(size_t)y * im.y_stride + x] * k255;
   const size_t ci = (size_t)(y >> 1) * im.c_stride + (x >> 1);
@@ -1450,15 +1448,21 @@ __device__ __forceinline__ PxIn px_inputs(const AppConsts& c, const AppImage& im
   in.v = (float)((int)im.v[ci] - 128) * k255;
 
   const uint32_t s = c.scale;
-  uint32_t xl = x / s, yl = y / s;
+  uint32_t xl, yl, ox, oy;
+  if ((s & (s - 1u)) == 0u) {   // (a launch-uniform branch: scale factors are powers of two in practice)
+    const uint32_t sh = (uint32_t)__builtin_ctz(s);
+    xl = x >> sh; yl = y >> sh; ox = x & (s - 1u); oy = y & (s - 1u);
+  } else {
+    xl = x / s; yl = y / s; ox = x - xl * s; oy = y - yl * s;
+  }
   uint32_t xu = xl + 1u, yu = yl + 1u;
   xl = min(xl, c.map_w - 1u); xu = min(xu, c.map_w - 1u);
   yl = min(yl, c.map_h - 1u); yu = min(yu, c.map_h - 1u);
-  const float e1 = map_to_float(im.map[(size_t)yl * c.map_w + xl]);
-  const float e2 = map_to_float(im.map[(size_t)yu * c.map_w + xl]);
-  const float e3 = map_to_float(im.map[(size_t)yl * c.map_w + xu]);
-  const float e4 = map_to_float(im.map[(size_t)yu * c.map_w + xu]);
-  const uint32_t ox = x % s, oy = y % s;
+  // (byte / 255.0f through the constant division that is proven equal for all 256 bytes, tests/test_gpu_transfer_exhaustive.py)
+  const float e1 = map_to_float_fast(im.map[(size_t)yl * c.map_w + xl]);
+  const float e2 = map_to_float_fast(im.map[(size_t)yu * c.map_w + xl]);
+  const float e3 = map_to_float_fast(im.map[(size_t)yl * c.map_w + xu]);
+  const float e4 = map_to_float_fast(im.map[(size_t)yu * c.map_w + xu]);
   int tbl = 0;
   if (xl == xu && yl == yu) tbl = 3;
   else if (xl == xu) tbl = 1;
@@ -1466,6 +1470,11 @@ __device__ __forceinline__ PxIn px_inputs(const AppConsts& c, const AppImage& im
   const float* w = c.idw + (size_t)tbl * s * s * 4u + (size_t)oy * s * 4u + ox * 4u;
   in.gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
   return in;
+}
+// the per-pixel kernels run on a (column block, row, image) grid: no division by the width; rows beyond the grid's 65535 are
+// reached by striding
+__host__ __device__ inline dim3 px_grid(uint32_t width, uint32_t height, int n) {
+  return dim3((width + 255u) / 256u, height < 65535u ? height : 65535u, (unsigned)n);
 }
 template <int FMT>
 __device__ __forceinline__ void px_store(const AppImage& im, size_t idx, size_t total, F3 e) {
@@ -1483,13 +1492,15 @@ __device__ __forceinline__ void px_store(const AppImage& im, size_t idx, size_t 
 
 template <int FMT, bool EXACT>
 __global__ void __launch_bounds__(256) k_apply_px(const AppConsts c, const AppBatch b) {
-  const AppImage& im = b.img[blockIdx.y];
+  const AppImage& im = b.img[blockIdx.z];
   const size_t total = (size_t)c.width * c.height;
-  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
-  if (idx >= total) return;
-  const PxIn in = px_inputs(c, im, idx);
-  const F3 lin = recover_hdr<EXACT>(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
-  px_store<FMT>(im, idx, total, hdr_oetf<FMT, EXACT>(lin));
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+  if (x >= c.width) return;
+  for (uint32_t y = blockIdx.y; y < c.height; y += gridDim.y) {
+    const PxIn in = px_inputs(c, im, x, y);
+    const F3 lin = recover_hdr<EXACT>(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
+    px_store<FMT>(im, (size_t)y * c.width + x, total, hdr_oetf<FMT, EXACT>(lin));
+  }
 }
 
 // ---- EXACT mode behind an f32 pre-filter (HLG, F16 and planar 10-bit outputs) ----------------------------------------------------
@@ -1538,47 +1549,51 @@ __device__ __forceinline__ void est_channel(float lin, float& out, float& doubt_
 
 template <int FMT>
 __global__ void __launch_bounds__(256) k_apply_px_est(const AppConsts c, const AppBatch b) {
-  const AppImage& im = b.img[blockIdx.y];
+  const AppImage& im = b.img[blockIdx.z];
   const size_t total = (size_t)c.width * c.height;
-  const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
-  bool doubt = false;
-  if (idx < total) {
-    const PxIn in = px_inputs(c, im, idx);
-    const F3 lin = recover_hdr_est(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
-    float o[3], dm = 1.0f;
-    est_channel<FMT>(lin.x, o[0], dm);
-    est_channel<FMT>(lin.y, o[1], dm);
-    est_channel<FMT>(lin.z, o[2], dm);
-    doubt = dm < 0.0f;
-    if (FMT == 2 || FMT == 3) {
-      static_cast<uint32_t*>(im.dst)[idx] = (0x3ffu & (uint32_t)o[0]) | ((0x3ffu & (uint32_t)o[1]) << 10) | ((0x3ffu & (uint32_t)o[2]) << 20) | (0x3u << 30);
-    } else if (FMT == 1) {
-      static_cast<uint2*>(im.dst)[idx] = pack_f16_hw(o[0], o[1], o[2]);
-    } else {
-      uint16_t* base = static_cast<uint16_t*>(im.dst);
-      base[idx] = (uint16_t)(0x3ffu & (uint32_t)o[0]);
-      base[total + idx] = (uint16_t)(0x3ffu & (uint32_t)o[1]);
-      base[2 * total + idx] = (uint16_t)(0x3ffu & (uint32_t)o[2]);
-    }
-  }
-  // one append per block: the list is chosen by the block so that no two neighbouring blocks share a counter
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+  uint32_t* hdr = c.ex_ws + (size_t)blockIdx.z * kExHdrWords;
   __shared__ uint32_t s_cnt[4], s_base;
-  const uint64_t mask = __ballot(doubt);
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
-  __syncthreads();
-  const uint32_t list = blockIdx.x % kExLists;
-  uint32_t* hdr = c.ex_ws + (size_t)blockIdx.y * kExHdrWords;
-  if (threadIdx.x == 0) {
-    const uint32_t t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    s_base = t ? atomicAdd(hdr + 8u + list, t) : 0u;
-  }
-  __syncthreads();
-  if (doubt) {
-    uint32_t pos = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    for (uint32_t w = 0; w < wave; ++w) pos += s_cnt[w];
-    if (pos < c.ex_cap)
-      c.ex_ws[(size_t)kMaxChunk * kExHdrWords + ((size_t)blockIdx.y * kExLists + list) * c.ex_cap + pos] = (uint32_t)idx;
+  for (uint32_t y = blockIdx.y; y < c.height; y += gridDim.y) {   // (block-uniform trip count: the barriers below are safe)
+    const size_t idx = (size_t)y * c.width + x;
+    bool doubt = false;
+    if (x < c.width) {
+      const PxIn in = px_inputs(c, im, x, y);
+      const F3 lin = recover_hdr_est(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
+      float o[3], dm = 1.0f;
+      est_channel<FMT>(lin.x, o[0], dm);
+      est_channel<FMT>(lin.y, o[1], dm);
+      est_channel<FMT>(lin.z, o[2], dm);
+      doubt = dm < 0.0f;
+      if (FMT == 2 || FMT == 3) {
+        static_cast<uint32_t*>(im.dst)[idx] = (0x3ffu & (uint32_t)o[0]) | ((0x3ffu & (uint32_t)o[1]) << 10) | ((0x3ffu & (uint32_t)o[2]) << 20) | (0x3u << 30);
+      } else if (FMT == 1) {
+        static_cast<uint2*>(im.dst)[idx] = pack_f16_hw(o[0], o[1], o[2]);
+      } else {
+        uint16_t* base = static_cast<uint16_t*>(im.dst);
+        base[idx] = (uint16_t)(0x3ffu & (uint32_t)o[0]);
+        base[total + idx] = (uint16_t)(0x3ffu & (uint32_t)o[1]);
+        base[2 * total + idx] = (uint16_t)(0x3ffu & (uint32_t)o[2]);
+      }
+    }
+    // one append per block and row: the list is chosen by the block so that neighbouring blocks do not share a counter
+    const uint64_t mask = __ballot(doubt);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    __syncthreads();   // (the previous row's s_cnt / s_base have been read)
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    const uint32_t list = (y * gridDim.x + blockIdx.x) % kExLists;
+    if (threadIdx.x == 0) {
+      const uint32_t t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+      s_base = t ? atomicAdd(hdr + 8u + list, t) : 0u;
+    }
+    __syncthreads();
+    if (doubt) {
+      uint32_t pos = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      for (uint32_t w = 0; w < wave; ++w) pos += s_cnt[w];
+      if (pos < c.ex_cap)
+        c.ex_ws[(size_t)kMaxChunk * kExHdrWords + ((size_t)blockIdx.z * kExLists + list) * c.ex_cap + pos] = (uint32_t)idx;
+    }
   }
 }
 
@@ -1723,7 +1738,8 @@ __global__ void __launch_bounds__(256) k_apply_resolve(const AppConsts c, const 
       while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_first[mid] <= (uint32_t)g) lo = mid; else hi = mid; }
       idx = entries[(size_t)lo * c.ex_cap + ((uint32_t)g - s_first[lo])];
     }
-    const PxIn in = px_inputs(c, im, idx);
+    const uint32_t py = (uint32_t)(idx / c.width), px = (uint32_t)(idx - (size_t)py * c.width);
+    const PxIn in = px_inputs(c, im, px, py);
     const F3 lin = recover_hdr<true>(c, in.yf, kP3Cr * in.v, kP3GCb * in.u, kP3GCr * in.v, kP3Cb * in.u, in.gain);
     px_store<FMT>(im, idx, total, hdr_oetf<FMT, true>(lin));
   }
@@ -1954,8 +1970,7 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
       hipLaunchKernelGGL((k_apply_s4<FMT, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
     }
   } else {
-    const size_t total = (size_t)c.width * c.height;
-    const dim3 grid((unsigned)((total + 255u) / 256u), n);
+    const dim3 grid = px_grid(c.width, c.height, n);
     if (exact && c.ex_ws != nullptr) {
       if (fast_s4) hipLaunchKernelGGL((k_apply_s4_est<FMT>), dim3((c.map_w * c.map_h + 255u) / 256u, n), dim3(256), 0, s, c, b);
       else hipLaunchKernelGGL((k_apply_px_est<FMT>), grid, dim3(256), 0, s, c, b);

@@ -5,6 +5,9 @@
 #   encoder: 8000 random images against the CPU restatement of libjpeg
 # Last run (round 1, final build): 40 000 + 12 000 identical decodes, 0 mismatches; 8000 identical encodes.
 set -e
+# pixel path: 1000 random configurations (sizes, strides, gamuts, transfer functions, map scales, output formats, display boosts,
+# EXACT on every fourth) against the oracle
+UHDR_FUZZ_SEEDS=1000 python -m pytest tests/test_gpu_fuzz.py -x -q
 python tests/stress_jpeg_dec.py 20000 11
 python tests/stress_jpeg_dec.py 6000 23 damage
 UHDR_ENC_SWEEP=8000 UHDR_ENC_SWEEP_SEED=5 python -m pytest tests/test_gpu_jpeg.py -x -q -k random_images

@@ -2,6 +2,7 @@
 random even dimensions, gamuts, transfer function, strides, separate chroma planes): every draw runs generate ->
 apply (random output format, display boost, EXACT or FAST) -> toneMap -> convertYuv on the GPU and on the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -26,7 +27,7 @@ def _planes(rng, w, h, ls, ycs, pcs, kind):
     return yl.reshape(-1), yc.reshape(-1), pl.reshape(-1), pcc.reshape(-1)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("UHDR_FUZZ_SEEDS", "24"))))   # scripts/long_checks.sh runs 1000
 def test_random_configuration(hip, orc, seed):
     from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr, diff_1010102, half_ulp_diff
     lib, L = hip.load(), orc.load()

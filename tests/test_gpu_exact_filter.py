@@ -183,3 +183,21 @@ def test_batch_of_frames_and_a_second_stream(hip, orc):
         res[mode] = [to_host(o) for o in outs]
     for a, b in zip(res[hip.APPLY_EXACT], res[hip.APPLY_EXACT_UNFILTERED]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_an_image_taller_than_the_grid(hip, orc, mode):
+    """65 540 rows: the per-pixel kernels' row dimension of the grid stops at 65 535 and the rest is reached by striding"""
+    from tests.test_gpu_parity import _oracle_apply, _check_apply
+    lib = hip.load()
+    w, h, scale = 8, 65540, 2
+    rng = np.random.RandomState(3)
+    yuv = rng.randint(0, 256, w * h * 3 // 2).astype(np.uint8)
+    gmap = rng.randint(0, 256, (h // scale, w // scale)).astype(np.uint8)
+    maxb = np.float32(4.0)
+    md = hip.metadata(maxb)
+    ref = _oracle_apply(orc, yuv, w, h, gmap, maxb, hip.OUTPUT_HDR_HLG, FLT_MAX)
+    if mode == "exact":
+        assert np.array_equal(_apply(lib, hip, yuv, w, h, gmap, md, hip.OUTPUT_HDR_HLG, FLT_MAX, hip.APPLY_EXACT), ref)
+    else:
+        _check_apply(hip, hip.OUTPUT_HDR_HLG, _apply(lib, hip, yuv, w, h, gmap, md, hip.OUTPUT_HDR_HLG, FLT_MAX, hip.APPLY_FAST), ref, w, h)

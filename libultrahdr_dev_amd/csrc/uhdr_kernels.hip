@@ -2051,24 +2051,25 @@ hipError_t launch_ycc420_to_rgba(const uint8_t* y, const uint8_t* cb, const uint
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_tonemap_luma(const ToneBatch b) {
   const ToneImage& t = b.img[blockIdx.z];
-  const uint32_t row = blockIdx.y;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  const uint16_t* src = t.sy + (size_t)row * t.sy_stride;
-  uint8_t* dst = t.dy + (size_t)row * t.dy_stride;
-  if (ALIGNED) {
-    const uint32_t x = i * 8u;
-    if (x >= t.dy_stride) return;
-    uint2 o = make_uint2(0u, 0u);
-    if (x < t.width) {  // width % 8 == 0 on this path
-      const uint4 q = *reinterpret_cast<const uint4*>(src + x);
-      o.x = ((q.x >> 8) & 0xffu) | ((q.x >> 24) << 8) | (((q.y >> 8) & 0xffu) << 16) | ((q.y >> 24) << 24);
-      o.y = ((q.z >> 8) & 0xffu) | ((q.z >> 24) << 8) | (((q.w >> 8) & 0xffu) << 16) | ((q.w >> 24) << 24);
+  for (uint32_t row = blockIdx.y; row < t.height; row += gridDim.y) {   // (rows beyond the grid's 65535 by striding)
+    const uint16_t* src = t.sy + (size_t)row * t.sy_stride;
+    uint8_t* dst = t.dy + (size_t)row * t.dy_stride;
+    if (ALIGNED) {
+      const uint32_t x = i * 8u;
+      if (x >= t.dy_stride) return;
+      uint2 o = make_uint2(0u, 0u);
+      if (x < t.width) {  // width % 8 == 0 on this path
+        const uint4 q = *reinterpret_cast<const uint4*>(src + x);
+        o.x = ((q.x >> 8) & 0xffu) | ((q.x >> 24) << 8) | (((q.y >> 8) & 0xffu) << 16) | ((q.y >> 24) << 24);
+        o.y = ((q.z >> 8) & 0xffu) | ((q.z >> 24) << 8) | (((q.w >> 8) & 0xffu) << 16) | ((q.w >> 24) << 24);
+      }
+      *reinterpret_cast<uint2*>(dst + x) = o;
+    } else {
+      if (i >= t.dy_stride && i >= t.width) return;
+      if (i < t.width) dst[i] = (uint8_t)((src[i] >> 6 >> 2) & 0xff);
+      else dst[i] = 0;  // memset(dst_y_row + width, 0, luma_stride - width)
     }
-    *reinterpret_cast<uint2*>(dst + x) = o;
-  } else {
-    if (i >= t.dy_stride && i >= t.width) return;
-    if (i < t.width) dst[i] = (uint8_t)((src[i] >> 6 >> 2) & 0xff);
-    else dst[i] = 0;  // memset(dst_y_row + width, 0, luma_stride - width)
   }
 }
 
@@ -2076,33 +2077,34 @@ __global__ void __launch_bounds__(256) k_tonemap_luma(const ToneBatch b) {
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_tonemap_chroma(const ToneBatch b) {
   const ToneImage& t = b.img[blockIdx.z];
-  const uint32_t row = blockIdx.y;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t cw = t.width / 2u;
-  const uint16_t* src = t.suv + (size_t)row * t.suv_stride;
-  uint8_t* du = t.du + (size_t)row * t.dc_stride;
-  uint8_t* dv = t.dv + (size_t)row * t.dc_stride;
-  if (ALIGNED) {
-    const uint32_t x = i * 8u;  // chroma sample index; cw % 8 == 0 on this path
-    if (x >= t.dc_stride) return;
-    uint2 ou = make_uint2(0u, 0u), ov = make_uint2(0u, 0u);
-    if (x < cw) {
-      const uint4 a = *reinterpret_cast<const uint4*>(src + 2u * x);
-      const uint4 bq = *reinterpret_cast<const uint4*>(src + 2u * x + 8u);
-      ou.x = ((a.x >> 8) & 0xffu) | (((a.y >> 8) & 0xffu) << 8) | (((a.z >> 8) & 0xffu) << 16) | (((a.w >> 8) & 0xffu) << 24);
-      ov.x = (a.x >> 24) | ((a.y >> 24) << 8) | ((a.z >> 24) << 16) | ((a.w >> 24) << 24);
-      ou.y = ((bq.x >> 8) & 0xffu) | (((bq.y >> 8) & 0xffu) << 8) | (((bq.z >> 8) & 0xffu) << 16) | (((bq.w >> 8) & 0xffu) << 24);
-      ov.y = (bq.x >> 24) | ((bq.y >> 24) << 8) | ((bq.z >> 24) << 16) | ((bq.w >> 24) << 24);
-    }
-    *reinterpret_cast<uint2*>(du + x) = ou;
-    *reinterpret_cast<uint2*>(dv + x) = ov;
-  } else {
-    if (i >= t.dc_stride && i >= cw) return;
-    if (i < cw) {
-      du[i] = (uint8_t)((src[2u * i] >> 6 >> 2) & 0xff);
-      dv[i] = (uint8_t)((src[2u * i + 1u] >> 6 >> 2) & 0xff);
+  for (uint32_t row = blockIdx.y; row < t.height / 2u; row += gridDim.y) {
+    const uint16_t* src = t.suv + (size_t)row * t.suv_stride;
+    uint8_t* du = t.du + (size_t)row * t.dc_stride;
+    uint8_t* dv = t.dv + (size_t)row * t.dc_stride;
+    if (ALIGNED) {
+      const uint32_t x = i * 8u;  // chroma sample index; cw % 8 == 0 on this path
+      if (x >= t.dc_stride) return;
+      uint2 ou = make_uint2(0u, 0u), ov = make_uint2(0u, 0u);
+      if (x < cw) {
+        const uint4 a = *reinterpret_cast<const uint4*>(src + 2u * x);
+        const uint4 bq = *reinterpret_cast<const uint4*>(src + 2u * x + 8u);
+        ou.x = ((a.x >> 8) & 0xffu) | (((a.y >> 8) & 0xffu) << 8) | (((a.z >> 8) & 0xffu) << 16) | (((a.w >> 8) & 0xffu) << 24);
+        ov.x = (a.x >> 24) | ((a.y >> 24) << 8) | ((a.z >> 24) << 16) | ((a.w >> 24) << 24);
+        ou.y = ((bq.x >> 8) & 0xffu) | (((bq.y >> 8) & 0xffu) << 8) | (((bq.z >> 8) & 0xffu) << 16) | (((bq.w >> 8) & 0xffu) << 24);
+        ov.y = (bq.x >> 24) | ((bq.y >> 24) << 8) | ((bq.z >> 24) << 16) | ((bq.w >> 24) << 24);
+      }
+      *reinterpret_cast<uint2*>(du + x) = ou;
+      *reinterpret_cast<uint2*>(dv + x) = ov;
     } else {
-      du[i] = 0; dv[i] = 0;
+      if (i >= t.dc_stride && i >= cw) return;
+      if (i < cw) {
+        du[i] = (uint8_t)((src[2u * i] >> 6 >> 2) & 0xff);
+        dv[i] = (uint8_t)((src[2u * i + 1u] >> 6 >> 2) & 0xff);
+      } else {
+        du[i] = 0; dv[i] = 0;
+      }
     }
   }
 }
@@ -2114,13 +2116,13 @@ hipError_t launch_tonemap(const ToneBatch& b, int n, bool aligned, hipStream_t s
   uint32_t lcols = t.width, ccols = t.width / 2u;
   for (int i = 0; i < n; ++i) { lcols = b.img[i].dy_stride > lcols ? b.img[i].dy_stride : lcols; ccols = b.img[i].dc_stride > ccols ? b.img[i].dc_stride : ccols; }
   if (aligned) {
-    hipLaunchKernelGGL((k_tonemap_luma<true>), dim3((lcols / 8u + 255u) / 256u, t.height, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL((k_tonemap_luma<true>), dim3((lcols / 8u + 255u) / 256u, t.height < 65535u ? t.height : 65535u, n), dim3(256), 0, s, b);
     if (t.height / 2u)
-      hipLaunchKernelGGL((k_tonemap_chroma<true>), dim3((ccols / 8u + 255u) / 256u, t.height / 2u, n), dim3(256), 0, s, b);
+      hipLaunchKernelGGL((k_tonemap_chroma<true>), dim3((ccols / 8u + 255u) / 256u, t.height / 2u < 65535u ? t.height / 2u : 65535u, n), dim3(256), 0, s, b);
   } else {
-    hipLaunchKernelGGL((k_tonemap_luma<false>), dim3((lcols + 255u) / 256u, t.height, n), dim3(256), 0, s, b);
+    hipLaunchKernelGGL((k_tonemap_luma<false>), dim3((lcols + 255u) / 256u, t.height < 65535u ? t.height : 65535u, n), dim3(256), 0, s, b);
     if (t.height / 2u && ccols)
-      hipLaunchKernelGGL((k_tonemap_chroma<false>), dim3((ccols + 255u) / 256u, t.height / 2u, n), dim3(256), 0, s, b);
+      hipLaunchKernelGGL((k_tonemap_chroma<false>), dim3((ccols + 255u) / 256u, t.height / 2u < 65535u ? t.height / 2u : 65535u, n), dim3(256), 0, s, b);
   }
   return hipGetLastError();
 }
@@ -2171,57 +2173,59 @@ __device__ __forceinline__ void cvt_block(const float (&m)[9], uint32_t (&yb)[4]
 template <bool ALIGNED>
 __global__ void __launch_bounds__(256) k_convert_yuv(const CvtBatch b) {
   const CvtImage& t = b.img[blockIdx.z];
-  const uint32_t cyr = blockIdx.y;  // chroma row
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t cw = t.width / 2u;
-  uint8_t* y0 = t.y + (size_t)(2u * cyr) * t.y_stride;
-  uint8_t* y1 = y0 + t.y_stride;
-  uint8_t* ur = t.u + (size_t)cyr * t.c_stride;
-  uint8_t* vr = t.v + (size_t)cyr * t.c_stride;
-  const uint8_t* sy0 = t.sy + (size_t)(2u * cyr) * t.sy_stride;
-  const uint8_t* sy1 = sy0 + t.sy_stride;
-  const uint8_t* sur = t.su + (size_t)cyr * t.sc_stride;
-  const uint8_t* svr = t.sv + (size_t)cyr * t.sc_stride;
-  if (ALIGNED) {  // 4 chroma samples = 8 luma columns per thread; cw % 4 == 0
-    const uint32_t cx = i * 4u;
-    if (cx >= cw) return;
-    uint2 a = *reinterpret_cast<const uint2*>(sy0 + 2u * cx);
-    uint2 bq = *reinterpret_cast<const uint2*>(sy1 + 2u * cx);
-    uint32_t uw = *reinterpret_cast<const uint32_t*>(sur + cx);
-    uint32_t vw = *reinterpret_cast<const uint32_t*>(svr + cx);
-    const uint32_t top[2] = {a.x, a.y}, bot[2] = {bq.x, bq.y};
-    uint32_t otop[2] = {0u, 0u}, obot[2] = {0u, 0u}, ou = 0u, ov = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int sh = 16 * (k & 1);
-      uint32_t yb[4] = {(top[k >> 1] >> sh) & 0xffu, (top[k >> 1] >> (sh + 8)) & 0xffu,
-                        (bot[k >> 1] >> sh) & 0xffu, (bot[k >> 1] >> (sh + 8)) & 0xffu};
-      uint32_t ub = (uw >> (8 * k)) & 0xffu, vb = (vw >> (8 * k)) & 0xffu;
+  for (uint32_t cyr = blockIdx.y; cyr < t.height / 2u; cyr += gridDim.y) {   // chroma row (rows beyond the grid's 65535 by striding)
+    uint8_t* y0 = t.y + (size_t)(2u * cyr) * t.y_stride;
+    uint8_t* y1 = y0 + t.y_stride;
+    uint8_t* ur = t.u + (size_t)cyr * t.c_stride;
+    uint8_t* vr = t.v + (size_t)cyr * t.c_stride;
+    const uint8_t* sy0 = t.sy + (size_t)(2u * cyr) * t.sy_stride;
+    const uint8_t* sy1 = sy0 + t.sy_stride;
+    const uint8_t* sur = t.su + (size_t)cyr * t.sc_stride;
+    const uint8_t* svr = t.sv + (size_t)cyr * t.sc_stride;
+    if (ALIGNED) {  // 4 chroma samples = 8 luma columns per thread; cw % 4 == 0
+      const uint32_t cx = i * 4u;
+      if (cx >= cw) return;
+      uint2 a = *reinterpret_cast<const uint2*>(sy0 + 2u * cx);
+      uint2 bq = *reinterpret_cast<const uint2*>(sy1 + 2u * cx);
+      uint32_t uw = *reinterpret_cast<const uint32_t*>(sur + cx);
+      uint32_t vw = *reinterpret_cast<const uint32_t*>(svr + cx);
+      const uint32_t top[2] = {a.x, a.y}, bot[2] = {bq.x, bq.y};
+      uint32_t otop[2] = {0u, 0u}, obot[2] = {0u, 0u}, ou = 0u, ov = 0u;
+  #pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sh = 16 * (k & 1);
+        uint32_t yb[4] = {(top[k >> 1] >> sh) & 0xffu, (top[k >> 1] >> (sh + 8)) & 0xffu,
+                          (bot[k >> 1] >> sh) & 0xffu, (bot[k >> 1] >> (sh + 8)) & 0xffu};
+        uint32_t ub = (uw >> (8 * k)) & 0xffu, vb = (vw >> (8 * k)) & 0xffu;
+        cvt_block(b.img[0].m, yb, ub, vb);
+        otop[k >> 1] |= (yb[0] << sh) | (yb[1] << (sh + 8));
+        obot[k >> 1] |= (yb[2] << sh) | (yb[3] << (sh + 8));
+        ou |= ub << (8 * k); ov |= vb << (8 * k);
+      }
+      *reinterpret_cast<uint2*>(y0 + 2u * cx) = make_uint2(otop[0], otop[1]);
+      *reinterpret_cast<uint2*>(y1 + 2u * cx) = make_uint2(obot[0], obot[1]);
+      *reinterpret_cast<uint32_t*>(ur + cx) = ou;
+      *reinterpret_cast<uint32_t*>(vr + cx) = ov;
+    } else {
+      if (i >= cw) return;
+      uint32_t yb[4] = {sy0[2u * i], sy0[2u * i + 1u], sy1[2u * i], sy1[2u * i + 1u]};
+      uint32_t ub = sur[i], vb = svr[i];
       cvt_block(b.img[0].m, yb, ub, vb);
-      otop[k >> 1] |= (yb[0] << sh) | (yb[1] << (sh + 8));
-      obot[k >> 1] |= (yb[2] << sh) | (yb[3] << (sh + 8));
-      ou |= ub << (8 * k); ov |= vb << (8 * k);
+      y0[2u * i] = (uint8_t)yb[0]; y0[2u * i + 1u] = (uint8_t)yb[1];
+      y1[2u * i] = (uint8_t)yb[2]; y1[2u * i + 1u] = (uint8_t)yb[3];
+      ur[i] = (uint8_t)ub; vr[i] = (uint8_t)vb;
     }
-    *reinterpret_cast<uint2*>(y0 + 2u * cx) = make_uint2(otop[0], otop[1]);
-    *reinterpret_cast<uint2*>(y1 + 2u * cx) = make_uint2(obot[0], obot[1]);
-    *reinterpret_cast<uint32_t*>(ur + cx) = ou;
-    *reinterpret_cast<uint32_t*>(vr + cx) = ov;
-  } else {
-    if (i >= cw) return;
-    uint32_t yb[4] = {sy0[2u * i], sy0[2u * i + 1u], sy1[2u * i], sy1[2u * i + 1u]};
-    uint32_t ub = sur[i], vb = svr[i];
-    cvt_block(b.img[0].m, yb, ub, vb);
-    y0[2u * i] = (uint8_t)yb[0]; y0[2u * i + 1u] = (uint8_t)yb[1];
-    y1[2u * i] = (uint8_t)yb[2]; y1[2u * i + 1u] = (uint8_t)yb[3];
-    ur[i] = (uint8_t)ub; vr[i] = (uint8_t)vb;
   }
 }
 
 hipError_t launch_convert_yuv(const CvtBatch& b, int n, bool aligned, hipStream_t s) {
   const uint32_t cw = b.img[0].width / 2u, ch = b.img[0].height / 2u;
   if (n <= 0 || cw == 0 || ch == 0) return hipSuccess;
-  if (aligned) hipLaunchKernelGGL((k_convert_yuv<true>), dim3((cw / 4u + 255u) / 256u, ch, n), dim3(256), 0, s, b);
-  else hipLaunchKernelGGL((k_convert_yuv<false>), dim3((cw + 255u) / 256u, ch, n), dim3(256), 0, s, b);
+  const uint32_t rows = ch < 65535u ? ch : 65535u;
+  if (aligned) hipLaunchKernelGGL((k_convert_yuv<true>), dim3((cw / 4u + 255u) / 256u, rows, n), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((k_convert_yuv<false>), dim3((cw + 255u) / 256u, rows, n), dim3(256), 0, s, b);
   return hipGetLastError();
 }
 

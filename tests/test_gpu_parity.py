@@ -667,3 +667,24 @@ def test_fast_apply_against_exact_apply_on_sixteen_4k_frames(hip, fmt):
                 worst = max(worst, int(d.max())); ndiff += int((d != 0).sum()); total += d.numel()
         print("fmt %d boost %s: worst %d, differing fraction %.2e" % (fmt, "max" if boost == FLT_MAX else "2.0", worst, ndiff / total))
         assert worst <= 1, (fmt, boost, worst)
+
+
+def test_tonemap_and_convert_yuv_on_an_image_taller_than_the_grid(hip, orc):
+    """131 080 rows: the row dimension of the launch grid stops at 65 535, the kernels stride over the rest"""
+    from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr
+    lib, olib = hip.load(), orc.load()
+    w, h = 16, 131080
+    rng = np.random.RandomState(9)
+    p010 = (rng.randint(64, 941, w * h * 3 // 2).astype(np.uint16) << 6)
+    oy = np.zeros(w * h * 3 // 2, np.uint8)
+    osrc, odst = orc.p010_image(p010, w, h, orc.CG_BT2100), orc.yuv420_image(oy, w, h, -1)
+    assert olib.orc_toneMap(C.byref(osrc), C.byref(odst)) == 0
+    dp, dy = to_dev(p010), dev_empty(w * h * 3 // 2, 0xEE)
+    src, dst = hip.p010_image(dp.data_ptr(), w, h, hip.CG_BT2100), hip.yuv420_image(dy.data_ptr(), w, h, -1)
+    assert lib.uhdr_hip_tonemap(C.byref(src), C.byref(dst), hip.MEM_DEVICE, stream_ptr()) == 0
+    assert np.array_equal(to_host(dy), oy)
+    oc = oy.copy()
+    oimg = orc.yuv420_image(oc, w, h, 2)
+    assert olib.orc_convertYuv(C.byref(oimg), 2, 1) == 0
+    assert lib.uhdr_hip_convert_yuv(C.byref(dst), 2, 1, hip.MEM_DEVICE, stream_ptr()) == 0
+    assert np.array_equal(to_host(dy), oc)

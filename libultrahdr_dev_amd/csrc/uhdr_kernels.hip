@@ -1930,10 +1930,11 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
       const uint32_t lds = (kOetf ? kLutHlgN * 2u : 0u) + (kLutSrgbInvN + kGainLutN) * 4u;
       const uint32_t chunks = (c.map_w * c.map_h + kLutS4Block - 1u) / kLutS4Block * (uint32_t)n;
       // more than 64 KiB of LDS has to be allowed per function (and per device: set on every launch, it is a host-side flag)
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply_lut_s4<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((k_apply_lut_s4<FMT>), dim3(chunks < 256u ? chunks : 256u), dim3(kLutS4Block), lds, s, c, b, (uint32_t)n);
-      return hipGetLastError();
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_apply_lut_s4<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+        hipLaunchKernelGGL((k_apply_lut_s4<FMT>), dim3(chunks < 256u ? chunks : 256u), dim3(kLutS4Block), lds, s, c, b, (uint32_t)n);
+        return hipGetLastError();
+      }
+      (void)hipGetLastError();   // (a device that does not grant the LDS: the per-pixel kernel below gives the same bytes)
     }
     const size_t total = (size_t)c.width * c.height, per_block = 256u * (size_t)kLutPixelsPerThread;
     hipLaunchKernelGGL((k_apply_lut<FMT>), dim3((unsigned)((total + per_block - 1u) / per_block), n), dim3(256), 0, s, c, b);

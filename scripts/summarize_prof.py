@@ -32,6 +32,7 @@ summary["kernel_stats_top"] = [
 
 # per-dispatch trace of our kernels: VGPR/SGPR/LDS + duration distribution
 tr = defaultdict(list)
+starts = defaultdict(list)
 meta = {}
 for f in glob.glob(os.path.join(prof, "stats", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -39,10 +40,19 @@ for f in glob.glob(os.path.join(prof, "stats", "**", "*kernel_trace.csv"), recur
         if not any(o in n for o in OURS):
             continue
         tr[short(n)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        starts[short(n)].append(int(r["Start_Timestamp"]))
         meta[short(n)] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
                                                  "Workgroup_Size_X", "Grid_Size_X", "Grid_Size_Y")}
 summary["our_kernels_trace"] = {n: {"dispatches": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v), "max_ns": max(v), **meta[n]}
                                 for n, v in tr.items()}
+# The timing pass runs `bench.py --steps 20 --warmup 5` with its 0.5 s clock ramp: the average over ALL dispatches includes the
+# launches of the ramp, made while the card is still raising its clocks.  What bench.py times is the last 20 dispatches.
+TIMED = 20
+summary["timed_steps"] = {}
+for n, v in tr.items():
+    if len(v) > 2 * TIMED:
+        last = [d for _, d in sorted(zip(starts[n], v))][-TIMED:]
+        summary["timed_steps"][n] = {"dispatches": TIMED, "avg_ns": sum(last) / TIMED, "min_ns": min(last), "max_ns": max(last)}
 
 # PMC passes: average per dispatch per kernel
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_clk"):
@@ -78,6 +88,9 @@ with open(outp + ".txt", "w") as o:
     o.write("== rocprofv3 --kernel-trace --stats: the product's kernels (everything else in the process -- torch kernels that synthesise the frames, outside the timed region: %s) ==\n" % json.dumps(summary["other_kernels_outside_the_timed_region"]))
     for k in summary["kernel_stats_top"]:
         o.write("%-112s calls=%-6d avg=%10.1f us  total=%10.3f ms  %5.1f%%\n" % (k["name"], k["calls"], k["avg_ns"] / 1e3, k["total_ns"] / 1e6, k["pct"]))
+    o.write("\n== the last %d dispatches of each hot kernel = the K timed steps of `bench.py --steps 20 --warmup 5` (the averages above include the ~450 launches of the 0.5 s clock ramp, made while the clocks are still rising) ==\n" % TIMED)
+    for n, v in summary["timed_steps"].items():
+        o.write("%-112s avg=%10.1f us  min=%8.1f  max=%8.1f\n" % (n, v["avg_ns"] / 1e3, v["min_ns"] / 1e3, v["max_ns"] / 1e3))
     o.write("\n== our kernels (per dispatch) ==\n")
     for n, v in summary["our_kernels_trace"].items():
         o.write("%s\n   %s\n" % (n, json.dumps(v)))

@@ -4,14 +4,17 @@
 //   k_apply_s4<FMT,MASK>     UltraHdr::applyGainMap hot loop, scale 4, FAST arithmetic (:427-496)
 //   k_apply_px<FMT,EXACT>    same loop, any integer scale / any alignment / EXACT arithmetic
 //   k_apply_s4_est, k_apply_px_est, k_apply_resolve   EXACT arithmetic as an f32 estimate + the exact path on the pixels in doubt
+//   k_apply_lut_s4, k_apply_lut   the loops with the reference's LUT accessors (opt-in LUT mode)
 //   k_tonemap_*              UltraHdr::toneMap                    (:517-558)
 //   k_convert_yuv<ALIGNED>   JpegR::convertYuv + transformYuv420  (lib/src/jpegr.cpp:1199-1203,
 //                                                                  lib/src/gainmapmath.cpp:483-520)
 //   k_effect, k_effect_rot   crop / mirror / rotate / resize      (lib/src/editorhelper.cpp:26-360)
 //   k_eval_transfer          scalar transfer functions over arrays (diagnostics for the exhaustive tests)
 //
-// All of it is pointwise byte/float work: no MFMA.  Measured, generate and apply are bound by VALU /
-// special-function issue rather than by HBM.  Design rules followed here:
+// All of it is pointwise byte/float work: no MFMA.  Measured: generate runs within 10 % of what its own
+// read pattern reaches on the same box, apply 3-8 % above a build of itself without arithmetic (its writes cap at 5.5 TB/s);
+// both got there by taking work off the VALU -- an f32 pre-filter with the exact path deferred to a resolve kernel in generate,
+// both transfer functions as line-segment tables in LDS in apply.  Design rules followed here:
 //   * one wave64 reads whole contiguous row segments (16 B/lane for P010, 8 B/lane for 8-bit luma),
 //     stores are 16 B/lane; no LDS round trip is needed because every input byte is consumed by
 //     exactly one lane;
@@ -924,7 +927,7 @@ __device__ __forceinline__ F3 hdr_oetf(F3 e) {
     else { e.x = hlg_oetf_fast(e.x); e.y = hlg_oetf_fast(e.y); e.z = hlg_oetf_fast(e.z); }
   } else if (FMT == 2) {
     if (EXACT) { float ch[3] = {e.x, e.y, e.z}; pq_oetf_guarded_n<3>(ch); e.x = ch[0]; e.y = ch[1]; e.z = ch[2]; }
-    else { e.x = pq_oetf_fast(e.x); e.y = pq_oetf_fast(e.y); e.z = pq_oetf_fast(e.z); }
+    else { e.x = pq_oetf_est(e.x); e.y = pq_oetf_est(e.y); e.z = pq_oetf_est(e.z); }   // (within 3e-4 of a code; pq_oetf_fast: 0.3)
   }
   return e;
 }

@@ -559,18 +559,18 @@ __device__ __forceinline__ void exact_pair(const GenConsts& c, const GenImage& i
 #else
 #define UHDR_GEN_OCC
 #endif
-template <int TF, bool ALIGNED, bool LUT, bool FILTER, int TILES, bool DEFER>
-__global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OCC k_generate(const GenConsts c, const GenBatch b) {
+template <int TF, bool ALIGNED, bool LUT, bool FILTER, int TILES, bool DEFER, int BLOCK = UHDR_GEN_BLOCK>
+__global__ void __launch_bounds__(BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OCC k_generate(const GenConsts c, const GenBatch b) {
   // LUT mode: block-private copies of the two tables (4 KiB + 16 KiB), so every lookup is an LDS gather
   __shared__ float s_srgb[LUT ? kLutSrgbInvN : 1];
   __shared__ float s_hdr[(LUT && TF != 0) ? kLutHlgInvN : 1];
-  __shared__ float s_kept[(FILTER && DEFER) ? TILES * 2 * UHDR_GEN_BLOCK : 1];  // FILTER: every thread's gains, for the candidate pass
+  __shared__ float s_kept[(FILTER && DEFER) ? TILES * 2 * BLOCK : 1];  // FILTER: every thread's gains, for the candidate pass
   if (LUT) {
-    for (uint32_t i = threadIdx.x; i < kLutSrgbInvN / 4u; i += UHDR_GEN_BLOCK)
+    for (uint32_t i = threadIdx.x; i < kLutSrgbInvN / 4u; i += BLOCK)
       reinterpret_cast<float4*>(s_srgb)[i] = reinterpret_cast<const float4*>(c.lut + kLutSrgbInv)[i];
     if (TF != 0) {
       const float4* src = reinterpret_cast<const float4*>(c.lut + (TF == 1 ? kLutHlgInv : kLutPqInv));
-      for (uint32_t i = threadIdx.x; i < kLutHlgInvN / 4u; i += UHDR_GEN_BLOCK) reinterpret_cast<float4*>(s_hdr)[i] = src[i];
+      for (uint32_t i = threadIdx.x; i < kLutHlgInvN / 4u; i += BLOCK) reinterpret_cast<float4*>(s_hdr)[i] = src[i];
     }
     __syncthreads();
   }
@@ -590,11 +590,11 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OC
   float amin = __builtin_inff(), amax = -__builtin_inff();   // over all gains (estimates included)
   uint32_t kept_exact = 0u, kept_valid = 0u, kept_doubt = 0u;   // 2 bits per tile
 
-  // each block walks TILES consecutive spans of UHDR_GEN_BLOCK pairs: fewer, longer-lived waves
+  // each block walks TILES consecutive spans of BLOCK pairs: fewer, longer-lived waves
   // (wave launch + descriptor fetch is a measurable share of a ~10 us wave)
 #pragma unroll 1
   for (uint32_t t = 0; t < (uint32_t)TILES; ++t) {
-    const uint32_t idx = (blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x;
+    const uint32_t idx = (blk * (uint32_t)TILES + t) * (uint32_t)BLOCK + threadIdx.x;
     if (idx >= total) break;
     const uint32_t my = idx / pairs_per_row;
     const uint32_t pr = idx - my * pairs_per_row;
@@ -615,8 +615,8 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OC
       const uint32_t dm = (ex >> 2) & (two ? 3u : 1u);
       kept_doubt |= dm << (2u * t);
       if (stats) {
-        s_kept[(2u * t) * UHDR_GEN_BLOCK + threadIdx.x] = gn[0];
-        s_kept[(2u * t + 1u) * UHDR_GEN_BLOCK + threadIdx.x] = gn[1];
+        s_kept[(2u * t) * BLOCK + threadIdx.x] = gn[0];
+        s_kept[(2u * t + 1u) * BLOCK + threadIdx.x] = gn[1];
         const uint32_t valid = (two ? 3u : 1u) & ~dm;
         kept_exact |= (ex & 3u) << (2u * t);
         kept_valid |= valid << (2u * t);
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OC
         for (uint32_t k = 0; k < 2u; ++k) {
           const uint32_t bit = 1u << (2u * t + k);
           if ((kept_valid & bit) && !(kept_exact & bit)) {
-            const float a = s_kept[(2u * t + k) * UHDR_GEN_BLOCK + threadIdx.x], slack = e * __builtin_fabsf(a);
+            const float a = s_kept[(2u * t + k) * BLOCK + threadIdx.x], slack = e * __builtin_fabsf(a);
             if ((a - slack <= min_hi) || (a + slack >= max_lo)) cand |= 1u << t;
           }
         }
@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(UHDR_GEN_BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OC
       for (uint32_t t = 0; t < (uint32_t)TILES; ++t) {
         const uint32_t flags = ((kept_doubt >> (2u * t)) & 3u) | (((cand >> t) & 1u) << 2);
         const uint32_t pos = base + (uint32_t)__builtin_popcountll(mask[t] & ((1ull << lane) - 1ull));
-        if (flags != 0u && pos < kStatCap) lw[pos] = (((blk * (uint32_t)TILES + t) * (uint32_t)UHDR_GEN_BLOCK + threadIdx.x) << 3) | flags;
+        if (flags != 0u && pos < kStatCap) lw[pos] = (((blk * (uint32_t)TILES + t) * (uint32_t)BLOCK + threadIdx.x) << 3) | flags;
         base += (uint32_t)__builtin_popcountll(mask[t]);
       }
     }
@@ -846,7 +846,16 @@ static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n
       else hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES, true>), g4, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
     } else {
       if (c.stat_keys != nullptr) return hipErrorInvalidValue;   // statistics of a filtered launch need the workspace
-      hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+      // a launch whose waves are all resident at once, from one 4K image up (1013 blocks of 256 threads): 128-thread blocks give
+      // the dispatcher twice the workgroups to spread -- same-box A/B: one 4K frame 11.9 -> 11.0 us; one 1080p frame (254 blocks)
+      // is better off as it is (6.9 against 7.9 us)
+      const unsigned h1 = (total + 127u) / 128u;
+      if ((uint64_t)h1 * (uint64_t)n >= 2000u) {
+        const dim3 gh = UHDR_GEN_IMAGE_MAJOR ? dim3(h1, (unsigned)n, 1) : dim3((unsigned)n, h1, 1);
+        hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false, 128>), gh, dim3(128, 1, 1), 0, s, c, b);
+      } else {
+        hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+      }
     }
   } else if (small) {
     hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);

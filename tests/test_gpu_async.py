@@ -167,3 +167,36 @@ def test_host_memory_callers_on_their_own_streams_do_not_share_staging(hip, orc)
         oimg = orc.yuv420_image(ocv, w, h, 0)
         assert olib.orc_convertYuv(C.byref(oimg), 0, 1) == 0
         assert np.array_equal(cv, ocv)
+
+
+def test_exact_apply_is_graph_capturable_once_its_workspace_exists(hip, orc):
+    """EXACT apply (estimate + resolve, two launches and a per-stream workspace) inside a captured graph: the workspace is
+    allocated by the first call on the stream, outside the capture; the replays give the oracle's bytes"""
+    from tests.gpu_util import to_host
+    lib = hip.load()
+    n, w, h = 3, 256, 128
+    keep, ya, pa, ma, oa, host = _batch(hip, orc, n, w, h, 640)
+    md = hip.Metadata()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s = C.c_void_p(side.cuda_stream)
+        assert lib.uhdr_hip_generate_gainmap_batch(n, ya, pa, hip.TF_HLG, C.byref(md), ma, 0, None, s) == 0
+        assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX, oa, hip.APPLY_EXACT, s) == 0
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for _, _, _, do in host:
+        do.zero_()
+    with torch.cuda.graph(g, stream=side):
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX, oa, hip.APPLY_EXACT, s) == 0
+    torch.cuda.synchronize()
+    assert all(int(do.sum()) == 0 for _, _, _, do in host), "capture must not execute the kernels"
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for p010, yuv, dm, do in host:
+        st, omap, omd = orc.generate("orc_", orc.yuv420_image(yuv, w, h, 0), orc.p010_image(p010, w, h, 2), 1)
+        st, ref, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, 0), omap, omd, orc.OUT_HDR_HLG, FLT_MAX)
+        assert np.array_equal(to_host(do, w * h * 4), ref.view(np.uint8).ravel())

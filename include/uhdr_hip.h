@@ -94,7 +94,9 @@ extern "C" {
  *   FAST  : transfer functions from line-segment tables in LDS (special-function unit where a call can exceed 1.0); every
  *           10-bit channel within 1 LSB and every F16 channel within 1 half-ULP of the reference CPU path;
  *   EXACT : the same bytes as the reference CPU path: its float/double promotion pattern replayed with correctly
- *           rounded pow/exp/log/exp2, on the pixels an f32 estimate cannot settle (HDR_PQ: on every pixel).
+ *           rounded pow/exp/log/exp2, on the pixels an f32 estimate with measured error bounds cannot settle (~1 %).
+ *           The first EXACT call on a stream (and the first with larger images) allocates that stream's list workspace;
+ *           after it the call only enqueues two kernels and can be captured into a graph like the others.
  * generate/tonemap/convert_yuv have a single, bit-exact mode. */
 #define UHDR_HIP_APPLY_FAST 0
 #define UHDR_HIP_APPLY_EXACT 1

@@ -69,6 +69,9 @@ struct DeviceState : StageSet {
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
 std::mutex g_host_mu;               // serialises the codec's host-staged calls (they share the device's own staging set)
+// a kernel and the resolve kernel behind it share a per-stream workspace: the pair is enqueued as one unit, so that two host threads
+// using the same stream cannot interleave their launches (they would read each other's lists)
+std::mutex g_pair_mu;
 std::mutex g_jpegr_mu;              // serialises uhdr_hip_jpegr_decode (slots 8-10), which calls the entry points above
 std::map<int, DeviceState> g_dev;
 
@@ -1788,6 +1791,8 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
     const bool small = generate_is_small(c, m);
     if (small && keys != nullptr) filter = false;
     const bool resolve = filter && aligned && !lut && !small;
+    std::unique_lock<std::mutex> pair_lk(g_pair_mu, std::defer_lock);
+    if (resolve) pair_lk.lock();
     if (resolve) {
       std::lock_guard<std::mutex> lk(g_mu);
       uint32_t** wp = nullptr;
@@ -1863,8 +1868,10 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
     }
     // EXACT: f32 estimate, then the exact path on the pixels it leaves in doubt.  The estimate's error bounds are measured for
     // |log2 boost| <= 32 (tests/test_gpu_exact_filter.py); beyond that every pixel takes the exact path.
+    std::unique_lock<std::mutex> pair_lk(g_pair_mu, std::defer_lock);
     if (writes && apply_mode == UHDR_HIP_APPLY_EXACT && (uint64_t)c.width * c.height <= 0xFFFFFFFFull &&
         std::fabs(c.log2_min_d) <= 32.0 && std::fabs(c.log2_max_d) <= 32.0) {
+      pair_lk.lock();
       const uint32_t cap = ex_list_cap((uint64_t)c.width * c.height);
       const size_t need = ((size_t)kMaxChunk * kExHdrWords + (size_t)m * kExLists * cap) * 4u;
       std::lock_guard<std::mutex> lk(g_mu);

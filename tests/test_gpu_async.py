@@ -200,3 +200,40 @@ def test_exact_apply_is_graph_capturable_once_its_workspace_exists(hip, orc):
         st, omap, omd = orc.generate("orc_", orc.yuv420_image(yuv, w, h, 0), orc.p010_image(p010, w, h, 2), 1)
         st, ref, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, 0), omap, omd, orc.OUT_HDR_HLG, FLT_MAX)
         assert np.array_equal(to_host(do, w * h * 4), ref.view(np.uint8).ravel())
+
+
+def test_two_host_threads_on_one_stream(hip, orc):
+    """generate (with its resolve kernel) and EXACT apply (estimate + resolve) are pairs of launches that share a workspace of the
+    stream: two threads enqueueing on the SAME stream must not interleave inside a pair"""
+    from tests.gpu_util import to_host
+    lib = hip.load()
+    w, h, n = 3840, 2160, 9          # nine 4K frames: a launch large enough for the deferred (resolve) form of generate
+    sets = [_batch(hip, orc, n, w, h, 2000 + 100 * t) for t in range(2)]
+    shared = torch.cuda.Stream()
+    errs = []
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            keep, ya, pa, ma, oa, host = sets[t]
+            md = hip.Metadata()
+            s = C.c_void_p(shared.cuda_stream)
+            for _ in range(8):
+                assert lib.uhdr_hip_generate_gainmap_batch(n, ya, pa, hip.TF_HLG, C.byref(md), ma, 0, None, s) == 0
+                assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX, oa, hip.APPLY_EXACT, s) == 0
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for t in range(2):
+        for p010, yuv, dm, do in (sets[t][5][0], sets[t][5][n - 1]):
+            st, omap, omd = orc.generate("orc_", orc.yuv420_image(yuv, w, h, 0), orc.p010_image(p010, w, h, 2), 1, threads=16)
+            assert np.array_equal(to_host(dm, omap.size).reshape(omap.shape), omap)
+            st, ref, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, 0), omap, omd, orc.OUT_HDR_HLG, FLT_MAX, threads=16)
+            assert np.array_equal(to_host(do, w * h * 4), ref.view(np.uint8).ravel())

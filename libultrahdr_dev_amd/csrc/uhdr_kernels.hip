@@ -2258,12 +2258,8 @@ __device__ __forceinline__ size_t fx_src_index(const FxJob& j, uint32_t i, uint3
   }
 }
 
-__global__ void __launch_bounds__(256) k_effect(const FxJobs jobs) {
-  const FxJob& j = jobs.job[blockIdx.z];
-  const uint32_t i = blockIdx.y;
-  const uint32_t c0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-  if (i >= j.rows || c0 >= j.cols) return;
-  uint8_t* d = j.dst + (size_t)i * j.dst_stride + c0;
+// 4 output bytes at column c0 of output row i, gathered one by one (any operation, any alignment)
+__device__ __forceinline__ void fx_quad(const FxJob& j, uint32_t i, uint32_t c0, uint8_t* d) {
   if (c0 + 4u <= j.cols && ((reinterpret_cast<uintptr_t>(d) & 3u) == 0u)) {
     uint32_t v = 0;
 #pragma unroll
@@ -2273,13 +2269,99 @@ __global__ void __launch_bounds__(256) k_effect(const FxJobs jobs) {
     for (uint32_t k = 0; k < 4u && c0 + k < j.cols; ++k) d[k] = j.src[fx_src_index(j, i, c0 + k)];
   }
 }
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_amdgcn_perm(v, v, 0x00010203u); }
+
+// One thread produces 16 consecutive output bytes of one plane row.  Copies, flips and the half turn move whole 16-byte pieces
+// when both sides are aligned (the mirrored ones with their bytes reversed: four v_perm_b32); resize gathers from a copy of the
+// source stretch in LDS.
+__global__ void __launch_bounds__(256) k_effect(const FxJobs jobs) {
+  const FxJob& j = jobs.job[blockIdx.z];
+  const uint32_t cb = blockIdx.x * 4096u;                 // the block's first output column
+  if (cb >= j.cols) return;                               // (block-uniform)
+  const uint32_t c0 = cb + threadIdx.x * 16u;
+  const bool active = c0 < j.cols;
+  // resize, at most 4 source bytes per output byte: the block's stretch of the source row is copied into LDS with dword loads and
+  // gathered from there (16 byte loads per thread made the kernel load-instruction bound: 44 us for a 4K -> 5760x3240 resize)
+  __shared__ uint32_t s_row[(4096u * 4u + 16u) / 4u];
+  const bool lds_resize = j.op == FX_RESIZE && j.col_num <= 4u * j.col_den && (uint64_t)j.rows * j.row_num < (1ull << 32) &&
+                          (uint64_t)j.cols * j.col_num < (1ull << 32);
+  for (uint32_t i = blockIdx.y; i < j.rows; i += gridDim.y) {   // (rows beyond the grid's 65535 by striding)
+    uint8_t* d = j.dst + (size_t)i * j.dst_stride + c0;
+    const bool whole = active && c0 + 16u <= j.cols && (reinterpret_cast<uintptr_t>(d) & 15u) == 0u;
+    if (lds_resize) {
+      const uint8_t* srow = j.src + (size_t)(i * j.row_num / j.row_den) * j.src_stride;
+      const uint32_t c_last = min(cb + 4095u, j.cols - 1u);
+      const uint32_t s_lo = cb * j.col_num / j.col_den, s_hi = min(c_last * j.col_num / j.col_den, j.in_w - 1u);
+      const uint8_t* first = srow + s_lo;
+      const uint32_t off0 = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 3u);
+      const uint8_t* p_al = first - off0;
+      const uint32_t nbytes = s_hi - s_lo + 1u + off0;
+      const uint8_t* row_end = srow + j.in_w;
+      __syncthreads();                                      // (the previous row's gathers are done)
+      for (uint32_t k = threadIdx.x; k < (nbytes + 3u) / 4u; k += 256u) {
+        const uint8_t* p = p_al + 4u * k;
+        uint32_t v;
+        if (p >= srow && p + 4 <= row_end) v = *reinterpret_cast<const uint32_t*>(p);
+        else {                                              // the row's first / last bytes: never read outside [srow, row_end)
+          v = 0;
+          for (int b = 0; b < 4; ++b) if (p + b >= srow && p + b < row_end) v |= (uint32_t)p[b] << (8 * b);
+        }
+        s_row[k] = v;
+      }
+      __syncthreads();
+      if (active) {
+        const uint8_t* lrow = reinterpret_cast<const uint8_t*>(s_row) + off0;
+        const uint32_t step = j.col_num / j.col_den, rem = j.col_num - step * j.col_den;
+        const uint32_t p0 = c0 * j.col_num;
+        uint32_t q = p0 / j.col_den, r = p0 - q * j.col_den;
+        q -= s_lo;
+        if (whole) {
+          uint32_t w[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v |= (uint32_t)lrow[q] << (8 * k);
+              q += step; r += rem;
+              if (r >= j.col_den) { r -= j.col_den; ++q; }
+            }
+            w[g] = v;
+          }
+          *reinterpret_cast<uint4*>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+          for (uint32_t k = 0; k < 16u && c0 + k < j.cols; ++k) {
+            d[k] = lrow[q];
+            q += step; r += rem;
+            if (r >= j.col_den) { r -= j.col_den; ++q; }
+          }
+        }
+      }
+      continue;
+    }
+    if (!active) continue;
+    if (whole && (j.op == FX_COPY || j.op == FX_FLIP_V || j.op == FX_FLIP_H || j.op == FX_ROT180)) {
+      const bool rev = j.op == FX_FLIP_H || j.op == FX_ROT180;
+      const uint32_t sr = j.op == FX_COPY || j.op == FX_FLIP_H ? i : (j.op == FX_FLIP_V ? j.rows - i - 1u : j.in_h - i - 1u);
+      const uint8_t* sp = j.src + (size_t)sr * j.src_stride + (rev ? j.in_w - c0 - 16u : c0);
+      if ((reinterpret_cast<uintptr_t>(sp) & 15u) == 0u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sp);
+        *reinterpret_cast<uint4*>(d) = rev ? make_uint4(bswap32(v.w), bswap32(v.z), bswap32(v.y), bswap32(v.x)) : v;
+        continue;
+      }
+    }
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4u; ++q)
+      if (c0 + 4u * q < j.cols) fx_quad(j, i, c0 + 4u * q, d + 4u * q);
+  }
+}
 
 // 90 / 270 degree rotations are transposes: a 64x64 source tile is read row-wise (coalesced), parked in LDS and
 // written row-wise in the rotated orientation, so neither side of the copy walks a column of the image in HBM
 // (the plain gather above reaches 0.45 TB/s on a 4K frame, this one is limited by launch latency).
 __global__ void __launch_bounds__(256) k_effect_rot(const FxJobs jobs) {
   const FxJob& j = jobs.job[blockIdx.z];
-  __shared__ uint8_t tile[64][68];
+  __shared__ __attribute__((aligned(4))) uint8_t tile[64][68];
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;  // output tile origin (row, col)
   if (i0 >= (int)j.rows || j0 >= (int)j.cols) return;
   const bool r90 = j.op == FX_ROT90;
@@ -2291,12 +2373,18 @@ __global__ void __launch_bounds__(256) k_effect_rot(const FxJobs jobs) {
   for (int p = 0; p < 4; ++p) {
     const int ry = p * 16 + (t >> 4), cx = 4 * (t & 15);
     const int sr = row_base + ry;
+    const int sc0 = col_base + cx;
+    const uint8_t* sp = j.src + (size_t)(sr < 0 ? 0 : sr) * j.src_stride + sc0;
+    if (sr >= 0 && sr < (int)j.in_h && sc0 >= 0 && sc0 + 3 < (int)j.in_w && (reinterpret_cast<uintptr_t>(sp) & 3u) == 0u) {
+      *reinterpret_cast<uint32_t*>(&tile[ry][cx]) = *reinterpret_cast<const uint32_t*>(sp);   // (a row of the tile is 68 bytes: cx a multiple of 4)
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int sc = col_base + cx + k;
-      uint8_t v = 0;
-      if (sr >= 0 && sr < (int)j.in_h && sc >= 0 && sc < (int)j.in_w) v = j.src[(size_t)sr * j.src_stride + sc];
-      tile[ry][cx + k] = v;
+      for (int k = 0; k < 4; ++k) {
+        const int sc = sc0 + k;
+        uint8_t v = 0;
+        if (sr >= 0 && sr < (int)j.in_h && sc >= 0 && sc < (int)j.in_w) v = j.src[(size_t)sr * j.src_stride + sc];
+        tile[ry][cx + k] = v;
+      }
     }
   }
   __syncthreads();
@@ -2325,7 +2413,7 @@ hipError_t launch_effect(const FxJobs& j, hipStream_t s) {
     hipLaunchKernelGGL(k_effect_rot, dim3((cols + 63u) / 64u, (rows + 63u) / 64u, (unsigned)j.n), dim3(256), 0, s, j);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_effect, dim3(((cols + 3u) / 4u + 255u) / 256u, rows, (unsigned)j.n), dim3(256), 0, s, j);
+  hipLaunchKernelGGL(k_effect, dim3(((cols + 15u) / 16u + 255u) / 256u, rows < 65535u ? rows : 65535u, (unsigned)j.n), dim3(256), 0, s, j);
   return hipGetLastError();
 }
 

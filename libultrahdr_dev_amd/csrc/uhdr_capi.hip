@@ -460,6 +460,9 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
   c.ex_ws = nullptr;
   c.ex_cap = 0;
   c.cells_per_thread = 8;
+  c.walk_blocks = 0;
+  c.step_x = c.step_y = 0;
+  c.edge_rows = 4;
   return c;
 }
 AppImage app_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map, void* dst) {
@@ -474,8 +477,8 @@ AppImage app_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map, voi
   return a;
 }
 bool app_fast_s4(const AppConsts& c, const AppImage& a) {
-  // the fast kernel indexes planes with 32-bit offsets
-  if ((uint64_t)a.y_stride * c.height >= (1ull << 32) || (uint64_t)c.width * c.height >= (1ull << 31)) return false;
+  // the fast kernels index planes with 32-bit byte offsets (the widest output is 8 bytes per pixel)
+  if ((uint64_t)a.y_stride * c.height >= (1ull << 32) || (uint64_t)c.width * c.height >= (1ull << 29)) return false;
   return c.scale == 4 && c.width == 4u * c.map_w && c.height == 4u * c.map_h && al(a.y, 4) && a.y_stride % 4u == 0 &&
          al(a.u, 2) && al(a.v, 2) && a.c_stride % 2u == 0 && al(a.dst, 16);
 }

@@ -56,6 +56,9 @@ constexpr float kP3GCr = kP3YR * kP3Cr / kP3YG;
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+// one half of a pair in both lanes of a packed operand (VOP3P op_sel / op_sel_hi: no instruction)
+__device__ __forceinline__ f2 bc_lo(f2 v) { return __builtin_shufflevector(v, v, 0, 0); }
+__device__ __forceinline__ f2 bc_hi(f2 v) { return __builtin_shufflevector(v, v, 1, 1); }
 
 // packed add / mul with the VOP3P clamp modifier: both lanes saturate to [0, 1] for free (hipcc only
 // folds clamps into scalar ops, so these two are spelled out)
@@ -1124,25 +1127,33 @@ __device__ __forceinline__ float cvt_byte(uint32_t w) { return (float)((w >> (8 
 // so that every read has a whole iteration (~50 VALU instructions) between issue and use.  sched_barrier keeps the stages apart.
 struct PairF { f2 c[3]; f2 factor; float2 e[6]; };
 struct PairM { f2 s[3]; float2 e[6]; };
-template <int FMT, bool INTERIOR>
+// the chroma terms of the BT.601 YUV->RGB of gainmapmath.cpp:184-202 for one row of two chroma samples, scaled like the luma
+struct ChromaRow { f2 crv, ngs, cbu; };
+__device__ __forceinline__ ChromaRow chroma_row(uint32_t uu, uint32_t vv) {
+  constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
+  const f2 uf = (f2){cvt_byte<0>(uu), cvt_byte<1>(uu)};
+  const f2 vf = (f2){cvt_byte<0>(vv), cvt_byte<1>(vv)};
+  ChromaRow o;
+  o.crv = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
+  o.cbu = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
+  o.ngs = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
+  return o;
+}
+template <int FMT>
 __device__ __forceinline__ void apply_cell_piped(const AppConsts& c, void* dst, uint32_t cx, uint32_t cy,
                                                  const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
-                                                 float m1, float m2, float m3, float m4, int tbl, uint32_t slot8, const char* lut) {
+                                                 float m1, float m2, float m3, float m4, uint32_t slot8, const char* lut) {
   typedef ApplyTab<FMT, false> T;
-  constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
-  f2 crv2[2], ngs2[2], cbu2[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const f2 uf = (f2){cvt_byte<0>(uu[r]), cvt_byte<1>(uu[r])};
-    const f2 vf = (f2){cvt_byte<0>(vv[r]), cvt_byte<1>(vv[r])};
-    crv2[r] = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
-    cbu2[r] = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
-    ngs2[r] = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
-  }
+  // only the chroma row in use is kept as floats (the second row's six values are formed when rows 2 and 3 start): the cell runs
+  // at the register budget of four waves per SIMD
+  ChromaRow cr = chroma_row(uu[0], vv[0]);
   const float a255 = c.fast.A255;
-  const float base = __builtin_fmaf(m1, a255, c.fast.B);
-  const float d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
-  const float* wt = c_idw4 + tbl * 64;
+  // The four per-cell scalars of the exponent travel as two register PAIRS whose halves v_pk_fma_f32 broadcasts through op_sel: a
+  // scalar splat by the compiler occupies a pair as well, with an undefined upper register -- which the allocator is free to
+  // place on a register an outstanding load of the next cell will write, and the s_waitcnt in front of the fma then waits for
+  // that load (seen in the ISA: one full trip to HBM per cell).
+  f2 d23 = (f2){m2 - m1, m3 - m1}, d4b = (f2){m4 - m1, __builtin_fmaf(m1, a255, c.fast.B)};
+  asm("" : "+v"(d23), "+v"(d4b));   // (opaque: or the pairs are taken apart again)
   PairF pf[2];
   PairM pm[2];
   uint32_t px[4];
@@ -1150,23 +1161,19 @@ __device__ __forceinline__ void apply_cell_piped(const AppConsts& c, void* dst, 
   for (int k = 0; k < 10; ++k) {
     if (k < 8) {  // ---- F(k)
       const int oy = k >> 1, pr = k & 1;
-      f2 w1, w2, w3;
-      if (INTERIOR) {
-        w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}; w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
-        w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
-      } else {
-        const float* p0 = wt + oy * 16 + pr * 8;
-        w1 = (f2){p0[1], p0[5]} * splat(a255); w2 = (f2){p0[2], p0[6]} * splat(a255); w3 = (f2){p0[3], p0[7]} * splat(a255);
-      }
+      // sampleMap's standard weights (the walk leaves the cells of the last column / row to apply_cell_edge), times A / 255: SGPR pairs
+      const f2 w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}, w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
+      const f2 w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
+      if (k == 4) cr = chroma_row(uu[1], vv[1]);
       PairF& f = pf[k & 1];
-      const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
+      const f2 E = pk_fma(bc_lo(d4b), w3, pk_fma(bc_hi(d23), w2, pk_fma(bc_lo(d23), w1, bc_hi(d4b))));
       const f2 yraw = pr ? (f2){cvt_byte<2>(yrow[oy]), cvt_byte<3>(yrow[oy])} : (f2){cvt_byte<0>(yrow[oy]), cvt_byte<1>(yrow[oy])};
       if (pr) {
-        f.c[0] = pk_fma_sat_bc<1>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<1>(yraw, splat(k255), ngs2[oy >> 1]);
-        f.c[2] = pk_fma_sat_bc<1>(yraw, splat(k255), cbu2[oy >> 1]);
+        f.c[0] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.crv); f.c[1] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.ngs);
+        f.c[2] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.cbu);
       } else {
-        f.c[0] = pk_fma_sat_bc<0>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<0>(yraw, splat(k255), ngs2[oy >> 1]);
-        f.c[2] = pk_fma_sat_bc<0>(yraw, splat(k255), cbu2[oy >> 1]);
+        f.c[0] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.crv); f.c[1] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.ngs);
+        f.c[2] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.cbu);
       }
       f.factor = exp2_2(E);
 #pragma unroll
@@ -1202,8 +1209,8 @@ __device__ __forceinline__ void apply_cell_piped(const AppConsts& c, void* dst, 
       px[2 * pr] = pack10_bits(o[0], o[2], o[4]);
       px[2 * pr + 1] = pack10_bits(o[1], o[3], o[5]);
       if (pr) {
-        const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
-        st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(dst) + pix0), make_uint4(px[0], px[1], px[2], px[3]));
+        const uint32_t off = ((4u * cy + oy) * c.width + 4u * cx) * 4u;  // (a 32-bit byte offset: app_fast_s4 keeps the image below 4 GiB)
+        st_stream(reinterpret_cast<uint4*>(static_cast<char*>(dst) + off), make_uint4(px[0], px[1], px[2], px[3]));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1215,24 +1222,18 @@ __device__ __forceinline__ void apply_cell_piped(const AppConsts& c, void* dst, 
 // OETF where there is one, the pack.
 constexpr uint32_t kXchSecond = 72;    // in uint4: the second halves start 1152 bytes into the wave's exchange area ...
 constexpr uint32_t kXchPerWave = 136;  // ... of 2176 bytes
-template <int FMT, bool INTERIOR, bool MASK>
+template <int FMT, bool MASK>
 __device__ __forceinline__ void apply_cell_piped1(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
                                                   const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
-                                                  float m1, float m2, float m3, float m4, int tbl, const char* lut, uint4* xch) {
-  constexpr float kCrS = kP3Cr * k255, kCbS = kP3Cb * k255, kGCbS = kP3GCb * k255, kGCrS = kP3GCr * k255;
-  f2 crv2[2], ngs2[2], cbu2[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const f2 uf = (f2){cvt_byte<0>(uu[r]), cvt_byte<1>(uu[r])};
-    const f2 vf = (f2){cvt_byte<0>(vv[r]), cvt_byte<1>(vv[r])};
-    crv2[r] = pk_fma(vf, splat(kCrS), splat(-128.0f * kCrS));
-    cbu2[r] = pk_fma(uf, splat(kCbS), splat(-128.0f * kCbS));
-    ngs2[r] = pk_fma(uf, splat(-kGCbS), pk_fma(vf, splat(-kGCrS), splat(128.0f * kGCbS + 128.0f * kGCrS)));
-  }
+                                                  float m1, float m2, float m3, float m4, const char* lut, uint4* xch, uint32_t dup_lane) {
+  ChromaRow cr = chroma_row(uu[0], vv[0]);
   const float a255 = c.fast.A255;
-  const float base = __builtin_fmaf(m1, a255, c.fast.B);
-  const float d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
-  const float* wt = c_idw4 + tbl * 64;
+  // The four per-cell scalars of the exponent travel as two register PAIRS whose halves v_pk_fma_f32 broadcasts through op_sel: a
+  // scalar splat by the compiler occupies a pair as well, with an undefined upper register -- which the allocator is free to
+  // place on a register an outstanding load of the next cell will write, and the s_waitcnt in front of the fma then waits for
+  // that load (seen in the ISA: one full trip to HBM per cell).
+  f2 d23 = (f2){m2 - m1, m3 - m1}, d4b = (f2){m4 - m1, __builtin_fmaf(m1, a255, c.fast.B)};
+  asm("" : "+v"(d23), "+v"(d4b));   // (opaque: or the pairs are taken apart again)
   PairF pf[2];
   PairOut po[2];
   const uint32_t lane = threadIdx.x & 63u;
@@ -1240,23 +1241,19 @@ __device__ __forceinline__ void apply_cell_piped1(const AppConsts& c, const AppI
   for (int k = 0; k < 9; ++k) {
     if (k < 8) {  // ---- F(k)
       const int oy = k >> 1, pr = k & 1;
-      f2 w1, w2, w3;
-      if (INTERIOR) {
-        w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}; w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
-        w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
-      } else {
-        const float* p0 = wt + oy * 16 + pr * 8;
-        w1 = (f2){p0[1], p0[5]} * splat(a255); w2 = (f2){p0[2], p0[6]} * splat(a255); w3 = (f2){p0[3], p0[7]} * splat(a255);
-      }
+      // sampleMap's standard weights (the walk leaves the cells of the last column / row to apply_cell_edge), times A / 255: SGPR pairs
+      const f2 w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}, w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
+      const f2 w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
+      if (k == 4) cr = chroma_row(uu[1], vv[1]);
       PairF& f = pf[k & 1];
-      const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
+      const f2 E = pk_fma(bc_lo(d4b), w3, pk_fma(bc_hi(d23), w2, pk_fma(bc_lo(d23), w1, bc_hi(d4b))));
       const f2 yraw = pr ? (f2){cvt_byte<2>(yrow[oy]), cvt_byte<3>(yrow[oy])} : (f2){cvt_byte<0>(yrow[oy]), cvt_byte<1>(yrow[oy])};
       if (pr) {
-        f.c[0] = pk_fma_sat_bc<1>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<1>(yraw, splat(k255), ngs2[oy >> 1]);
-        f.c[2] = pk_fma_sat_bc<1>(yraw, splat(k255), cbu2[oy >> 1]);
+        f.c[0] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.crv); f.c[1] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.ngs);
+        f.c[2] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.cbu);
       } else {
-        f.c[0] = pk_fma_sat_bc<0>(yraw, splat(k255), crv2[oy >> 1]); f.c[1] = pk_fma_sat_bc<0>(yraw, splat(k255), ngs2[oy >> 1]);
-        f.c[2] = pk_fma_sat_bc<0>(yraw, splat(k255), cbu2[oy >> 1]);
+        f.c[0] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.crv); f.c[1] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.ngs);
+        f.c[2] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.cbu);
       }
       f.factor = exp2_2(E);
 #pragma unroll
@@ -1297,8 +1294,9 @@ __device__ __forceinline__ void apply_cell_piped1(const AppConsts& c, const AppI
             const uint4 s0 = xch[from], s1 = xch[from + 32u];
             __builtin_amdgcn_wave_barrier();
             uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + (uint32_t)__builtin_amdgcn_readfirstlane((int)pix0));
-            st_stream(o + lane, s0);
-            st_stream(o + 64u + lane, s1);
+            // (lane dup_lane, if any, holds a copy of its left neighbour's cell -- see apply_walk_cell -- and its pieces go there)
+            st_stream(o + lane - ((lane >> 1) == dup_lane ? 2u : 0u), s0);
+            st_stream(o + 64u + lane - (32u + (lane >> 1) == dup_lane ? 2u : 0u), s1);
           } else {
             uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
             o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
@@ -1340,47 +1338,204 @@ __device__ __forceinline__ void apply_load_cell(const AppConsts& c, const AppIma
   o.mb[0] = im.map[m0 + cx]; o.mb[1] = im.map[m1 + cx]; o.mb[2] = im.map[m0 + xu]; o.mb[3] = im.map[m1 + xu];
 }
 
-// Each block copies its tables into LDS once (4 KiB + 32 KiB for the replicated stage-2 table of HLG / PQ output, 15 KiB for the
-// other outputs: two blocks of 512 threads per CU) and then walks c.cells_per_thread map cells per thread.
-#ifndef UHDR_APPLY_EXPERIMENT
-#define UHDR_APPLY_EXPERIMENT 0
-#endif
-// 1: consecutive blocks belong to different images, as in generate: the images of a launch progress together and the blocks in
-// flight spread over the whole batch's memory.  Same-box A/B, 150 steps (scripts/ab): 0.608 -> 0.576 ms per 64 frames.
-#ifndef UHDR_APPLY_IMAGE_MINOR
-#define UHDR_APPLY_IMAGE_MINOR 1
-#endif
-#ifndef UHDR_APPLY_BLOCK
-#define UHDR_APPLY_BLOCK 512
-#endif
-#ifndef UHDR_APPLY_MIN_WAVES
-#define UHDR_APPLY_MIN_WAVES 4
-#endif
-#ifndef UHDR_APPLY_CELLS
-#define UHDR_APPLY_CELLS 32
-#endif
-constexpr uint32_t kApplyBlock = UHDR_APPLY_BLOCK;
-constexpr uint32_t kApplyMaxCellsPerThread = UHDR_APPLY_CELLS;
+// Pixel rows [r0, r0 + nrows) of a cell of the last column / row (per-lane weights: the NR / NB / C tables of
+// gainmapmath.h:184-228) for the edge blocks of k_apply_s4: the arithmetic of the walk's cells, row by row in a rolled loop (a row's
+// two pixel pairs side by side).  Some 1500 cells of a 4K image take this path; what counts for them is latency -- nothing is
+// pipelined here, a row takes a few microseconds -- so a small launch gives every thread ONE row and a large one, where the edge
+// blocks only have to get out of the way, all four of a cell (launch_apply_t).
 template <int FMT, bool MASK>
-__global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_apply_s4(const AppConsts c, const AppBatch b) {
+__device__ __forceinline__ void apply_cell_edge(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, const ApplyCellIn& in,
+                                                int tbl, uint32_t r0, uint32_t nrows, uint32_t slot8, const char* lut, const float* idw4 /* in LDS */) {
+  typedef ApplyTab<FMT, MASK> T;
+  const float a255 = c.fast.A255, m1 = (float)in.mb[0];
+  const float base = __builtin_fmaf(m1, a255, c.fast.B), d2 = (float)in.mb[1] - m1, d3 = (float)in.mb[2] - m1, d4 = (float)in.mb[3] - m1;
+  const float* wt = idw4 + tbl * 64;
+#pragma unroll 1
+  for (uint32_t oy = r0; oy < r0 + nrows; ++oy) {   // (uniform: the selects below are scalar)
+    const uint32_t yw = oy == 0u ? in.yrow[0] : oy == 1u ? in.yrow[1] : oy == 2u ? in.yrow[2] : in.yrow[3];
+    const ChromaRow cr = chroma_row(oy < 2u ? in.uu[0] : in.uu[1], oy < 2u ? in.vv[0] : in.vv[1]);
+    const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
+    uint32_t px[4];
+    PairOut po[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const f2 yraw = pr ? (f2){cvt_byte<2>(yw), cvt_byte<3>(yw)} : (f2){cvt_byte<0>(yw), cvt_byte<1>(yw)};
+      const float* p0 = wt + oy * 16u + pr * 8;
+      const f2 w1 = (f2){p0[1], p0[5]} * splat(a255), w2 = (f2){p0[2], p0[6]} * splat(a255), w3 = (f2){p0[3], p0[7]} * splat(a255);
+      const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
+      const f2 factor = exp2_2(E);
+      f2 ch[3];
+      if (pr) {
+        ch[0] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.crv); ch[1] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.ngs); ch[2] = pk_fma_sat_bc<1>(yraw, splat(k255), cr.cbu);
+      } else {
+        ch[0] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.crv); ch[1] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.ngs); ch[2] = pk_fma_sat_bc<0>(yraw, splat(k255), cr.cbu);
+      }
+      if (T::kOetf) {
+        float o[6];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          float2 a, b;
+          pow_pair(ch[q], lut, a, b);
+          f2 t;
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(a.y), "v"(ch[q].x), "v"(a.x));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(b.y), "v"(ch[q].y), "v"(b.x));
+          const f2 s = pk_fma(t, factor, splat(2.0f));
+          const float2 ea = *reinterpret_cast<const float2*>(lut + T::kS2Base + s2_address(s.x, slot8));
+          const float2 eb = *reinterpret_cast<const float2*>(lut + T::kS2Base + s2_address(s.y, slot8));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o[2 * q]) : "v"(ea.y), "v"(s.x), "v"(ea.x));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(o[2 * q + 1]) : "v"(eb.y), "v"(s.y), "v"(eb.x));
+        }
+        px[2 * pr] = pack10_bits(o[0], o[2], o[4]);
+        px[2 * pr + 1] = pack10_bits(o[1], o[3], o[5]);
+      } else {
+        f2 lin[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          float2 a, b;
+          tab_pair<0>(ch[q], lut, a, b);
+          f2 t;
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(a.y), "v"(ch[q].x), "v"(a.x));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(b.y), "v"(ch[q].y), "v"(b.x));
+          lin[q] = oetf2_scaled<FMT>(t * factor);
+        }
+        po[pr].r = lin[0]; po[pr].g = lin[1]; po[pr].b = lin[2];
+      }
+    }
+    if (T::kOetf) {
+      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), make_uint4(px[0], px[1], px[2], px[3]));
+    } else if (FMT == 2 || FMT == 3) {
+      uint4 o;
+      o.x = pack10_scaled<MASK>(po[0].r.x, po[0].g.x, po[0].b.x); o.y = pack10_scaled<MASK>(po[0].r.y, po[0].g.y, po[0].b.y);
+      o.z = pack10_scaled<MASK>(po[1].r.x, po[1].g.x, po[1].b.x); o.w = pack10_scaled<MASK>(po[1].r.y, po[1].g.y, po[1].b.y);
+      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), o);
+    } else if (FMT == 1) {
+      const uint2 a = pack_f16_hw(po[0].r.x, po[0].g.x, po[0].b.x), bb = pack_f16_hw(po[0].r.y, po[0].g.y, po[0].b.y);
+      const uint2 cc = pack_f16_hw(po[1].r.x, po[1].g.x, po[1].b.x), d = pack_f16_hw(po[1].r.y, po[1].g.y, po[1].b.y);
+      uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+      o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+      o[1] = make_uint4(cc.x, cc.y, d.x, d.y);
+    } else {  // FMT == 4: planar R,G,B uint16 (ultrahdr.cpp:460-468)
+      const size_t plane = (size_t)c.width * c.height;
+      uint16_t* base16 = static_cast<uint16_t*>(im.dst);
+      const f2 pl[3][2] = {{po[0].r, po[1].r}, {po[0].g, po[1].g}, {po[0].b, po[1].b}};
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const uint32_t q0 = 0x3ffu & (uint32_t)pl[p][0].x, q1 = 0x3ffu & (uint32_t)pl[p][0].y;
+        const uint32_t q2 = 0x3ffu & (uint32_t)pl[p][1].x, q3 = 0x3ffu & (uint32_t)pl[p][1].y;
+        st_stream(reinterpret_cast<uint2*>(base16 + p * plane + pix0), make_uint2(q0 | (q1 << 16), q2 | (q3 << 16)));
+      }
+    }
+  }
+}
+
+// The same bytes as the walk of k_apply_s4 keeps them across a cell (the next cell's are in flight while the current one is
+// computed, so every dword counts against the 128 registers of four waves per SIMD): the two taps of a map row arrive as ONE
+// 16-bit load, mrow[j] = the bytes (cx, cx + 1) of map row cy + j.  The walk only computes cells that have a right and a lower
+// neighbour.  The loads are unaligned half the time; global memory takes that.
+struct ApplyCellPk { uint32_t yrow[4], uu[2], vv[2], mrow[2]; };
+struct __attribute__((packed)) U16Any { uint16_t v; };
+__device__ __forceinline__ void apply_load_cell_pk(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, ApplyCellPk& o) {
+  const uint32_t yoff = 4u * cy * im.y_stride + 4u * cx;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o.yrow[r] = ld_stream(reinterpret_cast<const uint32_t*>(im.y + (yoff + r * im.y_stride)));
+  const uint32_t coff = 2u * cy * im.c_stride + 2u * cx;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    o.uu[r] = *reinterpret_cast<const uint16_t*>(im.u + (coff + r * im.c_stride));
+    o.vv[r] = *reinterpret_cast<const uint16_t*>(im.v + (coff + r * im.c_stride));
+  }
+  const uint32_t m = cy * c.map_w + cx;
+  o.mrow[0] = reinterpret_cast<const U16Any*>(im.map + m)->v;
+  o.mrow[1] = reinterpret_cast<const U16Any*>(im.map + (m + c.map_w))->v;
+}
+
+// Each block copies its tables into LDS once (4 KiB + 32 KiB for the replicated stage-2 table of HLG / PQ output, 15 KiB for the
+// other outputs: two blocks of 512 threads per CU).  Consecutive blocks belong to different images, as in generate (grid.x =
+// image): the images of a launch progress together and the blocks in flight spread over the whole batch's memory (same-box A/B,
+// round 2: 0.608 -> 0.576 ms per 64 frames).  Two kinds of block (grid.y):
+//   * c.walk_blocks walk blocks: c.cells_per_thread map cells per thread over all rows of the map but the last, every lane on
+//     sampleMap's standard weights held in SGPRs.  The cells of the last column and row have other weights (gainmapmath.h:184-228);
+//     a lane that lands on the last column computes its left neighbour once more instead and stores the same bytes a second time.  So the loop is ONE straight line of
+//     code: no lane is masked and no memory instruction sits behind a branch -- which is what lets s_waitcnt count: behind a
+//     branch the compiler must assume the instruction was not issued, and a wait for the inputs of the next cell then also waits
+//     for every store issued after them (the loop used to drain its stores at every cell);
+//   * edge blocks in front of them: the map_w + map_h - 1 cells of the last column and row, one per thread, per-lane weights.
+constexpr uint32_t kApplyBlock = 512;
+constexpr uint32_t kApplyMaxCellsPerThread = 32;
+__host__ __device__ inline uint32_t apply_edge_blocks(uint32_t map_w, uint32_t map_h, uint32_t edge_rows) {
+  return ((map_w + map_h - 1u) * (4u / edge_rows) + kApplyBlock - 1u) / kApplyBlock;
+}
+
+// One cell of the walk: requests the inputs of the thread's next cell into `nxt` (a block's waves start together, and without this
+// they would also all wait for HBM together and all compute together), computes the cell whose inputs `cur` holds, and steps
+// (cx, cy) on.  The kernel calls it with its two register sets swapped from cell to cell, so nothing is copied between them.
+// Returns whether there is a next cell; when there is none the request repeats the current cell's (issued all the same: see above).
+template <int FMT, bool MASK>
+__device__ __forceinline__ bool apply_walk_cell(const AppConsts& c, const AppImage& im, uint32_t& cx, uint32_t& cy, uint32_t& left,
+                                                const ApplyCellPk& cur, ApplyCellPk& nxt, uint32_t slot8, const char* lut, uint4* s_xch) {
+  typedef ApplyTab<FMT, MASK> T;
+  // the block's next stretch of cells lies kApplyBlock = step_y * map_w + step_x cells further on
+  uint32_t ncx = cx + c.step_x, ncy = cy + c.step_y;
+  if (ncx >= c.map_w) { ncx -= c.map_w; ++ncy; }
+  --left;
+  const bool more = left != 0u && ncy + 1u < c.map_h;   // (the walk ends in front of the last row)
+  if (!more) { ncx = cx; ncy = cy; }
+  // (the cell computed for a lane on the last column: its left neighbour)
+  apply_load_cell_pk(c, im, ncx - (ncx + 1u == c.map_w ? 1u : 0u), ncy, nxt);
+  const uint32_t ecx = cx - (cx + 1u == c.map_w ? 1u : 0u), ecy = cy;
+  const float e1 = cvt_byte<0>(cur.mrow[0]), e2 = cvt_byte<0>(cur.mrow[1]), e3 = cvt_byte<1>(cur.mrow[0]), e4 = cvt_byte<1>(cur.mrow[1]);
+  if (T::kOetf) {
+    apply_cell_piped<FMT>(c, im.dst, ecx, ecy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, slot8, lut);
+  } else {
+    // F16: a full wave on one row of cells stores through the exchange area (apply_cell_piped1)
+    uint4* xch = nullptr;
+    uint32_t dup_lane = 64u;
+    if (FMT == 1 && __builtin_amdgcn_ballot_w64(true) == ~0ull &&
+        __builtin_amdgcn_ballot_w64(cy != (uint32_t)__builtin_amdgcn_readfirstlane((int)cy)) == 0ull) {
+      xch = s_xch + (threadIdx.x >> 6) * kXchPerWave;
+      const uint64_t dup = __builtin_amdgcn_ballot_w64(ecx != cx);
+      if (dup) dup_lane = (uint32_t)__builtin_ctzll(dup);
+    }
+    apply_cell_piped1<FMT, MASK>(c, im, ecx, ecy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, lut, xch, dup_lane);
+  }
+  cx = ncx; cy = ncy;
+  return more;
+}
+
+template <int FMT, bool MASK>
+__global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, const AppBatch b) {
   typedef ApplyTab<FMT, MASK> T;
   __shared__ uint4 s_tab[T::kBytes / 16u];
-  __shared__ uint4 s_xch[FMT == 1 ? (UHDR_APPLY_BLOCK / 64) * kXchPerWave : 1];   // F16: the waves' exchange areas
-#if UHDR_APPLY_IMAGE_MINOR
+  __shared__ uint4 s_xch[FMT == 1 ? (kApplyBlock / 64) * kXchPerWave : 1];   // F16: the waves' exchange areas
+  __shared__ float s_idw[4 * 64];   // edge blocks: the four weight tables (a lane's weights are then an LDS read, not a trip to L2 per pixel pair)
   const uint32_t img_i = blockIdx.x, span = blockIdx.y;
-#else
-  const uint32_t img_i = blockIdx.y, span = blockIdx.x;
-#endif
   const AppImage& im = b.img[img_i];
-  void* const dst = im.dst;
-  const uint32_t total = c.map_w * c.map_h;
-  uint32_t idx = span * c.cells_per_thread * kApplyBlock + threadIdx.x;
-  const bool any = idx < total;
-  uint32_t cy = idx / c.map_w;
-  uint32_t cx = idx - cy * c.map_w;
+  const uint32_t edge_blocks = gridDim.y - c.walk_blocks;
+  const bool walk = span >= edge_blocks;   // (block-uniform; the edge blocks first: they are short and latency-bound, and a small launch would end on them)
+  uint32_t cx, cy, ek0 = 0u;
+  bool any;
+  if (walk) {
+    const uint32_t idx = (span - edge_blocks) * c.cells_per_thread * kApplyBlock + threadIdx.x;
+    cy = idx / c.map_w;
+    cx = idx - cy * c.map_w;
+    any = cy + 1u < c.map_h;
+  } else {
+    // edge cell e: the last column top to bottom (the corner included), then the last row left to right; a thread takes
+    // c.edge_rows (1, 2 or 4) of the cell's four pixel rows
+    const uint32_t task = (span * kApplyBlock + threadIdx.x) * c.edge_rows;
+    const uint32_t e = task >> 2;
+    ek0 = task & 3u;
+    any = e < c.map_w + c.map_h - 1u;
+    cx = e < c.map_h ? c.map_w - 1u : e - c.map_h;
+    cy = e < c.map_h ? e : c.map_h - 1u;
+  }
   // the first cell's pixels are requested before the tables: both trips to memory overlap
-  ApplyCellIn cur;
-  if (any && UHDR_APPLY_EXPERIMENT != 2) apply_load_cell(c, im, cx, cy, cur);
+  ApplyCellPk ca, cb;
+  ApplyCellIn ce;
+  if (any) {
+    if (walk) apply_load_cell_pk(c, im, cx - (cx + 1u == c.map_w ? 1u : 0u), cy, ca);
+    else apply_load_cell(c, im, cx, cy, ce);
+  }
   {
     // all loads first, then all stores: one trip through L2's latency per block instead of one per piece
     constexpr uint32_t kN1 = T::kS1Bytes / 16u, kPer1 = (kN1 + kApplyBlock - 1u) / kApplyBlock;
@@ -1390,14 +1545,15 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
     uint4 t1[kPer1];
     uint2 t2[kPer2 ? kPer2 : 1u];
 #pragma unroll
-    for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN1) t1[k] = src1[i]; }
+    for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; t1[k] = src1[i < kN1 ? i : kN1 - 1u]; }
 #pragma unroll
-    for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN2) t2[k] = src2[i >> 5]; }
+    for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; t2[k] = src2[(i < kN2 ? i : 0u) >> 5]; }
 #pragma unroll
     for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN1) s_tab[i] = t1[k]; }
 #pragma unroll
     for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN2) reinterpret_cast<uint2*>(s_tab)[T::kS2Base / 8u + i] = t2[k]; }
   }
+  if (!walk && threadIdx.x < 4u * 64u) s_idw[threadIdx.x] = c_idw4[threadIdx.x];
   __syncthreads();
   const char* lut = reinterpret_cast<const char*>(s_tab);
   const uint32_t slot8 = (threadIdx.x & 31u) << 3;
@@ -1408,43 +1564,21 @@ __global__ void __launch_bounds__(UHDR_APPLY_BLOCK, UHDR_APPLY_MIN_WAVES) k_appl
     // follow are reached by addition.
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(cx), "+v"(cy));
   }
-  // The inputs of the next cell are requested before the current one is computed: a block's waves start together, and without
-  // this they would also all wait for HBM together and all compute together.
+  if (!walk) {
+    const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
+    const int tbl = edge_x ? (edge_y ? 3 : 1) : 2;
+    apply_cell_edge<FMT, MASK>(c, im, cx, cy, ce, tbl, ek0, c.edge_rows, slot8, lut, s_idw);
+    return;
+  }
+  uint32_t left = c.cells_per_thread;
 #pragma unroll 1
-  for (uint32_t it = 0;; ++it) {
-  const uint32_t nidx = idx + kApplyBlock;
-  const bool more = it + 1u < c.cells_per_thread && nidx < total;
-  uint32_t ncx = cx + kApplyBlock, ncy = cy;
-  while (ncx >= c.map_w) { ncx -= c.map_w; ++ncy; }
-  ApplyCellIn nxt;
-  if (more && UHDR_APPLY_EXPERIMENT != 2) apply_load_cell(c, im, ncx, ncy, nxt);
-  const float e1 = (float)cur.mb[0], e2 = (float)cur.mb[1], e3 = (float)cur.mb[2], e4 = (float)cur.mb[3];
-  const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
-  const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
-  // all waves but those touching the last column/row of cells take the SGPR-weight path
-#if UHDR_APPLY_EXPERIMENT   // memory floors (scripts/ab, never shipped): 1 the kernel's loads and stores, one XOR in between; 2 its stores alone; 3 its loads alone
-  {
-    uint32_t x = cur.yrow[0] ^ cur.yrow[1] ^ cur.yrow[2] ^ cur.yrow[3] ^ cur.uu[0] ^ cur.uu[1] ^ cur.vv[0] ^ cur.vv[1] ^ __float_as_uint(e1 + e2 + e3 + e4);
-    if (UHDR_APPLY_EXPERIMENT == 2) x = cx * cy;
-    if (UHDR_APPLY_EXPERIMENT != 3 || x == 0x12345678u)
-      for (int oy = 0; oy < 4; ++oy) st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(dst) + ((4u * cy + oy) * c.width + 4u * cx)), make_uint4(x, x + oy, x ^ 1u, x ^ 2u));
-  }
+  for (;;) {
+#ifdef UHDR_X_NOWAIT
+    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, ca, cb, slot8, lut, s_xch)) return;
 #else
-  if (T::kOetf) {
-    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) apply_cell_piped<FMT, true>(c, dst, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, 0, slot8, lut);
-    else apply_cell_piped<FMT, false>(c, dst, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, tbl, slot8, lut);
-  } else {
-    // F16: a full wave on one row of cells stores through the exchange area (apply_cell_piped1)
-    uint4* xch = nullptr;
-    if (FMT == 1 && __builtin_amdgcn_ballot_w64(true) == ~0ull &&
-        __builtin_amdgcn_ballot_w64(cy != (uint32_t)__builtin_amdgcn_readfirstlane((int)cy)) == 0ull)
-      xch = s_xch + (threadIdx.x >> 6) * kXchPerWave;
-    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) apply_cell_piped1<FMT, true, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, 0, lut, xch);
-    else apply_cell_piped1<FMT, false, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, tbl, lut, xch);
-  }
+    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, ca, cb, slot8, lut, s_xch)) return;
+    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, cb, ca, slot8, lut, s_xch)) return;
 #endif
-  if (!more) return;
-  cur = nxt; idx = nidx; cx = ncx; cy = ncy;
   }
 }
 
@@ -1952,8 +2086,8 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     hipLaunchKernelGGL((k_apply_lut<FMT>), dim3((unsigned)((total + per_block - 1u) / per_block), n), dim3(256), 0, s, c, b);
     return hipGetLastError();
   }
-  if (fast_s4 && !exact) {
-    const uint32_t total = c.map_w * c.map_h;
+  if (fast_s4 && !exact && c.map_w >= 2u && c.map_h >= 2u) {   // (the walk computes cells with a right and a lower neighbour)
+    const uint32_t total = c.map_w * (c.map_h - 1u);   // the walk's cells: all rows but the last
     // Cells per thread: a block copies 15-37 KB of tables into LDS before its first pixel, so it should walk many cells -- but a
     // launch also has to fill 256 CUs x 4 resident blocks, or a single 4K image (2025 blocks of 256 cells) would leave three
     // quarters of the chip idle with 8 cells per thread.
@@ -1961,18 +2095,32 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     uint32_t cpt = kApplyMaxCellsPerThread;
     auto blocks = [&](uint32_t k) { return (uint64_t)((total + kApplyBlock * k - 1u) / (kApplyBlock * k)) * (uint64_t)n; };
     while (cpt > 1u && blocks(cpt) < 448u) cpt >>= 1;   // (a single 4K image: 507 blocks of 2 cells per thread, all resident at once)
-    cc.cells_per_thread = cpt;
-#if UHDR_APPLY_IMAGE_MINOR
-    const dim3 grid(n, (unsigned)((total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt)));
-#else
-    const dim3 grid((unsigned)((total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt)), n);
+#ifdef UHDR_X_CPT_ENV
+    if (const char* e = getenv("UHDR_X_CPT")) cpt = (uint32_t)atoi(e);
 #endif
+    cc.cells_per_thread = cpt;
+    cc.walk_blocks = (total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt);
+    cc.step_x = kApplyBlock % c.map_w;
+    cc.step_y = kApplyBlock / c.map_w;
+    // The edge blocks (see k_apply_s4) go in front.  A small launch is one round of blocks, two per CU: there the edge threads take
+    // as few rows as still lets the launch fit that round (one 4K image: 506 walk blocks + 6 edge blocks of two rows per thread),
+    // because an edge block that outlives the walk blocks, or a block that has to wait for a slot, IS the launch's time.
+    cc.edge_rows = 4u;
+    if (cc.walk_blocks * (uint32_t)n <= 512u)
+      while (cc.edge_rows > 1u && (cc.walk_blocks + apply_edge_blocks(c.map_w, c.map_h, cc.edge_rows / 2u)) * (uint32_t)n <= 512u) cc.edge_rows >>= 1;
+#ifdef UHDR_X_CPT_ENV
+    if (const char* e = getenv("UHDR_X_ER")) cc.edge_rows = (uint32_t)atoi(e);
+#endif
+    const dim3 grid(n, cc.walk_blocks + apply_edge_blocks(c.map_w, c.map_h, cc.edge_rows));
     // Channels can only exceed 1.0 (reach code 1024 and wrap through the reference's & 0x3ff; leave the stage-2 table) when the
     // display boost is capped below the content boost -- and then only if the largest factor the call can produce,
     // max(minBoost, maxBoost)^(display / max) / display, is above 1: a display boost of 2 under a content boost of 4.9 stays
     // below (0.955), a display boost of 1 does not (1.38).
+    // The factor alone decides: with minContentBoost > maxContentBoost (nothing on the apply path refuses it, ultrahdr.cpp:360-425;
+    // a crafted XMP gets here through decodeJPEGR) `top` is far above 1 although display_boost == max_boost, and stage 2's cell
+    // number -- byte 2 of 2 + 2u, unclamped -- would index past its 129 cells.
     const double top = std::exp2(std::fmax(c.log2_min_d, c.log2_max_d) * (double)c.display_boost / (double)c.max_boost) / (double)c.display_boost;
-    if (c.display_boost < c.max_boost && top > 1.0 + 1e-6) hipLaunchKernelGGL((k_apply_s4<FMT, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
+    if (!(top <= 1.0 + 1e-6)) hipLaunchKernelGGL((k_apply_s4<FMT, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
     else {
       if (ApplyTab<FMT, false>::kOetf) {
         // u = T(c) * 2^(g E), handed to stage 2 as 2 + 2u: the exponent's constants times g (1/2 for HLG: sqrt; m1 for PQ), plus 1

@@ -87,17 +87,6 @@ __device__ __forceinline__ f2 pk_fma_sat_bc(f2 a, f2 b, f2 c) {
   return r;
 }
 
-#ifdef UHDR_GEN_COUNT   // instrumentation build only (scripts/dbg_filter_rate.py): how often do waves leave the fast path?
-__device__ unsigned long long g_gen_count[4];   // wave-tiles, wave-tiles on the exact path, exact statistics passes, doubtful pixels
-extern "C" hipError_t uhdr_hip_debug_counters(unsigned long long* out, int reset) {
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gen_count), sizeof(unsigned long long) * 4);
-  if (e == hipSuccess && reset) { unsigned long long z[4] = {0, 0, 0, 0}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_gen_count), z, sizeof(z)); }
-  return e;
-}
-#define UHDR_COUNT(i, v) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_gen_count[i], (unsigned long long)(v)); } while (0)
-#else
-#define UHDR_COUNT(i, v) do { } while (0)
-#endif
 
 // =================================================================================================
 // LUT mode: the reference's table accessors (gainmapmath.cpp:162-171,269-277,292-302,316-324,344-354) and
@@ -210,14 +199,6 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
                                              const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
                                              const uint32_t (&u8)[2][2], const uint32_t (&v8)[2][2],
                                              uint8_t (&out)[2], float (&gain)[2], const float* s_srgb, const float* s_hdr) {
-#if UHDR_GEN_EXPERIMENT == 1   // memory floor: loads + one store, no arithmetic to speak of
-  {
-    uint32_t x = 0;
-    for (int k = 0; k < 2; ++k) { for (int r = 0; r < 4; ++r) x ^= hy[k][r][0] ^ hy[k][r][1] ^ y8[k][r]; for (int r = 0; r < 2; ++r) x ^= huv[k][r][0] ^ huv[k][r][1] ^ u8[k][r] ^ v8[k][r]; }
-    out[0] = (uint8_t)x; out[1] = (uint8_t)(x >> 8); gain[0] = gain[1] = 1.0f;
-    return 3u;
-  }
-#endif
   f2 sy = splat(0.0f), su = splat(0.0f), sv = splat(0.0f);
   f2 hsy = splat(0.0f), hsu = splat(0.0f), hsv = splat(0.0f);
 #pragma unroll
@@ -275,13 +256,6 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
   f2 hg = pk_add_sat(hsy - splat(c.hdr_gcb) * hsu, -(splat(c.hdr_gcr) * hsv));
   f2 hb = pk_add_sat(hsy, splat(c.hdr_cb) * hsu);
 
-#if UHDR_GEN_EXPERIMENT == 2   // sampling + YUV->RGB only
-  {
-    const f2 t = r + g + b + hr + hg + hb;
-    out[0] = (uint8_t)(int)(t.x * 40.0f); out[1] = (uint8_t)(int)(t.y * 40.0f); gain[0] = gain[1] = 1.0f;
-    return 3u;
-  }
-#endif
   if (FILTER && !LUT) {
     const f2 fr = (f2){srgb_inv_oetf_fast(r.x), srgb_inv_oetf_fast(r.y)};
     const f2 fg = (f2){srgb_inv_oetf_fast(g.x), srgb_inv_oetf_fast(g.y)};
@@ -324,11 +298,6 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
       // gainmapmath.cpp:531) is decided identically on both paths
       if (!(ys > 0.0f)) fexact |= 1u << k;
     }
-#if UHDR_GEN_EXPERIMENT == 3   // filter without fallback
-    doubt = 0u;
-#endif
-    UHDR_COUNT(0, 1);
-    UHDR_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(doubt != 0u)));
     // DEFER (large launches): the kernel never runs the exact path: a pixel in doubt keeps its estimate's byte for now and is
     // handed (bits 2, 3 of the result) to k_generate_resolve, which replaces the byte and accounts for the pixel's exact gain.
     // Otherwise (a launch too small to be worth a second kernel's latency) a wave holding such a pixel runs the exact path below.
@@ -341,9 +310,7 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
   // independent f64 evaluations advanced in lock step: 6 = 3 channels x 2 pixels.  Measured on MI355X
   // (scripts/ab): 6 -> 0.388 ms per 32-frame launch, 3 -> 0.432, 2 -> 0.490 although the narrower forms
   // need fewer VGPRs (98 / 84 / 78): exposed f64 FMA latency costs more than the lost occupancy.
-#ifndef UHDR_LOCKSTEP
-#define UHDR_LOCKSTEP 6
-#endif
+  constexpr int kLockstep = 6;
   if (LUT) {
     r = (f2){s_srgb[lut_index_unit(r.x, kLutSrgbInvN)], s_srgb[lut_index_unit(r.y, kLutSrgbInvN)]};
     g = (f2){s_srgb[lut_index_unit(g.x, kLutSrgbInvN)], s_srgb[lut_index_unit(g.y, kLutSrgbInvN)]};
@@ -351,13 +318,13 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
   } else {
     float ch[6] = {r.x, r.y, g.x, g.y, b.x, b.y};
 #pragma unroll
-    for (int i = 0; i < 6; i += UHDR_LOCKSTEP) {
-      float part[UHDR_LOCKSTEP];
+    for (int i = 0; i < 6; i += kLockstep) {
+      float part[kLockstep];
 #pragma unroll
-      for (int j = 0; j < UHDR_LOCKSTEP; ++j) part[j] = ch[i + j];
-      srgb_inv_oetf_guarded_n<UHDR_LOCKSTEP>(part);
+      for (int j = 0; j < kLockstep; ++j) part[j] = ch[i + j];
+      srgb_inv_oetf_guarded_n<kLockstep>(part);
 #pragma unroll
-      for (int j = 0; j < UHDR_LOCKSTEP; ++j) ch[i + j] = part[j];
+      for (int j = 0; j < kLockstep; ++j) ch[i + j] = part[j];
     }
     r = (f2){ch[0], ch[1]}; g = (f2){ch[2], ch[3]}; b = (f2){ch[4], ch[5]};
   }
@@ -371,14 +338,14 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
   } else if (TF != 0) {  // ULTRAHDR_TF_LINEAR: identityConversion (ultrahdr.cpp:223-228)
     float ch[6] = {hr.x, hr.y, hg.x, hg.y, hb.x, hb.y};
 #pragma unroll
-    for (int i = 0; i < 6; i += UHDR_LOCKSTEP) {
-      float part[UHDR_LOCKSTEP];
+    for (int i = 0; i < 6; i += kLockstep) {
+      float part[kLockstep];
 #pragma unroll
-      for (int j = 0; j < UHDR_LOCKSTEP; ++j) part[j] = ch[i + j];
-      if (TF == 1) hlg_inv_oetf_guarded_n<UHDR_LOCKSTEP>(part);
-      else pq_inv_oetf_guarded_n<UHDR_LOCKSTEP>(part);
+      for (int j = 0; j < kLockstep; ++j) part[j] = ch[i + j];
+      if (TF == 1) hlg_inv_oetf_guarded_n<kLockstep>(part);
+      else pq_inv_oetf_guarded_n<kLockstep>(part);
 #pragma unroll
-      for (int j = 0; j < UHDR_LOCKSTEP; ++j) ch[i + j] = part[j];
+      for (int j = 0; j < kLockstep; ++j) ch[i + j] = part[j];
     }
     hr = (f2){ch[0], ch[1]}; hg = (f2){ch[2], ch[3]}; hb = (f2){ch[4], ch[5]};
   }
@@ -399,72 +366,35 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
   return 3u;
 }
 
-// Frames are read once and outputs written once: the aligned fast paths use non-temporal loads (bit 0) and stores
-// (bit 1) so that 2 GB of apply output do not sit dirty in L2 / Infinity Cache when the next kernel starts reading.
-// Same-box A/B (scripts/ab, 64 x 4K, ms per launch): generate 0.484 -> 0.444 with either bit, 0.394 with both;
+// Frames are read once and outputs written once: the aligned fast paths use non-temporal loads and stores
+// so that 2 GB of apply output do not sit dirty in L2 / Infinity Cache when the next kernel starts reading.
+// Same-box A/B (scripts/ab, 64 x 4K, ms per launch): generate 0.484 -> 0.444 with either, 0.394 with both;
 // apply 0.98 -> 0.996.
-#ifndef UHDR_NT
-#define UHDR_NT 3
-#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 ld_stream(const uint4* p) {
-#if UHDR_NT & 1
   const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
-#else
-  return *p;
-#endif
 }
 __device__ __forceinline__ uint2 ld_stream(const uint2* p) {
-#if UHDR_NT & 1
   const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
   return make_uint2(v.x, v.y);
-#else
-  return *p;
-#endif
 }
 __device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) {
-#if UHDR_NT & 1
   return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
 }
 __device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
-#if UHDR_NT & 2
   __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p));
-#else
-  *p = v;
-#endif
 }
 __device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
-#if UHDR_NT & 2
   __builtin_nontemporal_store((u32x2){v.x, v.y}, reinterpret_cast<u32x2*>(p));
-#else
-  *p = v;
-#endif
 }
 __device__ __forceinline__ uint32_t ld8(const uint8_t* p) { return *p; }
 __device__ __forceinline__ uint32_t ld16(const uint16_t* p) { return *p; }
 
-#ifndef UHDR_GEN_EXPERIMENT
-#define UHDR_GEN_EXPERIMENT 0   // 1..3: timing experiments only (scripts/ab), never shipped
-#endif
-#ifndef UHDR_GEN_BLOCK
-#define UHDR_GEN_BLOCK 256
-#endif
 // launch geometry of k_generate, chosen by same-box A/B (scripts/ab, ms per 32-frame 4K launch):
 //   block 64/128/256/512/1024, 1 span: 0.64 / 0.50 / 0.39 / 0.355 / 0.43;   block 256, 4 spans: 0.350
-#ifndef UHDR_GEN_TILES
-#define UHDR_GEN_TILES 4
-#endif
-#ifndef UHDR_GEN_MINWAVES
-#define UHDR_GEN_MINWAVES 1
-#endif
-#ifndef UHDR_GEN_IMAGE_MAJOR
-#define UHDR_GEN_IMAGE_MAJOR 0   // 1: the blocks of an image are consecutive (scripts/ab)
-#endif
+constexpr int kGenBlock = 256, kGenTiles = 4;
 
 // inputs of pair `idx` (two horizontally adjacent map pixels = an 8x4 pixel block of both images) -> registers
 template <bool ALIGNED>
@@ -557,13 +487,8 @@ __device__ __forceinline__ void exact_pair(const GenConsts& c, const GenImage& i
 // extreme -- and could still beat the extreme already published for the image -- are re-evaluated on the exact path
 // (typically none).  Waves never wait for each other: a block-wide reduction here measured +25 % on the whole kernel,
 // because one wave in seven takes the exact path in some tile and its three siblings would idle at the barrier.
-#ifdef UHDR_GEN_MAXWAVES
-#define UHDR_GEN_OCC __attribute__((amdgpu_waves_per_eu(1, UHDR_GEN_MAXWAVES)))
-#else
-#define UHDR_GEN_OCC
-#endif
-template <int TF, bool ALIGNED, bool LUT, bool FILTER, int TILES, bool DEFER, int BLOCK = UHDR_GEN_BLOCK>
-__global__ void __launch_bounds__(BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OCC k_generate(const GenConsts c, const GenBatch b) {
+template <int TF, bool ALIGNED, bool LUT, bool FILTER, int TILES, bool DEFER, int BLOCK = kGenBlock>
+__global__ void __launch_bounds__(BLOCK, 1) k_generate(const GenConsts c, const GenBatch b) {
   // LUT mode: block-private copies of the two tables (4 KiB + 16 KiB), so every lookup is an LDS gather
   __shared__ float s_srgb[LUT ? kLutSrgbInvN : 1];
   __shared__ float s_hdr[(LUT && TF != 0) ? kLutHlgInvN : 1];
@@ -579,11 +504,7 @@ __global__ void __launch_bounds__(BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OCC k_gener
   }
   // consecutive workgroups belong to different images (grid.x = image): the images of a launch progress together, so
   // the extremes a finished wave publishes prune the statistics candidates of the image's later waves
-#if UHDR_GEN_IMAGE_MAJOR
-  const uint32_t img_i = blockIdx.y, blk = blockIdx.x;
-#else
   const uint32_t img_i = blockIdx.x, blk = blockIdx.y;
-#endif
   const GenImage& im = b.img[img_i];
   const uint8_t* im_v = im.u + (size_t)im.c_stride * (c.height / 2u);
   const uint32_t pairs_per_row = (c.map_w + 1u) >> 1;
@@ -697,7 +618,6 @@ __global__ void __launch_bounds__(BLOCK, UHDR_GEN_MINWAVES) UHDR_GEN_OCC k_gener
       total += (uint32_t)__builtin_popcountll(mask[t]);
     }
     if (total != 0u) {
-      UHDR_COUNT(2, total);
       const uint32_t lane = threadIdx.x & 63u, list = blk % kStatLists;
       uint32_t base = 0u;
       if (lane == 0u) base = atomicAdd(&ws[8u + list], total);
@@ -826,7 +746,7 @@ hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, in
 
 bool generate_is_small(const GenConsts& c, int n) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
-  const uint32_t span = (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES;
+  const uint32_t span = (uint32_t)kGenBlock * (uint32_t)kGenTiles;
   return (uint64_t)((total + span - 1u) / span) * (uint64_t)n < 2048u;
 }
 
@@ -834,19 +754,19 @@ template <int TF, bool ALIGNED, bool LUT, bool FILTER>
 static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n, hipStream_t s) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   if (total == 0 || n == 0) return hipSuccess;
-  // Spans per block: UHDR_GEN_TILES (fewer, longer-lived waves) where the launch still fills the chip, one otherwise -- a single
+  // Spans per block: kGenTiles (fewer, longer-lived waves) where the launch still fills the chip, one otherwise -- a single
   // 4K image is 1013 spans: 254 blocks of 4 would put one wave on each SIMD and leave the memory system nothing to overlap.
   // Filtered kernel: a large launch leaves its pixels in doubt to k_generate_resolve (c.stat_ws set by the caller); a small one
   // (c.stat_ws null) runs the exact path in place, for the waves that hold such a pixel.
   const bool small = generate_is_small(c, n);
-  const unsigned b4 = (total + (uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES - 1u) / ((uint32_t)UHDR_GEN_BLOCK * (uint32_t)UHDR_GEN_TILES);
-  const unsigned b1 = (total + UHDR_GEN_BLOCK - 1u) / UHDR_GEN_BLOCK;
-  const dim3 g4 = UHDR_GEN_IMAGE_MAJOR ? dim3(b4, (unsigned)n, 1) : dim3((unsigned)n, b4, 1);
-  const dim3 g1 = UHDR_GEN_IMAGE_MAJOR ? dim3(b1, (unsigned)n, 1) : dim3((unsigned)n, b1, 1);
+  const unsigned b4 = (total + (uint32_t)kGenBlock * (uint32_t)kGenTiles - 1u) / ((uint32_t)kGenBlock * (uint32_t)kGenTiles);
+  const unsigned b1 = (total + kGenBlock - 1u) / kGenBlock;
+  const dim3 g4 = dim3((unsigned)n, b4, 1);
+  const dim3 g1 = dim3((unsigned)n, b1, 1);
   if (FILTER) {
     if (c.stat_ws != nullptr) {
-      if (small) hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, true>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
-      else hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES, true>), g4, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+      if (small) hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, true>), g1, dim3(kGenBlock, 1, 1), 0, s, c, b);
+      else hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, kGenTiles, true>), g4, dim3(kGenBlock, 1, 1), 0, s, c, b);
     } else {
       if (c.stat_keys != nullptr) return hipErrorInvalidValue;   // statistics of a filtered launch need the workspace
       // a launch whose waves are all resident at once, from one 4K image up (1013 blocks of 256 threads): 128-thread blocks give
@@ -854,16 +774,16 @@ static hipError_t launch_generate_t(const GenConsts& c, const GenBatch& b, int n
       // is better off as it is (6.9 against 7.9 us)
       const unsigned h1 = (total + 127u) / 128u;
       if ((uint64_t)h1 * (uint64_t)n >= 2000u) {
-        const dim3 gh = UHDR_GEN_IMAGE_MAJOR ? dim3(h1, (unsigned)n, 1) : dim3((unsigned)n, h1, 1);
+        const dim3 gh = dim3((unsigned)n, h1, 1);
         hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false, 128>), gh, dim3(128, 1, 1), 0, s, c, b);
       } else {
-        hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+        hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(kGenBlock, 1, 1), 0, s, c, b);
       }
     }
   } else if (small) {
-    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, 1, false>), g1, dim3(kGenBlock, 1, 1), 0, s, c, b);
   } else {
-    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, UHDR_GEN_TILES, false>), g4, dim3(UHDR_GEN_BLOCK, 1, 1), 0, s, c, b);
+    hipLaunchKernelGGL((k_generate<TF, ALIGNED, LUT, FILTER, kGenTiles, false>), g4, dim3(kGenBlock, 1, 1), 0, s, c, b);
   }
   return hipGetLastError();
 }
@@ -1161,7 +1081,7 @@ __device__ __forceinline__ void apply_cell_piped(const AppConsts& c, void* dst, 
   for (int k = 0; k < 10; ++k) {
     if (k < 8) {  // ---- F(k)
       const int oy = k >> 1, pr = k & 1;
-      // sampleMap's standard weights (the walk leaves the cells of the last column / row to apply_cell_edge), times A / 255: SGPR pairs
+      // sampleMap's standard weights (cells of the last column / row: apply_cell_edge) times A / 255: SGPR pairs
       const f2 w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}, w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
       const f2 w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
       if (k == 4) cr = chroma_row(uu[1], vv[1]);
@@ -1241,7 +1161,7 @@ __device__ __forceinline__ void apply_cell_piped1(const AppConsts& c, const AppI
   for (int k = 0; k < 9; ++k) {
     if (k < 8) {  // ---- F(k)
       const int oy = k >> 1, pr = k & 1;
-      // sampleMap's standard weights (the walk leaves the cells of the last column / row to apply_cell_edge), times A / 255: SGPR pairs
+      // sampleMap's standard weights (cells of the last column / row: apply_cell_edge) times A / 255: SGPR pairs
       const f2 w1 = (f2){c.fast.wD[oy][pr][0][0], c.fast.wD[oy][pr][0][1]}, w2 = (f2){c.fast.wD[oy][pr][1][0], c.fast.wD[oy][pr][1][1]};
       const f2 w3 = (f2){c.fast.wD[oy][pr][2][0], c.fast.wD[oy][pr][2][1]};
       if (k == 4) cr = chroma_row(uu[1], vv[1]);
@@ -1338,22 +1258,23 @@ __device__ __forceinline__ void apply_load_cell(const AppConsts& c, const AppIma
   o.mb[0] = im.map[m0 + cx]; o.mb[1] = im.map[m1 + cx]; o.mb[2] = im.map[m0 + xu]; o.mb[3] = im.map[m1 + xu];
 }
 
-// Pixel rows [r0, r0 + nrows) of a cell of the last column / row (per-lane weights: the NR / NB / C tables of
-// gainmapmath.h:184-228) for the edge blocks of k_apply_s4: the arithmetic of the walk's cells, row by row in a rolled loop (a row's
-// two pixel pairs side by side).  Some 1500 cells of a 4K image take this path; what counts for them is latency -- nothing is
-// pipelined here, a row takes a few microseconds -- so a small launch gives every thread ONE row and a large one, where the edge
-// blocks only have to get out of the way, all four of a cell (launch_apply_t).
+// Pixel rows [r0, r0 + nrows) of a cell with per-lane weights (the last column / row of the map: the NR / NB / C tables of
+// gainmapmath.h:184-228): the arithmetic of the walk's cells, row by row in a rolled loop, a row's two pixel pairs side by side.
+// Some 1500 cells of a 4K image take this path.  It is short and needs few registers -- a second copy of the pipelined cell with
+// per-lane weights, inlined next to the first, made the allocator spill in the loop they share -- and nothing in it is pipelined:
+// it runs in the edge blocks of a large launch, and in a small one in the waves that touch the last column / row.
 template <int FMT, bool MASK>
-__device__ __forceinline__ void apply_cell_edge(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, const ApplyCellIn& in,
-                                                int tbl, uint32_t r0, uint32_t nrows, uint32_t slot8, const char* lut, const float* idw4 /* in LDS */) {
+__device__ __forceinline__ void apply_cell_edge(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
+                                                const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
+                                                float m1, float m2, float m3, float m4, const float* wt /* the lane's table, in LDS */,
+                                                uint32_t r0, uint32_t nrows, uint32_t slot8, const char* lut) {
   typedef ApplyTab<FMT, MASK> T;
-  const float a255 = c.fast.A255, m1 = (float)in.mb[0];
-  const float base = __builtin_fmaf(m1, a255, c.fast.B), d2 = (float)in.mb[1] - m1, d3 = (float)in.mb[2] - m1, d4 = (float)in.mb[3] - m1;
-  const float* wt = idw4 + tbl * 64;
+  const float a255 = c.fast.A255;
+  const float base = __builtin_fmaf(m1, a255, c.fast.B), d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
 #pragma unroll 1
   for (uint32_t oy = r0; oy < r0 + nrows; ++oy) {   // (uniform: the selects below are scalar)
-    const uint32_t yw = oy == 0u ? in.yrow[0] : oy == 1u ? in.yrow[1] : oy == 2u ? in.yrow[2] : in.yrow[3];
-    const ChromaRow cr = chroma_row(oy < 2u ? in.uu[0] : in.uu[1], oy < 2u ? in.vv[0] : in.vv[1]);
+    const uint32_t yw = oy == 0u ? yrow[0] : oy == 1u ? yrow[1] : oy == 2u ? yrow[2] : yrow[3];
+    const ChromaRow cr = chroma_row(oy < 2u ? uu[0] : uu[1], oy < 2u ? vv[0] : vv[1]);
     const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
     uint32_t px[4];
     PairOut po[2];
@@ -1434,7 +1355,8 @@ __device__ __forceinline__ void apply_cell_edge(const AppConsts& c, const AppIma
 // neighbour.  The loads are unaligned half the time; global memory takes that.
 struct ApplyCellPk { uint32_t yrow[4], uu[2], vv[2], mrow[2]; };
 struct __attribute__((packed)) U16Any { uint16_t v; };
-__device__ __forceinline__ void apply_load_cell_pk(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, ApplyCellPk& o) {
+// (mx < map_w - 1: the column of the byte pairs; cy1: the row of the lower taps)
+__device__ __forceinline__ void apply_load_cell_pk(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, uint32_t mx, uint32_t cy1, ApplyCellPk& o) {
   const uint32_t yoff = 4u * cy * im.y_stride + 4u * cx;
 #pragma unroll
   for (int r = 0; r < 4; ++r) o.yrow[r] = ld_stream(reinterpret_cast<const uint32_t*>(im.y + (yoff + r * im.y_stride)));
@@ -1444,22 +1366,31 @@ __device__ __forceinline__ void apply_load_cell_pk(const AppConsts& c, const App
     o.uu[r] = *reinterpret_cast<const uint16_t*>(im.u + (coff + r * im.c_stride));
     o.vv[r] = *reinterpret_cast<const uint16_t*>(im.v + (coff + r * im.c_stride));
   }
-  const uint32_t m = cy * c.map_w + cx;
-  o.mrow[0] = reinterpret_cast<const U16Any*>(im.map + m)->v;
-  o.mrow[1] = reinterpret_cast<const U16Any*>(im.map + (m + c.map_w))->v;
+  o.mrow[0] = reinterpret_cast<const U16Any*>(im.map + (cy * c.map_w + mx))->v;
+  o.mrow[1] = reinterpret_cast<const U16Any*>(im.map + (cy1 * c.map_w + mx))->v;
 }
 
 // Each block copies its tables into LDS once (4 KiB + 32 KiB for the replicated stage-2 table of HLG / PQ output, 15 KiB for the
-// other outputs: two blocks of 512 threads per CU).  Consecutive blocks belong to different images, as in generate (grid.x =
-// image): the images of a launch progress together and the blocks in flight spread over the whole batch's memory (same-box A/B,
-// round 2: 0.608 -> 0.576 ms per 64 frames).  Two kinds of block (grid.y):
-//   * c.walk_blocks walk blocks: c.cells_per_thread map cells per thread over all rows of the map but the last, every lane on
-//     sampleMap's standard weights held in SGPRs.  The cells of the last column and row have other weights (gainmapmath.h:184-228);
-//     a lane that lands on the last column computes its left neighbour once more instead and stores the same bytes a second time.  So the loop is ONE straight line of
-//     code: no lane is masked and no memory instruction sits behind a branch -- which is what lets s_waitcnt count: behind a
-//     branch the compiler must assume the instruction was not issued, and a wait for the inputs of the next cell then also waits
-//     for every store issued after them (the loop used to drain its stores at every cell);
-//   * edge blocks in front of them: the map_w + map_h - 1 cells of the last column and row, one per thread, per-lane weights.
+// other outputs, 1 KiB of sampleMap weights: two blocks of 512 threads per CU) and then walks c.cells_per_thread map cells per
+// thread.  Consecutive blocks belong to different images, as in generate (grid.x = image): the images of a launch progress
+// together and the blocks in flight spread over the whole batch's memory (same-box A/B, round 2: 0.608 -> 0.576 ms per 64 frames).
+//
+// The walk is ONE straight line of code per cell: no memory instruction sits behind a branch (the request for the next cell is
+// issued even when there is none -- it repeats the current cell's --, no lane is masked, and where a wave chooses between two
+// forms of the cell both issue the same memory instructions).  That is what lets s_waitcnt count: behind a branch the compiler
+// has to assume an instruction was not issued, and a wait for the inputs of the next cell then also waits for every store issued
+// after them -- round 2's loop drained its stores at every cell, reloaded six spilled registers, and waited for loads of the NEXT
+// cell through registers the allocator had placed under undefined halves of operand pairs (apply_cell_piped).  Same box, 64 x 4K:
+// 0.579 -> 0.536 ms.
+//
+// The cells of the last column and row have per-lane weights (the NR / NB / C tables of gainmapmath.h:184-228).  Two layouts:
+//   * EDGE_BLOCKS (large launches): grid.y = edge blocks, then c.walk_blocks walk blocks.  The walk covers all rows of the map but
+//     the last, every lane on sampleMap's standard weights held in SGPRs; a lane that lands on the last column computes its left
+//     neighbour once more and stores the same bytes a second time.  The map_w + map_h - 1 edge cells go to the edge blocks, a
+//     thread per cell (apply_cell_edge);
+//   * otherwise (one round of blocks, all resident at once: a few latency-bound edge blocks would be what the launch waits for --
+//     one 4K frame: 13 -> 17 us): the walk covers every cell, and a wave that touches the last column / row runs apply_cell_edge
+//     for its cell instead of the pipelined form.
 constexpr uint32_t kApplyBlock = 512;
 constexpr uint32_t kApplyMaxCellsPerThread = 32;
 __host__ __device__ inline uint32_t apply_edge_blocks(uint32_t map_w, uint32_t map_h, uint32_t edge_rows) {
@@ -1470,22 +1401,42 @@ __host__ __device__ inline uint32_t apply_edge_blocks(uint32_t map_w, uint32_t m
 // they would also all wait for HBM together and all compute together), computes the cell whose inputs `cur` holds, and steps
 // (cx, cy) on.  The kernel calls it with its two register sets swapped from cell to cell, so nothing is copied between them.
 // Returns whether there is a next cell; when there is none the request repeats the current cell's (issued all the same: see above).
-template <int FMT, bool MASK>
+// EDGE_BLOCKS false (small launches): the walk covers every cell, and a wave that touches the last column / row runs the variant of
+// the cell with per-lane weights.
+template <int FMT, bool MASK, bool EDGE_BLOCKS>
 __device__ __forceinline__ bool apply_walk_cell(const AppConsts& c, const AppImage& im, uint32_t& cx, uint32_t& cy, uint32_t& left,
-                                                const ApplyCellPk& cur, ApplyCellPk& nxt, uint32_t slot8, const char* lut, uint4* s_xch) {
+                                                const ApplyCellPk& cur, ApplyCellPk& nxt, uint32_t slot8, const char* lut,
+                                                const float* s_idw, uint4* s_xch) {
   typedef ApplyTab<FMT, MASK> T;
+  const uint32_t rows = EDGE_BLOCKS ? c.map_h - 1u : c.map_h;   // (with edge blocks the walk ends in front of the last row)
   // the block's next stretch of cells lies kApplyBlock = step_y * map_w + step_x cells further on
   uint32_t ncx = cx + c.step_x, ncy = cy + c.step_y;
   if (ncx >= c.map_w) { ncx -= c.map_w; ++ncy; }
   --left;
-  const bool more = left != 0u && ncy + 1u < c.map_h;   // (the walk ends in front of the last row)
+  const bool more = left != 0u && ncy < rows;
   if (!more) { ncx = cx; ncy = cy; }
-  // (the cell computed for a lane on the last column: its left neighbour)
-  apply_load_cell_pk(c, im, ncx - (ncx + 1u == c.map_w ? 1u : 0u), ncy, nxt);
-  const uint32_t ecx = cx - (cx + 1u == c.map_w ? 1u : 0u), ecy = cy;
-  const float e1 = cvt_byte<0>(cur.mrow[0]), e2 = cvt_byte<0>(cur.mrow[1]), e3 = cvt_byte<1>(cur.mrow[0]), e4 = cvt_byte<1>(cur.mrow[1]);
+  const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
+  uint32_t ecx = cx;
+  float e1, e2, e3, e4;
+  if (EDGE_BLOCKS) {
+    // (the cell computed for a lane on the last column: its left neighbour)
+    const uint32_t lcx = ncx - (ncx + 1u == c.map_w ? 1u : 0u);
+    apply_load_cell_pk(c, im, lcx, ncy, lcx, ncy + 1u, nxt);
+    ecx = cx - (edge_x ? 1u : 0u);
+    e1 = cvt_byte<0>(cur.mrow[0]); e2 = cvt_byte<0>(cur.mrow[1]); e3 = cvt_byte<1>(cur.mrow[0]); e4 = cvt_byte<1>(cur.mrow[1]);
+  } else {
+    // In the last column sampleMap's right tap IS the left one (gainmapmath.cpp:690-703, xu == xl): the two bytes are loaded one
+    // column to the left, the right tap is byte 1 either way, the left tap byte 0 -- or byte 1 in the last column.
+    apply_load_cell_pk(c, im, ncx, ncy, ncx - (ncx + 1u == c.map_w ? 1u : 0u), min(ncy + 1u, c.map_h - 1u), nxt);
+    e3 = cvt_byte<1>(cur.mrow[0]); e4 = cvt_byte<1>(cur.mrow[1]);
+    e1 = edge_x ? e3 : cvt_byte<0>(cur.mrow[0]); e2 = edge_x ? e4 : cvt_byte<0>(cur.mrow[1]);
+  }
+  // all waves of a large launch, and of a small one all but those touching the last column / row, take the SGPR-weight variant
+  const bool interior = EDGE_BLOCKS || __builtin_amdgcn_ballot_w64(edge_x || edge_y) == 0ull;
+  const float* wt = s_idw + (edge_x ? (edge_y ? 192 : 64) : (edge_y ? 128 : 0));   // tables: 0 std, 1 no-right, 2 no-bottom, 3 corner
   if (T::kOetf) {
-    apply_cell_piped<FMT>(c, im.dst, ecx, ecy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, slot8, lut);
+    if (interior) apply_cell_piped<FMT>(c, im.dst, ecx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, slot8, lut);
+    else apply_cell_edge<FMT, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, wt, 0u, 4u, slot8, lut);
   } else {
     // F16: a full wave on one row of cells stores through the exchange area (apply_cell_piped1)
     uint4* xch = nullptr;
@@ -1496,45 +1447,46 @@ __device__ __forceinline__ bool apply_walk_cell(const AppConsts& c, const AppIma
       const uint64_t dup = __builtin_amdgcn_ballot_w64(ecx != cx);
       if (dup) dup_lane = (uint32_t)__builtin_ctzll(dup);
     }
-    apply_cell_piped1<FMT, MASK>(c, im, ecx, ecy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, lut, xch, dup_lane);
+    if (interior) apply_cell_piped1<FMT, MASK>(c, im, ecx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, lut, xch, dup_lane);
+    else apply_cell_edge<FMT, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, wt, 0u, 4u, slot8, lut);
   }
   cx = ncx; cy = ncy;
   return more;
 }
 
-template <int FMT, bool MASK>
+template <int FMT, bool MASK, bool EDGE_BLOCKS>
 __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, const AppBatch b) {
   typedef ApplyTab<FMT, MASK> T;
   __shared__ uint4 s_tab[T::kBytes / 16u];
   __shared__ uint4 s_xch[FMT == 1 ? (kApplyBlock / 64) * kXchPerWave : 1];   // F16: the waves' exchange areas
-  __shared__ float s_idw[4 * 64];   // edge blocks: the four weight tables (a lane's weights are then an LDS read, not a trip to L2 per pixel pair)
+  __shared__ float s_idw[4 * 64];   // sampleMap's four weight tables: per-lane weights are an LDS read, not a trip to L2 per pixel pair
   const uint32_t img_i = blockIdx.x, span = blockIdx.y;
   const AppImage& im = b.img[img_i];
-  const uint32_t edge_blocks = gridDim.y - c.walk_blocks;
-  const bool walk = span >= edge_blocks;   // (block-uniform; the edge blocks first: they are short and latency-bound, and a small launch would end on them)
-  uint32_t cx, cy, ek0 = 0u;
+  const uint32_t edge_blocks = EDGE_BLOCKS ? gridDim.y - c.walk_blocks : 0u;
+  const bool walk = !EDGE_BLOCKS || span >= edge_blocks;   // (block-uniform; the edge blocks first: they are short and latency-bound)
+  uint32_t cx, cy, er0 = 0u;
   bool any;
   if (walk) {
     const uint32_t idx = (span - edge_blocks) * c.cells_per_thread * kApplyBlock + threadIdx.x;
     cy = idx / c.map_w;
     cx = idx - cy * c.map_w;
-    any = cy + 1u < c.map_h;
+    any = cy < (EDGE_BLOCKS ? c.map_h - 1u : c.map_h);
   } else {
     // edge cell e: the last column top to bottom (the corner included), then the last row left to right; a thread takes
     // c.edge_rows (1, 2 or 4) of the cell's four pixel rows
     const uint32_t task = (span * kApplyBlock + threadIdx.x) * c.edge_rows;
     const uint32_t e = task >> 2;
-    ek0 = task & 3u;
+    er0 = task & 3u;
     any = e < c.map_w + c.map_h - 1u;
     cx = e < c.map_h ? c.map_w - 1u : e - c.map_h;
     cy = e < c.map_h ? e : c.map_h - 1u;
   }
   // the first cell's pixels are requested before the tables: both trips to memory overlap
   ApplyCellPk ca, cb;
-  ApplyCellIn ce;
-  if (any) {
-    if (walk) apply_load_cell_pk(c, im, cx - (cx + 1u == c.map_w ? 1u : 0u), cy, ca);
-    else apply_load_cell(c, im, cx, cy, ce);
+  if (any && walk) {
+    const uint32_t mx = cx - (cx + 1u == c.map_w ? 1u : 0u);
+    if (EDGE_BLOCKS) apply_load_cell_pk(c, im, mx, cy, mx, cy + 1u, ca);
+    else apply_load_cell_pk(c, im, cx, cy, mx, min(cy + 1u, c.map_h - 1u), ca);
   }
   {
     // all loads first, then all stores: one trip through L2's latency per block instead of one per piece
@@ -1544,16 +1496,18 @@ __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, 
     const uint2* src2 = reinterpret_cast<const uint2*>(c.tab + T::kS2Float);
     uint4 t1[kPer1];
     uint2 t2[kPer2 ? kPer2 : 1u];
+    float w = 0.0f;
+    if (!EDGE_BLOCKS || !walk) w = c_idw4[threadIdx.x & 255u];
 #pragma unroll
     for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; t1[k] = src1[i < kN1 ? i : kN1 - 1u]; }
 #pragma unroll
     for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; t2[k] = src2[(i < kN2 ? i : 0u) >> 5]; }
+    if ((!EDGE_BLOCKS || !walk) && threadIdx.x < 256u) s_idw[threadIdx.x] = w;
 #pragma unroll
     for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN1) s_tab[i] = t1[k]; }
 #pragma unroll
     for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN2) reinterpret_cast<uint2*>(s_tab)[T::kS2Base / 8u + i] = t2[k]; }
   }
-  if (!walk && threadIdx.x < 4u * 64u) s_idw[threadIdx.x] = c_idw4[threadIdx.x];
   __syncthreads();
   const char* lut = reinterpret_cast<const char*>(s_tab);
   const uint32_t slot8 = (threadIdx.x & 31u) << 3;
@@ -1566,19 +1520,17 @@ __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, 
   }
   if (!walk) {
     const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
-    const int tbl = edge_x ? (edge_y ? 3 : 1) : 2;
-    apply_cell_edge<FMT, MASK>(c, im, cx, cy, ce, tbl, ek0, c.edge_rows, slot8, lut, s_idw);
+    ApplyCellIn ce;
+    apply_load_cell(c, im, cx, cy, ce);
+    apply_cell_edge<FMT, MASK>(c, im, cx, cy, ce.yrow, ce.uu, ce.vv, (float)ce.mb[0], (float)ce.mb[1], (float)ce.mb[2], (float)ce.mb[3],
+                               s_idw + (edge_x ? (edge_y ? 192 : 64) : 128), er0, c.edge_rows, slot8, lut);
     return;
   }
   uint32_t left = c.cells_per_thread;
 #pragma unroll 1
   for (;;) {
-#ifdef UHDR_X_NOWAIT
-    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, ca, cb, slot8, lut, s_xch)) return;
-#else
-    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, ca, cb, slot8, lut, s_xch)) return;
-    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, cb, ca, slot8, lut, s_xch)) return;
-#endif
+    if (!apply_walk_cell<FMT, MASK, EDGE_BLOCKS>(c, im, cx, cy, left, ca, cb, slot8, lut, s_idw, s_xch)) return;
+    if (!apply_walk_cell<FMT, MASK, EDGE_BLOCKS>(c, im, cx, cy, left, cb, ca, slot8, lut, s_idw, s_xch)) return;
   }
 }
 
@@ -1688,7 +1640,9 @@ __device__ __forceinline__ void est_channel(float lin, float& out, float& doubt_
     out = v;
   } else {
     const _Float16 lo = (_Float16)(lin * (1.0f - kEstRel)), hi = (_Float16)(lin * (1.0f + kEstRel));
-    if (lo != hi || (lin != 0.0f && lin < 0x1p-13f)) doubt_min = -1.0f;
+    // (beyond the largest half the reference's floatToHalf does not saturate to infinity like the conversion above: it leaves
+    // 0x7C00 | mantissa bits, 0x7FFF from 2^17 on -- gainmapmath.cpp:745-780; reachable with minContentBoost > maxContentBoost)
+    if (lo != hi || (lin != 0.0f && lin < 0x1p-13f) || !(lin * (1.0f + kEstRel) < 65504.0f)) doubt_min = -1.0f;
     out = lin;
   }
 }
@@ -2086,32 +2040,26 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     hipLaunchKernelGGL((k_apply_lut<FMT>), dim3((unsigned)((total + per_block - 1u) / per_block), n), dim3(256), 0, s, c, b);
     return hipGetLastError();
   }
-  if (fast_s4 && !exact && c.map_w >= 2u && c.map_h >= 2u) {   // (the walk computes cells with a right and a lower neighbour)
-    const uint32_t total = c.map_w * (c.map_h - 1u);   // the walk's cells: all rows but the last
+  if (fast_s4 && !exact && c.map_w >= 2u && c.map_h >= 2u) {   // (apply_load_cell_pk reads two columns; the walk of a large launch two rows)
     // Cells per thread: a block copies 15-37 KB of tables into LDS before its first pixel, so it should walk many cells -- but a
-    // launch also has to fill 256 CUs x 4 resident blocks, or a single 4K image (2025 blocks of 256 cells) would leave three
+    // launch also has to fill 256 CUs x 2 resident blocks, or a single 4K image (2025 blocks of 256 cells) would leave three
     // quarters of the chip idle with 8 cells per thread.
+    // The cells of the last column and row have per-lane weights.  A large launch leaves them to edge blocks and keeps its walk
+    // one straight line of code at the register budget (k_apply_s4); in a small launch (one round of blocks, all resident at
+    // once) a handful of latency-bound edge blocks would be the blocks everything waits for (one 4K frame: 13 -> 17 us), so there
+    // the walk covers every cell and its waves on the last column / row run a second variant of the cell.
     AppConsts cc = c;
+    const bool edge_blocks = (uint64_t)c.map_w * c.map_h * (uint64_t)n > (uint64_t)kApplyBlock * 2048u;
+    const uint32_t total = c.map_w * (edge_blocks ? c.map_h - 1u : c.map_h);   // the walk's cells
     uint32_t cpt = kApplyMaxCellsPerThread;
     auto blocks = [&](uint32_t k) { return (uint64_t)((total + kApplyBlock * k - 1u) / (kApplyBlock * k)) * (uint64_t)n; };
     while (cpt > 1u && blocks(cpt) < 448u) cpt >>= 1;   // (a single 4K image: 507 blocks of 2 cells per thread, all resident at once)
-#ifdef UHDR_X_CPT_ENV
-    if (const char* e = getenv("UHDR_X_CPT")) cpt = (uint32_t)atoi(e);
-#endif
     cc.cells_per_thread = cpt;
     cc.walk_blocks = (total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt);
     cc.step_x = kApplyBlock % c.map_w;
     cc.step_y = kApplyBlock / c.map_w;
-    // The edge blocks (see k_apply_s4) go in front.  A small launch is one round of blocks, two per CU: there the edge threads take
-    // as few rows as still lets the launch fit that round (one 4K image: 506 walk blocks + 6 edge blocks of two rows per thread),
-    // because an edge block that outlives the walk blocks, or a block that has to wait for a slot, IS the launch's time.
     cc.edge_rows = 4u;
-    if (cc.walk_blocks * (uint32_t)n <= 512u)
-      while (cc.edge_rows > 1u && (cc.walk_blocks + apply_edge_blocks(c.map_w, c.map_h, cc.edge_rows / 2u)) * (uint32_t)n <= 512u) cc.edge_rows >>= 1;
-#ifdef UHDR_X_CPT_ENV
-    if (const char* e = getenv("UHDR_X_ER")) cc.edge_rows = (uint32_t)atoi(e);
-#endif
-    const dim3 grid(n, cc.walk_blocks + apply_edge_blocks(c.map_w, c.map_h, cc.edge_rows));
+    const dim3 grid(n, cc.walk_blocks + (edge_blocks ? apply_edge_blocks(c.map_w, c.map_h, cc.edge_rows) : 0u));
     // Channels can only exceed 1.0 (reach code 1024 and wrap through the reference's & 0x3ff; leave the stage-2 table) when the
     // display boost is capped below the content boost -- and then only if the largest factor the call can produce,
     // max(minBoost, maxBoost)^(display / max) / display, is above 1: a display boost of 2 under a content boost of 4.9 stays
@@ -2120,15 +2068,19 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     // a crafted XMP gets here through decodeJPEGR) `top` is far above 1 although display_boost == max_boost, and stage 2's cell
     // number -- byte 2 of 2 + 2u, unclamped -- would index past its 129 cells.
     const double top = std::exp2(std::fmax(c.log2_min_d, c.log2_max_d) * (double)c.display_boost / (double)c.max_boost) / (double)c.display_boost;
-    if (!(top <= 1.0 + 1e-6)) hipLaunchKernelGGL((k_apply_s4<FMT, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
-    else {
-      if (ApplyTab<FMT, false>::kOetf) {
-        // u = T(c) * 2^(g E), handed to stage 2 as 2 + 2u: the exponent's constants times g (1/2 for HLG: sqrt; m1 for PQ), plus 1
-        const float g = FMT == 3 ? 0.5f : UHDR_PQ_M1;
-        cc.fast.A *= g; cc.fast.A255 *= g; cc.fast.B = cc.fast.B * g + 1.0f;
-        for (int i = 0; i < 4 * 2 * 3 * 2; ++i) (&cc.fast.wD[0][0][0][0])[i] *= g;
-      }
-      hipLaunchKernelGGL((k_apply_s4<FMT, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
+    const bool mask = !(top <= 1.0 + 1e-6);
+    if (!mask && ApplyTab<FMT, false>::kOetf) {
+      // u = T(c) * 2^(g E), handed to stage 2 as 2 + 2u: the exponent's constants times g (1/2 for HLG: sqrt; m1 for PQ), plus 1
+      const float g = FMT == 3 ? 0.5f : UHDR_PQ_M1;
+      cc.fast.A *= g; cc.fast.A255 *= g; cc.fast.B = cc.fast.B * g + 1.0f;
+      for (int i = 0; i < 4 * 2 * 3 * 2; ++i) (&cc.fast.wD[0][0][0][0])[i] *= g;
+    }
+    if (mask) {
+      if (edge_blocks) hipLaunchKernelGGL((k_apply_s4<FMT, true, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
+      else hipLaunchKernelGGL((k_apply_s4<FMT, true, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
+    } else {
+      if (edge_blocks) hipLaunchKernelGGL((k_apply_s4<FMT, false, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
+      else hipLaunchKernelGGL((k_apply_s4<FMT, false, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
     }
   } else {
     const dim3 grid = px_grid(c.width, c.height, n);

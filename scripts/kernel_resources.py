@@ -17,18 +17,18 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
 
 _KEYS = {
-    "VGPRs": "vgpr", "AGPRs": "agpr", "SGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch",
+    "VGPRs": "vgpr", "AGPRs": "agpr", "TotalSGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch",
     "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
     "LDS Size [bytes/block]": "lds",
 }
 
 
 def demangle(names):
-    try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout
-        return out.split("\n")[:len(names)]
-    except Exception:
-        return list(names)
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "/usr/bin/c++filt"):
+        if os.path.exists(tool):
+            out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True, check=True).stdout
+            return out.split("\n")[:len(names)]
+    return list(names)
 
 
 def resources(src=None, defines=()):

@@ -352,6 +352,50 @@ def test_apply_min_boost_below_one_and_strides(hip, orc):
     _check_apply(hip, hip.OUTPUT_HDR_HLG, fast, ref, w, h, wrap=True)   # max_display_boost 4.0 < maxContentBoost 6.0
 
 
+@pytest.mark.parametrize("fmt", [1, 2, 3, 4])
+@pytest.mark.parametrize("boost", [FLT_MAX, 3.0])
+@pytest.mark.parametrize("dims", [(256, 128), (36, 20)])
+def test_apply_min_boost_above_max_boost(hip, orc, fmt, boost, dims):
+    """minContentBoost > maxContentBoost: nothing on the reference's apply path refuses it (only appendGainMap does), and a crafted
+    XMP reaches it through decodeJPEGR.  Values then pass 1.0 although the display boost is not capped below the content boost:
+    the FAST kernel must take its masked form (its stage-2 table ends at 1.0), EXACT must stay byte-identical."""
+    from tests.gpu_util import gpu_apply, to_dev
+    lib = hip.load()
+    w, h = dims
+    _, yuv = smooth_frame(w, h, 12)
+    gmap = np.random.RandomState(4).randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    minb, maxb = np.float32(8.0), np.float32(2.0)
+    dy, dmap = to_dev(yuv), to_dev(gmap)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    md = hip.metadata(maxb, minb)
+    ref = _oracle_apply(orc, yuv, w, h, gmap, maxb, fmt, boost, minb)
+    st, exact, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, boost, hip.APPLY_EXACT)
+    assert st == 0 and np.array_equal(exact, ref), int((exact != ref).sum())
+    st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, boost, hip.APPLY_FAST)
+    assert st == 0
+    _check_apply(hip, fmt, fast, ref, w, h, wrap=True)
+
+
+def test_exact_f16_beyond_the_largest_half(hip, orc):
+    """minContentBoost = 2^20 over maxContentBoost = 2: linear values up to 2^19.  floatToHalf (gainmapmath.cpp:745-780) does not
+    saturate to infinity there, so the f32 estimate of EXACT mode has to hand such pixels to the exact path."""
+    from tests.gpu_util import gpu_apply, to_dev
+    lib = hip.load()
+    w, h = 128, 64
+    _, yuv = smooth_frame(w, h, 13)
+    gmap = np.random.RandomState(5).randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    minb, maxb = np.float32(2.0 ** 20), np.float32(2.0)
+    dy, dmap = to_dev(yuv), to_dev(gmap)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    md = hip.metadata(maxb, minb)
+    ref = _oracle_apply(orc, yuv, w, h, gmap, maxb, hip.OUTPUT_HDR_LINEAR, FLT_MAX, minb)
+    assert int((ref.view(np.uint16) & 0x7FFF).max()) >= 0x7C00   # the frame does reach the patterns in question
+    st, exact, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, hip.OUTPUT_HDR_LINEAR, FLT_MAX, hip.APPLY_EXACT)
+    assert st == 0 and np.array_equal(exact, ref), int((exact != ref).sum())
+    st, plain, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, hip.OUTPUT_HDR_LINEAR, FLT_MAX, hip.APPLY_EXACT_UNFILTERED)
+    assert st == 0 and np.array_equal(plain, ref)
+
+
 def test_apply_unwritten_formats_and_errors(hip):
     from tests.gpu_util import to_dev, dev_empty, stream_ptr, to_host
     lib = hip.load()

@@ -89,6 +89,53 @@ def launch_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
+def workload_name(a, world, dry=False):
+    """config.workload: BASELINE.json configs[2] on one GPU; weak scaling keeps 64 frames per GPU, which at 8 GPUs IS configs[3]
+    (512 = 64 x 8 frames sharded 8-way, the min/max-boost all-reduce over RCCL)"""
+    fmt = getattr(a, "apply_format", "hlg").upper()
+    per = "%d x 3840x2160 P010(BT.2100,HLG)+YUV420(BT.709) per GPU, generate + apply(FAST)->RGBA1010102 %s, HBM-resident" % (a.frames, fmt)
+    if world == 1:
+        name = "configs[2]: batch " + per
+    elif a.frames * world == 512 and world == 8:
+        name = "configs[3]: batch 512 = 64 x 8 frames sharded 8-way (image i on rank i // 64), min/max-boost all-reduce over RCCL; " + per
+    else:
+        name = "configs[2] per GPU on %d GPUs (weak scaling towards configs[3] = 64 x 8): batch %d = " % (world, a.frames * world) + per
+    return ("dry run, no GPU work: " if dry else "") + name
+
+
+def collective_report(dist, backend, rank, world, device_label, local_mm, reduced, dev=None, iters=50):
+    """What lets a reader of rank 0's line check that the N ranks were real and that the path's one exchange crossed all of them:
+    every rank's identity (host, pid, device), the reduced (min, max) checked against the ranks' own contributions gathered on the
+    side, and the time of the 8-byte all-reduce by itself (median over `iters`, max over ranks).  Collective: every rank calls it."""
+    import socket
+    import statistics
+    import torch
+    ident = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "device": device_label}
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    contrib = [None] * world
+    dist.all_gather_object(contrib, [float(local_mm[0]), float(local_mm[1])])
+    want = [min(c[0] for c in contrib), max(c[1] for c in contrib)]
+    t = torch.zeros(2, dtype=torch.float32, device=dev if dev is not None else "cpu")
+    times = []
+    for _ in range(iters):
+        if dev is not None:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if dev is not None:
+            torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e6)
+    med = torch.tensor([statistics.median(times)], dtype=torch.float64, device=dev if dev is not None else "cpu")
+    dist.all_reduce(med, op=dist.ReduceOp.MAX)
+    return {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world": dist.get_world_size(), "ranks": idents,
+            "devices": [i["device"] for i in idents], "distinct_processes": len({(i["host"], i["pid"]) for i in idents}),
+            "distinct_devices": len({(i["host"], i["device"]) for i in idents}),
+            "allreduce_us": round(float(med.item()), 1), "allreduce_bytes": 8,
+            "content_minmax": [float(reduced[0]), float(reduced[1])], "content_minmax_of_gathered_contributions": want,
+            "reduction_checked": [float(reduced[0]), float(reduced[1])] == want}
+
+
 def dry_run(a, world, rank):
     """the multi-rank plumbing without a GPU: gloo rendezvous, the per-step content min/max reduction, the MAX over ranks of the
     elapsed time, one JSON line from rank 0"""
@@ -104,15 +151,19 @@ def dry_run(a, world, rank):
             _, work = sharding.reduce_content_minmax(mm, dist, red, async_op=True)
             sharding.finish_content_minmax(red, work)
     elapsed = time.perf_counter() - t0
+    coll = None
     if world > 1:
+        assert dist.get_world_size() == a.gpus == world, (dist.get_world_size(), a.gpus, world)
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        coll = collective_report(dist, "gloo", rank, world, "cpu", (1.0 + rank, 4.0 + rank), (float(red[0]), float(-red[1])))
     if rank == 0:
         print(json.dumps({"metric": "MPixels/sec gain-map generate+apply, 4K P010 batch", "value": None, "unit": "MPix/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "dry_run": True, "scaling": "weak",
                           "content_minmax": None if world == 1 else [float(red[0]), float(-red[1])],
-                          "config": {"workload": "dry run: no GPU work", "frames_per_gpu": a.frames}}), flush=True)
+                          "collective": coll,
+                          "config": {"workload": workload_name(a, world, dry=True), "frames_per_gpu": a.frames, "global_frames": a.frames * world}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -517,6 +568,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(a.backend)
+        assert dist.get_world_size() == a.gpus == world, "ranks in the process group %d, --gpus %d, WORLD_SIZE %d" % (dist.get_world_size(), a.gpus, world)
     lib = api.init(dev)
     fmt = api.OUTPUT_HDR_HLG if a.apply_format == "hlg" else api.OUTPUT_HDR_PQ
 
@@ -577,6 +629,14 @@ def main():
 
     gen_ms, gen_tot, gen_frames = avg_ms_per_launch(ev_gen)
     app_ms, app_tot, app_frames = avg_ms_per_launch(ev_app)
+    coll = None
+    if world > 1:   # (outside the timed region; every rank takes part)
+        mine = sharding.reduce_content_minmax(batch.minmax)             # this rank's own (min, max): no collective
+        glob = sharding.reduce_content_minmax(batch.minmax, dist)       # the step's exchange once more, joined
+        props = torch.cuda.get_device_properties(dev)
+        label = "cuda:%d %s%s" % (dev, props.name, (" pci " + str(getattr(props, "pci_bus_id", ""))) if hasattr(props, "pci_bus_id") else "")
+        coll = collective_report(dist, a.backend, rank, world, label, (float(mine[0]), float(mine[1])), (float(glob[0]), float(glob[1])),
+                                 dev=torch.device("cuda", dev) if a.backend == "nccl" else None)
 
     if rank == 0:
         mpix_frame = W * H / 1e6
@@ -617,9 +677,8 @@ def main():
                         "measurement after the step has kept the card busy for clock_ramp_ms"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 in, f32+f64 math, u8/u32 out",
             "data": "synthetic",
-            "config": {"workload": "configs[2]: batch %d x 3840x2160 P010(BT.2100,HLG)+YUV420(BT.709) per GPU, "
-                                   "generate + apply(FAST)->RGBA1010102 %s, HBM-resident" % (a.frames, a.apply_format.upper()),
-                       "frames_per_gpu": a.frames, "width": W, "height": H, "images_per_launch": min(CHUNK, a.frames),
+            "config": {"workload": workload_name(a, world),
+                       "frames_per_gpu": a.frames, "global_frames": a.frames * world, "width": W, "height": H, "images_per_launch": min(CHUNK, a.frames),
                        "parallelism": "one image batch per GPU, no pixel traffic between GPUs"},
             "roofline": {"bound": "hbm", "kernel": "k_apply_s4<HLG>" if dominant == "apply" else "k_generate<HLG,aligned>",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -639,6 +698,8 @@ def main():
                 "frac_of_8TBs_whole_step_per_gpu": round((GEN_BYTES + APP_BYTES) * total_frames / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
+        if coll is not None:
+            out["collective"] = coll
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, fmt, max(1, min(a.cpu_frames, a.frames)))
         if world == 1 and not a.no_other_configs:

@@ -25,6 +25,25 @@ def test_gpus_2_launches_two_ranks_and_reports_them():
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["steps"] == 3
     # rank r contributes (min, max) = (1 + r, 4 + r): the reduction went across both ranks
     assert d["content_minmax"] == [1.0, 5.0]
+    # what makes a multi-rank line self-proving (the driver's SCALE run carries the same object with backend nccl): the ranks'
+    # identities gathered on rank 0, the reduced pair checked against the gathered contributions, the all-reduce timed by itself
+    c = d["collective"]
+    assert c["world"] == 2 and c["backend"] == "gloo" and len(c["ranks"]) == 2 and [r["rank"] for r in c["ranks"]] == [0, 1]
+    assert c["distinct_processes"] == 2 and len({r["pid"] for r in c["ranks"]}) == 2 and len(c["devices"]) == 2
+    assert c["reduction_checked"] is True and c["content_minmax"] == c["content_minmax_of_gathered_contributions"] == [1.0, 5.0]
+    assert c["allreduce_us"] > 0 and c["allreduce_bytes"] == 8
+    assert d["config"]["global_frames"] == 8 and "2 GPUs" in d["config"]["workload"]
+
+
+def test_workload_names_the_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class A:
+        frames, apply_format = 64, "hlg"
+    assert bench.workload_name(A, 1).startswith("configs[2]: batch 64 x 3840x2160")
+    assert bench.workload_name(A, 8).startswith("configs[3]: batch 512 = 64 x 8 frames sharded 8-way")
+    assert "weak scaling towards configs[3]" in bench.workload_name(A, 4)
 
 
 def test_single_rank_dry_run_and_gpus_mismatch():

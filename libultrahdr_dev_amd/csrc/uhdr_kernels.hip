@@ -38,7 +38,18 @@ namespace uhdr {
 // 2 no-bottom, 3 corner (gainmapmath.h:184-228).  Filled by the host at uhdr_hip_init().
 __constant__ float c_idw4[4 * 64];
 
+// the standard table once more, arranged for two horizontally adjacent pixels per instruction:
+// [oy][pair][tap][pixel of the pair] (an aligned 8-byte scalar load is one packed operand)
+__constant__ float c_idw4p[64];
+
 hipError_t upload_idw4(const float* tables) {
+  float p[64];
+  for (int oy = 0; oy < 4; ++oy)
+    for (int pr = 0; pr < 2; ++pr)
+      for (int k = 0; k < 4; ++k)
+        for (int h = 0; h < 2; ++h) p[((oy * 2 + pr) * 4 + k) * 2 + h] = tables[oy * 16 + (2 * pr + h) * 4 + k];
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_idw4p), p, sizeof(p));
+  if (e != hipSuccess) return e;
   return hipMemcpyToSymbol(HIP_SYMBOL(c_idw4), tables, sizeof(float) * 4 * 64);
 }
 
@@ -1770,6 +1781,134 @@ __device__ __forceinline__ uint32_t est_cell(const AppConsts& c, const AppImage&
   return doubt;
 }
 
+// ---- the same estimate, two horizontally adjacent pixels per instruction (interior waves of k_apply_s4_est) --------------------------
+// The scalar cell above spends ~115 VALU instructions per pixel; v_pk_mul / v_pk_add / v_pk_fma_f32 do two floats per issue slot.
+// Every elementary function below performs, per element, the operation sequence of its scalar twin (srgb_inv_oetf_fast,
+// hlg_oetf_fast, pq_oetf_est: the error bounds tests/test_gpu_exact_filter.py measures for those hold unchanged); what differs:
+//   * the exponent's argument.  The reference rounds log2(max) * gain (a double product) to float, multiplies by the display boost
+//     and divides by the content boost.  Here, for |argument| <= 6 and minContentBoost == 1: the double product as a two-float
+//     product (exact but for a 2^-48 relative slip that moves the rounded result by one ulp once in 2^24 pixels; one ulp of an
+//     argument <= 6 moves the factor by <= 5e-7 relative: part of the budget the test checks) and the division as
+//     q + fma(-q, a, x) / a (div_const); other launches keep the scalar cell;
+//   * the doubt test: fract(max(v, 1/2) + d) < 2 d instead of min(f, 1 - f) < d -- the same interval but for one rounding at the
+//     magnitude of the code value, which kEstPkAbs carries.
+constexpr float kEstPkAbs = 6.2e-5f;   // one ulp at 1023
+__device__ __forceinline__ f2 srgb_inv_oetf_fast2(f2 e) {
+  const f2 lin = e * splat(1.0f / 12.92f);
+  const f2 x = (e + splat(0.055f)) * splat(1.0f / 1.055f);
+  const f2 p = (x * x) * exp2_2(splat(0.4f) * log2_2(x));
+  return (f2){e.x <= 0.04045f ? lin.x : p.x, e.y <= 0.04045f ? lin.y : p.y};
+}
+__device__ __forceinline__ f2 hlg_oetf_fast2(f2 e) {
+  const f2 lo = sqrt_2(splat(3.0f) * e);
+  const f2 hi = splat(UHDR_HLG_A * 0.693147180559945f) * log2_2(splat(12.0f) * e - splat(UHDR_HLG_B)) + splat(UHDR_HLG_C);
+  return (f2){e.x <= 1.0f / 12.0f ? lo.x : hi.x, e.y <= 1.0f / 12.0f ? lo.y : hi.y};
+}
+__device__ __forceinline__ f2 pq_oetf_est2(f2 e) {
+  const f2 p = exp2_2(splat(UHDR_PQ_M1) * log2_2(e));
+  const f2 w = (splat(1.0f - UHDR_PQ_C1) * (splat(1.0f) - p)) * rcp_2(pk_fma(splat(UHDR_PQ_C3), p, splat(1.0f)));
+  const f2 s = w * rcp_2(splat(2.0f) - w);
+  const f2 s2 = s * s;
+  f2 h = pk_fma(s2, splat(1.0f / 7.0f), splat(1.0f / 5.0f));
+  h = pk_fma(s2, h, splat(1.0f / 3.0f));
+  h = pk_fma(s2 * s, h, s);
+  const f2 r = exp2_2(h * splat(-2.0f * 1.4426950408889634f * UHDR_PQ_M2));
+  return (f2){e.x <= 0.0f ? 0.0f : r.x, e.y <= 0.0f ? 0.0f : r.y};
+}
+// one channel of a pixel pair: lin -> code values; dx / dy: that pixel has a channel in doubt (conditions, so that the three
+// channels of a pixel combine on the scalar unit)
+template <int FMT>
+__device__ __forceinline__ void est_channel2(f2 lin, f2& out, bool& dx, bool& dy) {
+  if (FMT != 1) {
+    const f2 v = (FMT == 3 ? hlg_oetf_fast2(lin) : FMT == 2 ? pq_oetf_est2(lin) : lin) * splat(1023.0f);
+    const f2 d = FMT == 4 ? pk_fma(v, splat(kEstRel), splat(kEstPkAbs)) : pk_fma(v, splat(kEstOetfRel), splat(kEstOetfAbs + kEstPkAbs));
+    const f2 w = (f2){fmaxf(v.x, 0.5f), fmaxf(v.y, 0.5f)} + d;
+    const f2 d2 = d + d;
+    out = v;
+    dx = dx || __builtin_amdgcn_fractf(w.x) < d2.x;
+    dy = dy || __builtin_amdgcn_fractf(w.y) < d2.y;
+  } else {
+    float o0, o1, m0 = 1.0f, m1 = 1.0f;
+    est_channel<1>(lin.x, o0, m0);
+    est_channel<1>(lin.y, o1, m1);
+    out = (f2){o0, o1};
+    dx = dx || m0 < 0.0f;
+    dy = dy || m1 < 0.0f;
+  }
+}
+template <int FMT>
+__device__ __forceinline__ uint32_t est_cell_pk(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, const ApplyCellIn& in) {
+  const f2 e1 = splat(map_to_float_fast(in.mb[0])), e2 = splat(map_to_float_fast(in.mb[1]));
+  const f2 e3 = splat(map_to_float_fast(in.mb[2])), e4 = splat(map_to_float_fast(in.mb[3]));
+  float crv[2][2], gcbu[2][2], gcrv[2][2], cbu[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float u = (float)((int)((in.uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      const float v = (float)((int)((in.vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      crv[r][k] = kP3Cr * v; gcbu[r][k] = kP3GCb * u; gcrv[r][k] = kP3GCr * v; cbu[r][k] = kP3Cb * u;
+    }
+  // log2(max) as two floats (the caller has checked |log2 max| display / max <= 6 and min == 1)
+  const float lh = (float)c.log2_max_d, ll = (float)(c.log2_max_d - (double)lh);
+  uint32_t doubt = 0u;
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy) {
+    f2 o[2][3];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const float* w = c_idw4p + (oy * 2 + pr) * 8;
+      f2 gain = e1 * (f2){w[0], w[1]};
+      gain = gain + e2 * (f2){w[2], w[3]};
+      gain = gain + e3 * (f2){w[4], w[5]};
+      gain = gain + e4 * (f2){w[6], w[7]};
+      // (float)(log2(max) * (double)gain), then * display / max as the reference rounds them
+      const f2 p = gain * splat(lh);
+      const f2 log_boost = p + pk_fma(gain, splat(ll), pk_fma(gain, splat(lh), -p));
+      const f2 x = log_boost * splat(c.display_boost);
+      const f2 q = x * splat(c.inv_max_boost);
+      const f2 arg = pk_fma(pk_fma(-q, splat(c.max_boost), x), splat(c.inv_max_boost), q);
+      const f2 factor = exp2_2(arg) * splat(c.inv_display_boost);
+      const f2 yf = (pr ? (f2){cvt_byte<2>(in.yrow[oy]), cvt_byte<3>(in.yrow[oy])} : (f2){cvt_byte<0>(in.yrow[oy]), cvt_byte<1>(in.yrow[oy])}) * splat(k255);
+      const int r2 = oy >> 1;
+      const f2 r = pk_add_sat(yf, splat(crv[r2][pr])), g = pk_add_sat(yf - splat(gcbu[r2][pr]), splat(-gcrv[r2][pr]));
+      const f2 b = pk_add_sat(yf, splat(cbu[r2][pr]));
+      bool dx = false, dy = false;
+      est_channel2<FMT>(srgb_inv_oetf_fast2(r) * factor, o[pr][0], dx, dy);
+      est_channel2<FMT>(srgb_inv_oetf_fast2(g) * factor, o[pr][1], dx, dy);
+      est_channel2<FMT>(srgb_inv_oetf_fast2(b) * factor, o[pr][2], dx, dy);
+      doubt |= (dx ? 1u << (oy * 4 + 2 * pr) : 0u) | (dy ? 2u << (oy * 4 + 2 * pr) : 0u);
+    }
+    const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;
+    if (FMT == 2 || FMT == 3) {
+      uint4 qv;
+      uint32_t* qq = &qv.x;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        qq[2 * pr] = (0x3ffu & (uint32_t)o[pr][0].x) | ((0x3ffu & (uint32_t)o[pr][1].x) << 10) | ((0x3ffu & (uint32_t)o[pr][2].x) << 20) | (0x3u << 30);
+        qq[2 * pr + 1] = (0x3ffu & (uint32_t)o[pr][0].y) | ((0x3ffu & (uint32_t)o[pr][1].y) << 10) | ((0x3ffu & (uint32_t)o[pr][2].y) << 20) | (0x3u << 30);
+      }
+      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), qv);
+    } else if (FMT == 1) {
+      const uint2 a = pack_f16_hw(o[0][0].x, o[0][1].x, o[0][2].x), bb = pack_f16_hw(o[0][0].y, o[0][1].y, o[0][2].y);
+      const uint2 cc = pack_f16_hw(o[1][0].x, o[1][1].x, o[1][2].x), d = pack_f16_hw(o[1][0].y, o[1][1].y, o[1][2].y);
+      uint4* dst = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+      dst[0] = make_uint4(a.x, a.y, bb.x, bb.y);
+      dst[1] = make_uint4(cc.x, cc.y, d.x, d.y);
+    } else {
+      const size_t plane = (size_t)c.width * c.height;
+      uint16_t* base16 = static_cast<uint16_t*>(im.dst);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const uint32_t q0 = 0x3ffu & (uint32_t)o[0][p].x, q1 = 0x3ffu & (uint32_t)o[0][p].y;
+        const uint32_t q2 = 0x3ffu & (uint32_t)o[1][p].x, q3 = 0x3ffu & (uint32_t)o[1][p].y;
+        *reinterpret_cast<uint2*>(base16 + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+      }
+    }
+  }
+  return doubt;
+}
+
 template <int FMT>
 __global__ void __launch_bounds__(256) k_apply_s4_est(const AppConsts c, const AppBatch b) {
   const AppImage& im = b.img[blockIdx.y];
@@ -1783,8 +1922,11 @@ __global__ void __launch_bounds__(256) k_apply_s4_est(const AppConsts c, const A
     apply_load_cell(c, im, cx, cy, in);
     const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
     const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
-    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) doubt = est_cell<FMT, true>(c, im, cx, cy, in, 0);
-    else doubt = est_cell<FMT, false>(c, im, cx, cy, in, tbl);
+    // (launch-uniform: the packed cell's exponent is budgeted for arguments up to 6 and takes minContentBoost == 1)
+    const bool pk = c.log2_min_d == 0.0 && __builtin_fabs(c.log2_max_d) * (double)(c.display_boost * c.inv_max_boost) <= 6.0;
+    if (__builtin_amdgcn_ballot_w64(tbl != 0) != 0ull) doubt = est_cell<FMT, false>(c, im, cx, cy, in, tbl);
+    else if (pk) doubt = est_cell_pk<FMT>(c, im, cx, cy, in);
+    else doubt = est_cell<FMT, true>(c, im, cx, cy, in, 0);
   }
   // one append per block
   __shared__ uint32_t s_part[4], s_base;

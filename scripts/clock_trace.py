@@ -48,7 +48,7 @@ def sampler():
             samples.append((t, cur(card + "/pp_dpm_sclk"), cur(card + "/pp_dpm_mclk"), cur(card + "/pp_dpm_fclk"),
                             hw(card, "power1_average") // 1000000 if hw(card, "power1_average") > 0 else hw(card, "power1_input") // 1000000,
                             hw(card, "temp2_input") // 1000, hw(card, "temp3_input") // 1000))
-        time.sleep(0.02)
+        time.sleep(0.005)
 
 
 torch.cuda.set_device(0)
@@ -57,23 +57,37 @@ lib = api.init(0)
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 w = bench.Batch(lib, 64, 0)
 w.generate(stream); w.apply(stream, api.OUTPUT_HDR_HLG); torch.cuda.synchronize()
+# the card is left alone for a moment first, as it is when bench.py's setup ends
+torch.cuda.synchronize(); time.sleep(1.0)
 th = threading.Thread(target=sampler); th.start()
 t0 = time.perf_counter()
 rows = []
+first = True
 while time.perf_counter() - t0 < secs:
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * 20)]
+    n = 60 if first else 20
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * n)]
     tb = time.perf_counter() - t0
-    for i in range(20):
+    for i in range(n):
         ev[3 * i].record(); w.generate(stream); ev[3 * i + 1].record(); w.apply(stream, api.OUTPUT_HDR_HLG); ev[3 * i + 2].record()
     torch.cuda.synchronize()
-    g = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(20)) / 20
-    a = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(20)) / 20
-    rows.append((tb, g, a))
+    if first:   # the first 60 steps one by one: what `cold_start` measures (5 warmup + 20 timed steps) lies in here
+        acc = 0.0
+        for i in range(n):
+            g, a = ev[3 * i].elapsed_time(ev[3 * i + 1]), ev[3 * i + 1].elapsed_time(ev[3 * i + 2])
+            rows.append((tb + acc * 1e-3, g, a)); acc += g + a
+        first = False
+    else:
+        g = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(n)) / n
+        a = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(n)) / n
+        rows.append((tb, g, a))
 stop = True; th.join()
 print("card", card)
-print("# t_s generate_ms apply_ms")
-for r in rows[::max(1, len(rows) // 60)]:
-    print("%.3f %.4f %.4f" % r)
+print("# t_s generate_ms apply_ms   (the first 60 rows: single steps from an idle card; then averages of 20)")
+keep = rows[:60] + rows[60::max(1, (len(rows) - 60) // 40)]
+for r in keep:
+    print("%.4f %.4f %.4f" % r)
 print("# t_s sclk mclk fclk power_W temp_hotspot temp_mem")
-for s in samples[::max(1, len(samples) // 60)]:
-    print("%.3f %s %s %s %s %s %s" % ((s[0] - t0,) + s[1:]))
+early = [x for x in samples if x[0] - t0 < 0.3]
+late = [x for x in samples if x[0] - t0 >= 0.3]
+for x in early + late[::max(1, len(late) // 40)]:
+    print("%.3f %s %s %s %s %s %s" % ((x[0] - t0,) + x[1:]))

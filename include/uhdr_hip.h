@@ -27,7 +27,13 @@
  *    YUV420: U plane at chroma_data, V plane at chroma_data + chroma_stride*(height/2).
  *  - mem_space says where every data pointer of the call lives:
  *      UHDR_HIP_MEM_DEVICE  device pointers; the call only enqueues kernels on `stream`
- *                           (asynchronous; graph-capturable; nothing is allocated or copied);
+ *                           (asynchronous; graph-capturable; nothing is allocated or copied -- with three
+ *                           exceptions, each the FIRST use of a stream's workspace: a generate launch of more
+ *                           than a few images allocates the stream's 4 MiB statistics workspace, an EXACT apply
+ *                           its lists of pixels in doubt (first call, and again for larger images), and an apply
+ *                           with a map scale factor the device holds no weight table for uploads one and waits.
+ *                           uhdr_hip_stream_reserve() does all of that ahead of time -- call it before capturing
+ *                           a graph --, uhdr_hip_stream_release() gives a stream's workspace back);
  *      UHDR_HIP_MEM_HOST    host pointers; the library stages through its own device workspace
  *                           (H2D, kernels, D2H) and returns after the result is back in host memory.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
@@ -154,6 +160,14 @@ int uhdr_hip_device_count(void);
 int uhdr_hip_init(int device);
 /* release the workspace of every initialised device */
 int uhdr_hip_shutdown(void);
+/* Allocate, now, what device-memory calls on `stream` would otherwise allocate at their first use (see mem_space above): the
+ * statistics workspace of generate, and -- when exact_images > 0 -- the lists EXACT apply needs for launches of up to
+ * exact_images images of width x height pixels (at most 64 per launch; 0 for width / height with exact_images == 0), and the
+ * sampleMap weight table of `map_scale_factor` (0: none; 4 is always resident).  After this the calls it covers only enqueue. */
+int uhdr_hip_stream_reserve(void* stream, int exact_images, size_t width, size_t height, int map_scale_factor);
+/* Free what the library holds for `stream` (waits for the stream first).  A service that creates and destroys streams calls this
+ * before hipStreamDestroy: workspaces are keyed by the stream handle, and a recycled handle would inherit the old one. */
+int uhdr_hip_stream_release(void* stream);
 /* last HIP error text seen by the library on this thread ("" if none) */
 const char* uhdr_hip_last_error(void);
 

@@ -63,6 +63,8 @@ SIGNATURES = {
     "uhdr_hip_device_count": (C.c_int, []),
     "uhdr_hip_init": (C.c_int, [C.c_int]),
     "uhdr_hip_shutdown": (C.c_int, []),
+    "uhdr_hip_stream_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_int]),
+    "uhdr_hip_stream_release": (C.c_int, [C.c_void_p]),
     "uhdr_hip_last_error": (C.c_char_p, []),
     "uhdr_hip_generate_gainmap": (C.c_int, [_IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_apply_gainmap": (C.c_int, [_IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_int, C.c_void_p]),

@@ -635,6 +635,82 @@ int uhdr_hip_init(int device) {
   return UHDR_HIP_NO_ERROR;
 }
 
+// the workspaces device-memory calls keep per stream (uhdr_hip_stream_reserve / _release hand them out ahead of time / take them back)
+int stat_workspace(DeviceState* st, hipStream_t s, uint32_t** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  uint32_t** wp = nullptr;
+  try { wp = &st->stat_ws[s]; } catch (const std::bad_alloc&) { return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE; }
+  uint32_t*& w = *wp;
+  if (w == nullptr) {   // cleared once, in stream order: every launch leaves the headers cleared behind it
+    HIP_TRY(hipMalloc(&w, kStatWsBytes));
+    HIP_TRY(hipMemsetAsync(w, 0, kStatWsBytes, s));
+  }
+  *out = w;
+  return UHDR_HIP_NO_ERROR;
+}
+int exact_workspace(DeviceState* st, hipStream_t s, int images, uint32_t cap, uint32_t** out) {
+  const size_t need = ((size_t)kMaxChunk * kExHdrWords + (size_t)images * kExLists * cap) * 4u;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DeviceState::ExWs* wp = nullptr;
+  try {
+    wp = &st->ex_ws[s];
+    if (wp->bytes < need && wp->p) st->retired.reserve(st->retired.size() + 1);
+  } catch (const std::bad_alloc&) {
+    return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  }
+  DeviceState::ExWs& w = *wp;
+  if (w.bytes < need) {
+    // another caller of this stream may be about to launch with the old one: it stays allocated (sizes at least double)
+    if (w.p) { st->retired.push_back(w.p); w.p = nullptr; }
+    const size_t grown = std::max(need, 2 * w.bytes);
+    w.bytes = 0;
+    HIP_TRY(hipMalloc(&w.p, grown));
+    w.bytes = grown;
+    HIP_TRY(hipMemsetAsync(w.p, 0, (size_t)kMaxChunk * kExHdrWords * 4u, s));   // the headers: cleared once, left cleared by every launch
+  }
+  *out = w.p;
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_stream_reserve(void* stream, int exact_images, size_t width, size_t height, int map_scale_factor) {
+  DeviceState* st = nullptr;
+  int rc0 = current_state(&st);
+  if (rc0 != UHDR_HIP_NO_ERROR) return rc0;
+  if (exact_images < 0 || map_scale_factor < 0 || (exact_images > 0 && (width == 0 || height == 0 || (uint64_t)width * height > 0xFFFFFFFFull)))
+    return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint32_t* w = nullptr;
+  int rc = stat_workspace(st, s, &w);
+  if (rc != UHDR_HIP_NO_ERROR) return rc;
+  if (exact_images > 0) {
+    const int m = exact_images < kMaxChunk ? exact_images : kMaxChunk;
+    if ((rc = exact_workspace(st, s, m, ex_list_cap((uint64_t)width * height), &w)) != UHDR_HIP_NO_ERROR) return rc;
+  }
+  if (map_scale_factor > 0) {
+    const float* idw = nullptr;
+    float* transient = nullptr;
+    if ((rc = idw_for_scale(st, map_scale_factor, &idw, &transient)) != UHDR_HIP_NO_ERROR) return rc;
+    if (transient) { (void)hipStreamSynchronize(s); (void)hipFree(transient); }   // (a table too large to keep: nothing to reserve)
+  }
+  HIP_TRY(hipStreamSynchronize(s));   // the clears are done: what follows on the stream only enqueues
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_stream_release(void* stream) {
+  DeviceState* st = nullptr;
+  const int rc0 = current_state(&st);
+  if (rc0 != UHDR_HIP_NO_ERROR) return rc0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipStreamSynchronize(s));
+  std::lock_guard<std::mutex> pl(g_pair_mu);   // no launch of a generate / apply pair is between its workspace and its kernels
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto a = st->stat_ws.find(s);
+  if (a != st->stat_ws.end()) { if (a->second) (void)hipFree(a->second); st->stat_ws.erase(a); }
+  auto b = st->ex_ws.find(s);
+  if (b != st->ex_ws.end()) { if (b->second.p) (void)hipFree(b->second.p); st->ex_ws.erase(b); }
+  return UHDR_HIP_NO_ERROR;
+}
+
 int uhdr_hip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   int prev = -1;
@@ -806,6 +882,7 @@ int uhdr_hip_jpeg_progressive_coefficients(const void* jpeg, size_t jpeg_size, i
   if (jpeg == nullptr || blocks == nullptr || width == nullptr || height == nullptr || gray == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   jpeg::DecInfo info;
   const int prc = jpeg::parse_header(static_cast<const uint8_t*>(jpeg), jpeg_size, &info);
+  if (prc == -3) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   if (prc == -2 || (prc == 0 && !info.progressive)) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
   if (prc != 0) return UHDR_HIP_UNKNOWN_ERROR;
   *width = info.w; *height = info.h; *gray = info.gray;
@@ -833,6 +910,7 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
 #ifdef UHDR_JD_TIMING
   const auto T1 = std::chrono::steady_clock::now();
 #endif
+  if (prc == -3) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
   if (prc != 0) return UHDR_HIP_UNKNOWN_ERROR;
   const size_t w = (size_t)info.w, h = (size_t)info.h;
@@ -925,7 +1003,11 @@ int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bo
   const bool sdr = output_format == UHDR_HIP_OUTPUT_SDR;   // the gain map is neither decompressed nor (unless asked for) read (:728, :754)
   jpegr::Range img[2];
   bool by_header = false;   // both ranges and both headers in one walk per image (the file the reference's encoder writes)
+  bool have0 = false;       // the primary image at least (kept when the second image needs the container's walk: a progressive
+                            // primary has had all its scans entropy-decoded by then, once is enough)
+  size_t len0 = 0;
   if (file != nullptr && jpegr_size >= 4 && file[0] == 0xFF && file[1] == 0xD8 && image_by_header(file, jpegr_size, 0, &f->info[0], &img[0].len)) {
+    have0 = true; len0 = img[0].len;
     img[0].begin = 0;
     size_t pos = img[0].len;
     while (pos + 1 < jpegr_size) {   // the next SOI, as find_images looks for it
@@ -947,7 +1029,9 @@ int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bo
   }
   for (int k = 0; k < (sdr ? 1 : 2); ++k) {   // the headers, parsed once (jpeg_read_header of either decompressImage call, :690-694 / :731-733)
     f->jpg[k] = file + img[k].begin; f->len[k] = img[k].len;
-    const int prc = by_header ? 0 : jpeg::parse_header(f->jpg[k], f->len[k], &f->info[k]);
+    const bool parsed = by_header || (k == 0 && have0 && img[0].begin == 0 && img[0].len == len0);
+    const int prc = parsed ? 0 : jpeg::parse_header(f->jpg[k], f->len[k], &f->info[k]);
+    if (prc == -3) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
     if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
     if (prc != 0 || f->info[k].w > 8192 || f->info[k].h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;
   }
@@ -1797,14 +1881,9 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
     std::unique_lock<std::mutex> pair_lk(g_pair_mu, std::defer_lock);
     if (resolve) pair_lk.lock();
     if (resolve) {
-      std::lock_guard<std::mutex> lk(g_mu);
-      uint32_t** wp = nullptr;
-      try { wp = &st->stat_ws[s]; } catch (const std::bad_alloc&) { return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE; }
-      uint32_t*& w = *wp;
-      if (w == nullptr) {   // cleared once: every launch leaves the headers cleared behind it
-        HIP_TRY(hipMalloc(&w, kStatWsBytes));
-        HIP_TRY(hipMemset(w, 0, kStatWsBytes));
-      }
+      uint32_t* w = nullptr;
+      const int wrc = stat_workspace(st, s, &w);
+      if (wrc != UHDR_HIP_NO_ERROR) return wrc;
       c.stat_ws = w;
       c.stat_keys = keys ? w + 4 : nullptr;
       c.stat_stride = kStatWords;
@@ -1876,26 +1955,10 @@ int uhdr_hip_apply_gainmap_batch(int n, const uhdr_hip_image_t* yuvs, const uhdr
         std::fabs(c.log2_min_d) <= 32.0 && std::fabs(c.log2_max_d) <= 32.0) {
       pair_lk.lock();
       const uint32_t cap = ex_list_cap((uint64_t)c.width * c.height);
-      const size_t need = ((size_t)kMaxChunk * kExHdrWords + (size_t)m * kExLists * cap) * 4u;
-      std::lock_guard<std::mutex> lk(g_mu);
-      DeviceState::ExWs* wp = nullptr;
-      try {
-        wp = &st->ex_ws[s];
-        if (wp->bytes < need && wp->p) st->retired.reserve(st->retired.size() + 1);
-      } catch (const std::bad_alloc&) {
-        return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
-      }
-      DeviceState::ExWs& w = *wp;
-      if (w.bytes < need) {
-        // another caller of this stream may be about to launch with the old one: it stays allocated (sizes at least double)
-        if (w.p) { st->retired.push_back(w.p); w.p = nullptr; }
-        const size_t grown = std::max(need, 2 * w.bytes);
-        w.bytes = 0;
-        HIP_TRY(hipMalloc(&w.p, grown));
-        w.bytes = grown;
-        HIP_TRY(hipMemsetAsync(w.p, 0, (size_t)kMaxChunk * kExHdrWords * 4u, s));   // the headers: cleared once, left cleared by every launch
-      }
-      c.ex_ws = w.p;
+      uint32_t* w = nullptr;
+      const int wrc = exact_workspace(st, s, m, cap, &w);
+      if (wrc != UHDR_HIP_NO_ERROR) return wrc;
+      c.ex_ws = w;
       c.ex_cap = cap;
     }
     if (writes) HIP_TRY(launch_apply(c, b, m, output_format, apply_mode, fast, s));

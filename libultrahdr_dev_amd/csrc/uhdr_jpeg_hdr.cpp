@@ -13,6 +13,8 @@
 
 #include "uhdr_jpeg.h"
 
+#include <new>
+
 namespace uhdr {
 namespace jpeg {
 
@@ -112,7 +114,17 @@ size_t skip_entropy_coded(const uint8_t* p, size_t e, size_t n) {
   }
 }
 
+static int parse_header_impl(const uint8_t* jpg, size_t n, DecInfo* info);
+// 0 ok, -1 malformed, -2 outside what is supported, -3 out of memory (the vectors of DecInfo; a progressive frame's coefficients):
+// the callers are extern "C" entry points, nothing may throw through them
 int parse_header(const uint8_t* jpg, size_t n, DecInfo* info) {
+  try {
+    return parse_header_impl(jpg, n, info);
+  } catch (const std::bad_alloc&) {
+    return -3;
+  }
+}
+static int parse_header_impl(const uint8_t* jpg, size_t n, DecInfo* info) {
   if (jpg == nullptr || n < 4 || jpg[0] != 0xFF || jpg[1] != 0xD8) return -1;
   *info = DecInfo();
   static const uint8_t nat[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,

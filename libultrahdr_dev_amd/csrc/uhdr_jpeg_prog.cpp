@@ -178,8 +178,7 @@ int decode_progressive(const uint8_t* jpg, size_t n, DecInfo* info) {
       nblk = mcus_x * mcus_y * (nc == 1 ? 1u : 6u);
       bw[0] = (uint32_t)((w + 7) / 8); bh[0] = (uint32_t)((h + 7) / 8);
       bw[1] = bw[2] = (uint32_t)(((w + 1) / 2 + 7) / 8); bh[1] = bh[2] = (uint32_t)(((h + 1) / 2 + 7) / 8);
-      coef.assign((size_t)nblk * 64u, 0);
-      frame = true;
+      frame = true;   // (the coefficient array -- up to 200 MB for an 8192 x 8192 frame -- is allocated at the first valid scan header)
     } else if (m == 0xC0 || m == 0xC1 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
       return -2;
     } else if (m == 0xDD) {
@@ -198,6 +197,7 @@ int decode_progressive(const uint8_t* jpg, size_t n, DecInfo* info) {
         sc[i] = c; td[i] = seg[2 + 2 * i] >> 4; ta[i] = seg[2 + 2 * i] & 15;
         if (td[i] > 3 || ta[i] > 3) return -1;
       }
+      if (coef.empty()) coef.assign((size_t)nblk * 64u, 0);
       const int Ss = seg[1 + 2 * ns], Se = seg[2 + 2 * ns], Ah = seg[3 + 2 * ns] >> 4, Al = seg[3 + 2 * ns] & 15;
       // jdphuff.c start_pass_phuff_decoder: the progression parameters must make sense
       const bool is_dc = Ss == 0;
@@ -255,8 +255,10 @@ int decode_progressive(const uint8_t* jpg, size_t n, DecInfo* info) {
                 const int s = dc_t[i].decode(br);
                 if (s < 0 || s > 15) return -1;
                 const int diff = s ? extend(br.get(s), s) : 0;
-                pred[c] += diff;
-                blk[0] = (int16_t)(pred[c] * (1 << Al));
+                // (unsigned: a hostile file can run the predictor or the shift out of int; what is stored is the low 16 bits either
+                // way, as libjpeg's JCOEF assignment keeps them, and the device's running sum is taken modulo 2^16 as well)
+                pred[c] = (int)((unsigned)pred[c] + (unsigned)diff);
+                blk[0] = (int16_t)(uint16_t)((unsigned)pred[c] << Al);
               } else if (br.get(1)) {
                 blk[0] = (int16_t)(blk[0] | p1);
               }
@@ -345,7 +347,7 @@ int decode_progressive(const uint8_t* jpg, size_t n, DecInfo* info) {
       const int c = nc == 1 ? 0 : ((b % 6u) < 4u ? 0 : (int)(b % 6u) - 3);
       int16_t* blk = coef.data() + (size_t)b * 64u;
       const int v = blk[0];
-      blk[0] = (int16_t)(v - prev[c]);
+      blk[0] = (int16_t)(uint16_t)((unsigned)v - (unsigned)prev[c]);   // modulo 2^16: k_jd_idct reads the running sum as int16
       prev[c] = v;
     }
   }

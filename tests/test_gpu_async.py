@@ -69,6 +69,44 @@ def test_batch_calls_are_graph_capturable(hip, orc):
     assert float(mm[0]) <= float(mm[1])
 
 
+def test_reserved_stream_captures_first_use_and_release_frees(hip, orc):
+    """A stream nobody has used: uhdr_hip_stream_reserve allocates its workspaces (generate's statistics, EXACT apply's lists), so
+    the very first generate / EXACT apply on it can be captured into a graph; uhdr_hip_stream_release gives the memory back and the
+    stream works again afterwards (its workspaces are allocated afresh)."""
+    lib = hip.load()
+    n, w, h = 40, 256, 128    # (enough pairs for the deferred-resolve form of generate: the one with a workspace)
+    keep, ya, pa, ma, oa, host = _batch(hip, orc, n, w, h, 900)
+    md = hip.Metadata()
+    mm = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    s = C.c_void_p(side.cuda_stream)
+    assert lib.uhdr_hip_stream_reserve(s, n, w, h, 4) == 0
+    free0 = torch.cuda.mem_get_info()[0]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        sc = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert sc.value == s.value
+        assert lib.uhdr_hip_generate_gainmap_batch(n, ya, pa, hip.TF_HLG, C.byref(md), ma, 0, C.c_void_p(mm.data_ptr()), sc) == 0
+        assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX, oa, hip.APPLY_EXACT, sc) == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "the captured calls allocated"
+    assert all(int(dm.sum()) == 0 for _, _, dm, _ in host), "capture must not execute the kernels"
+    g.replay()
+    torch.cuda.synchronize()
+    from tests.gpu_util import to_host
+    for p010, yuv, dm, do in host[:6]:   # EXACT: the oracle's bytes
+        st, omap, omd = orc.generate("orc_", orc.yuv420_image(yuv, w, h, 0), orc.p010_image(p010, w, h, 2), 1)
+        assert np.array_equal(to_host(dm, omap.size).reshape(omap.shape), omap)
+        st, ref, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, 0), omap, omd, orc.OUT_HDR_HLG, FLT_MAX)
+        assert np.array_equal(to_host(do, w * h * 4), ref.view(np.uint8).reshape(-1))
+    del g
+    assert lib.uhdr_hip_stream_release(s) == 0
+    assert torch.cuda.mem_get_info()[0] > free0, "release did not free the stream's workspaces"
+    assert lib.uhdr_hip_generate_gainmap_batch(n, ya, pa, hip.TF_HLG, C.byref(md), ma, 0, C.c_void_p(mm.data_ptr()), s) == 0
+    side.synchronize()
+    assert lib.uhdr_hip_stream_release(s) == 0
+
+
 def test_two_host_threads_two_streams(hip, orc):
     lib = hip.load()
     w, h, n = 192, 96, 6

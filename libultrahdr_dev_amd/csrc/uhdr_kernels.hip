@@ -2191,11 +2191,13 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     // once) a handful of latency-bound edge blocks would be the blocks everything waits for (one 4K frame: 13 -> 17 us), so there
     // the walk covers every cell and its waves on the last column / row run a second variant of the cell.
     AppConsts cc = c;
-    const bool edge_blocks = (uint64_t)c.map_w * c.map_h * (uint64_t)n > (uint64_t)kApplyBlock * 2048u;
-    const uint32_t total = c.map_w * (edge_blocks ? c.map_h - 1u : c.map_h);   // the walk's cells
+    uint32_t total = c.map_w * c.map_h;   // the walk's cells
     uint32_t cpt = kApplyMaxCellsPerThread;
     auto blocks = [&](uint32_t k) { return (uint64_t)((total + kApplyBlock * k - 1u) / (kApplyBlock * k)) * (uint64_t)n; };
     while (cpt > 1u && blocks(cpt) < 448u) cpt >>= 1;   // (a single 4K image: 507 blocks of 2 cells per thread, all resident at once)
+    // (edge blocks from two rounds of blocks on: one 8K frame -- 506 blocks of 8 cells per thread -- takes 45 us without, 51 with)
+    const bool edge_blocks = blocks(cpt) > 1024u;
+    if (edge_blocks) total = c.map_w * (c.map_h - 1u);
     cc.cells_per_thread = cpt;
     cc.walk_blocks = (total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt);
     cc.step_x = kApplyBlock % c.map_w;

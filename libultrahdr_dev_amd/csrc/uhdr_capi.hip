@@ -455,7 +455,7 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
     for (int pr = 0; pr < 2; ++pr)
       for (int k = 1; k < 4; ++k)
         for (int j = 0; j < 2; ++j)
-          c.fast.wD[oy][pr][k - 1][j] = (float)((double)t[oy * 16 + (2 * pr + j) * 4 + k] * (c.log2_max_d - c.log2_min_d) * ratio / 255.0);
+          c.fast.wD[oy][pr][k - 1][j] = t[oy * 16 + (2 * pr + j) * 4 + k];   // the weight itself: launch_apply_t multiplies by the final A / 255
   c.tab = nullptr;
   c.ex_ws = nullptr;
   c.ex_cap = 0;

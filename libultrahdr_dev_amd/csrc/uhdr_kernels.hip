@@ -1293,7 +1293,7 @@ __device__ __forceinline__ void apply_cell_edge(const AppConsts& c, const AppIma
     for (int pr = 0; pr < 2; ++pr) {
       const f2 yraw = pr ? (f2){cvt_byte<2>(yw), cvt_byte<3>(yw)} : (f2){cvt_byte<0>(yw), cvt_byte<1>(yw)};
       const float* p0 = wt + oy * 16u + pr * 8;
-      const f2 w1 = (f2){p0[1], p0[5]} * splat(a255), w2 = (f2){p0[2], p0[6]} * splat(a255), w3 = (f2){p0[3], p0[7]} * splat(a255);
+      const f2 w1 = (f2){p0[1], p0[5]}, w2 = (f2){p0[2], p0[6]}, w3 = (f2){p0[3], p0[7]};   // (times A / 255 already: the kernel's prologue)
       const f2 E = pk_fma(splat(d4), w3, pk_fma(splat(d3), w2, pk_fma(splat(d2), w1, splat(base))));
       const f2 factor = exp2_2(E);
       f2 ch[3];
@@ -1470,7 +1470,7 @@ __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, 
   typedef ApplyTab<FMT, MASK> T;
   __shared__ uint4 s_tab[T::kBytes / 16u];
   __shared__ uint4 s_xch[FMT == 1 ? (kApplyBlock / 64) * kXchPerWave : 1];   // F16: the waves' exchange areas
-  __shared__ float s_idw[4 * 64];   // sampleMap's four weight tables: per-lane weights are an LDS read, not a trip to L2 per pixel pair
+  __shared__ float s_idw[4 * 64];   // sampleMap's four weight tables times A / 255: per-lane weights are an LDS read, not a trip to L2 per pixel pair
   const uint32_t img_i = blockIdx.x, span = blockIdx.y;
   const AppImage& im = b.img[img_i];
   const uint32_t edge_blocks = EDGE_BLOCKS ? gridDim.y - c.walk_blocks : 0u;
@@ -1508,7 +1508,7 @@ __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, 
     uint4 t1[kPer1];
     uint2 t2[kPer2 ? kPer2 : 1u];
     float w = 0.0f;
-    if (!EDGE_BLOCKS || !walk) w = c_idw4[threadIdx.x & 255u];
+    if (!EDGE_BLOCKS || !walk) w = c_idw4[threadIdx.x & 255u] * c.fast.A255;   // (before the rounding mode changes: launch_apply_t's product)
 #pragma unroll
     for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; t1[k] = src1[i < kN1 ? i : kN1 - 1u]; }
 #pragma unroll
@@ -2217,8 +2217,10 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
       // u = T(c) * 2^(g E), handed to stage 2 as 2 + 2u: the exponent's constants times g (1/2 for HLG: sqrt; m1 for PQ), plus 1
       const float g = FMT == 3 ? 0.5f : UHDR_PQ_M1;
       cc.fast.A *= g; cc.fast.A255 *= g; cc.fast.B = cc.fast.B * g + 1.0f;
-      for (int i = 0; i < 4 * 2 * 3 * 2; ++i) (&cc.fast.wD[0][0][0][0])[i] *= g;
     }
+    // sampleMap's standard weights times A / 255: ONE float product per weight, the same one the kernel forms for the per-lane
+    // tables of the last column / row (its prologue, round to nearest) -- a cell gets the same bytes whichever form computes it
+    for (int i = 0; i < 4 * 2 * 3 * 2; ++i) (&cc.fast.wD[0][0][0][0])[i] *= cc.fast.A255;
     if (mask) {
       if (edge_blocks) hipLaunchKernelGGL((k_apply_s4<FMT, true, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
       else hipLaunchKernelGGL((k_apply_s4<FMT, true, false>), grid, dim3(kApplyBlock), 0, s, cc, b);

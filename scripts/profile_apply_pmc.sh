@@ -6,13 +6,22 @@ OUT=/tmp/pmc_apply_$TAG
 rm -rf $OUT; mkdir -p $OUT $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --steps 4 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-other-configs"
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT --output-format csv -d $OUT/b -- python3 $ARGS > $OUT/b.log 2>&1
-rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/c -- python3 $ARGS > $OUT/c.log 2>&1
+timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1 || echo "pass a: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+echo "pass a done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT --output-format csv -d $OUT/b -- python3 $ARGS > $OUT/b.log 2>&1 || echo "pass b: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+echo "pass b done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+timeout -k 10 150 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/c -- python3 $ARGS > $OUT/c.log 2>&1 || echo "pass c: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+echo "pass c done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+# L2: requests, hits, misses, what leaves it (round 2's 24 M hits per launch were the traffic of six spilled registers)
+timeout -k 10 150 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/d -- python3 $ARGS > $OUT/d.log 2>&1 || echo "pass d: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+echo "pass d done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+# instruction classes that would show scratch traffic (scratch_* count as FLAT)
+timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_FLAT SQ_INSTS_FLAT_LDS_ONLY SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_VALU --output-format csv -d $OUT/e -- python3 $ARGS > $OUT/e.log 2>&1 || echo "pass e: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
+echo "pass e done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
 python3 - $OUT $R/gpurun_out/pmc_apply_$TAG.txt <<'PY'
 import csv, glob, sys, collections
 out = open(sys.argv[2], "w")
-for d in "abc":
+for d in "abcde":
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (sys.argv[1], d), recursive=True):
         for r in csv.DictReader(open(f)):

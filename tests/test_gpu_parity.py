@@ -713,6 +713,45 @@ def test_fast_apply_against_exact_apply_on_sixteen_4k_frames(hip, fmt):
         assert worst <= 1, (fmt, boost, worst)
 
 
+@pytest.mark.parametrize("fmt", [1, 3])
+@pytest.mark.parametrize("dims", [(3844, 2164), (2052, 1028)])
+def test_fast_apply_layouts_agree_on_ragged_frames(hip, fmt, dims):
+    """k_apply_s4 has two layouts for the cells of the last map column / row: edge blocks (launches of more than two rounds of blocks)
+    and the walk's own waves (smaller launches).  The same frames through one large call and through single-image calls must give
+    the same bytes -- map widths that are no multiple of a wave (961, 513 cells), so that waves wrap rows everywhere -- and the
+    large call stays within 1 LSB / half-ULP of the bit-exact mode."""
+    import torch
+    from libultrahdr_dev_amd import synth
+    from tests.gpu_util import stream_ptr
+    lib = hip.load()
+    w, h = dims
+    n = 36 if w > 3000 else 64
+    bpp = {1: 8, 3: 4}[fmt]
+    frames = [synth.lcg_frame(w, h, 8100 + i) for i in range(n)]
+    maps = [torch.randint(0, 256, ((w // 4) * (h // 4),), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    yi = [hip.yuv420_image(f[1].data_ptr(), w, h, hip.CG_BT709) for f in frames]
+    mi = [hip.mono_image(m.data_ptr(), w // 4, h // 4) for m in maps]
+    big = [torch.zeros(w * h * bpp, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    md = hip.metadata(float(np.float32(1000.0) / np.float32(203.0)))
+    ya, ma, ba = hip.image_array(yi), hip.image_array(mi), hip.image_array([hip.out_image(t.data_ptr()) for t in big])
+    assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), fmt, FLT_MAX, ba, hip.APPLY_FAST, stream_ptr()) == 0
+    one = torch.zeros(w * h * bpp, dtype=torch.uint8, device="cuda")
+    ex = torch.zeros(w * h * bpp, dtype=torch.uint8, device="cuda")
+    for i in range(0, n, 5):
+        oi, ei = hip.out_image(one.data_ptr()), hip.out_image(ex.data_ptr())
+        assert lib.uhdr_hip_apply_gainmap(C.byref(yi[i]), C.byref(mi[i]), C.byref(md), fmt, FLT_MAX, C.byref(oi), hip.APPLY_FAST, hip.MEM_DEVICE, stream_ptr()) == 0
+        assert lib.uhdr_hip_apply_gainmap(C.byref(yi[i]), C.byref(mi[i]), C.byref(md), fmt, FLT_MAX, C.byref(ei), hip.APPLY_EXACT, hip.MEM_DEVICE, stream_ptr()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(one, big[i]), "frame %d: the two layouts of k_apply_s4 disagree in %d bytes" % (i, int((one != big[i]).sum()))
+        if fmt == 3:
+            x, y = big[i].view(torch.int32), ex.view(torch.int32)
+            for sh in (0, 10, 20):
+                assert int((((x >> sh) & 0x3ff) - ((y >> sh) & 0x3ff)).abs().max()) <= LSB_TOL
+        else:
+            x, y = big[i].view(torch.int16).to(torch.int32), ex.view(torch.int16).to(torch.int32)
+            assert int((x - y).abs().max()) <= HALF_ULP_TOL
+
+
 def test_tonemap_and_convert_yuv_on_an_image_taller_than_the_grid(hip, orc):
     """131 080 rows: the row dimension of the launch grid stops at 65 535, the kernels stride over the rest"""
     from tests.gpu_util import to_dev, dev_empty, to_host, stream_ptr

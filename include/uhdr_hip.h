@@ -92,7 +92,9 @@ extern "C" {
  * Threads: every entry point may be called from several host threads.  Device-memory calls on different streams overlap; the
  * host-memory forms of generate / apply / tonemap / convert_yuv lease a staging set per call, so callers on their own streams
  * overlap their copies and kernels as well (one thread moves 0.54, eight 0.94 4K pairs per ms over the host link); the codec entry
- * points (jpeg_*, jpegr_*) serialise on the device's codec workspace. */
+ * points (jpeg_*, jpegr_*, the effects and table calls through host memory) lease a codec context per call -- staging buffers,
+ * decoder workspaces, a side stream -- so callers on their own streams overlap too (a JPEG decode is latency-bound: two threads
+ * decode nearly twice as many files per second as one). */
 #define UHDR_HIP_MEM_HOST 0
 #define UHDR_HIP_MEM_DEVICE 1
 

@@ -42,7 +42,7 @@ void set_err(const char* where, hipError_t e) {
 // ---- per-device state --------------------------------------------------------------------------
 // grow-only device staging buffers of one UHDR_HIP_MEM_HOST call.  The four pixel-path entry points (generate, apply, toneMap,
 // convertYuv) lease a set of their own for the duration of a call, so host callers on different streams overlap their copies and
-// kernels; the codec entry points use the device's own set (the DeviceState itself) under g_host_mu / g_jpegr_mu.
+// kernels; the codec entry points lease a whole context (CodecLease).
 struct StageSet {
   void* stage[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -66,13 +66,16 @@ struct DeviceState : StageSet {
   // EXACT apply behind its pre-filter: the lists of pixels in doubt (uhdr_kernels.h: ex_ws_bytes), per stream, grown on demand
   struct ExWs { uint32_t* p = nullptr; size_t bytes = 0; };
   std::map<hipStream_t, ExWs> ex_ws;
+  // the codec entry points (jpeg_*, jpegr_*, effects and tables through host memory) each lease a context of their own for the
+  // duration of a call -- staging slots, decoder pool, side stream and event -- so that callers on different streams overlap
+  // (CodecLease); a context is a DeviceState that borrows this one's tables
+  std::vector<std::unique_ptr<DeviceState>> codec_sets;   // every context ever leased ...
+  std::vector<DeviceState*> free_codec;                    // ... and those not in use (both under g_mu)
 };
 std::mutex g_mu;                    // guards g_dev (init / table cache)
-std::mutex g_host_mu;               // serialises the codec's host-staged calls (they share the device's own staging set)
 // a kernel and the resolve kernel behind it share a per-stream workspace: the pair is enqueued as one unit, so that two host threads
 // using the same stream cannot interleave their launches (they would read each other's lists)
 std::mutex g_pair_mu;
-std::mutex g_jpegr_mu;              // serialises uhdr_hip_jpegr_decode (slots 8-10), which calls the entry points above
 std::map<int, DeviceState> g_dev;
 
 // gainmapmath.cpp:69-110: sqrt runs in double on a float expression, weights are float divisions
@@ -531,6 +534,41 @@ class StageLease {
   StageSet* set_;
 };
 
+// A codec call's private context.  Round 2 serialised every jpeg_* / jpegr_* call of a process behind two mutexes because the calls
+// shared the device's staging slots, decoder pool and side stream; a JPEG decode is latency-bound (tens of synchronisation rounds
+// of one lane's work each), so two callers on their own streams now overlap almost completely (tests/test_gpu_async.py).
+class CodecLease {
+ public:
+  explicit CodecLease(DeviceState* st) : st_(st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!st_->free_codec.empty()) {
+      ctx_ = st_->free_codec.back();
+      st_->free_codec.pop_back();
+    } else {
+      try {
+        st_->free_codec.reserve(st_->codec_sets.size() + 1);   // (so that giving it back cannot fail)
+        st_->codec_sets.emplace_back(new DeviceState());
+        ctx_ = st_->codec_sets.back().get();
+      } catch (const std::bad_alloc&) {
+        ctx_ = nullptr;
+      }
+    }
+    if (ctx_) { ctx_->ready = true; ctx_->lut = st_->lut; }
+  }
+  ~CodecLease() {
+    if (ctx_ == nullptr) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    st_->free_codec.push_back(ctx_);
+  }
+  CodecLease(const CodecLease&) = delete;
+  CodecLease& operator=(const CodecLease&) = delete;
+  DeviceState* get() const { return ctx_; }
+
+ private:
+  DeviceState* st_;
+  DeviceState* ctx_ = nullptr;
+};
+
 // copy `rows` rows of `row_elems` elements of `esz` bytes from a strided host plane into a device
 // plane with pitch dpitch_elems.  Only bytes the reference itself would touch are read.
 int h2d_plane(void* d, size_t dpitch_elems, const void* h, size_t hstride_elems, size_t row_elems, size_t rows,
@@ -731,6 +769,13 @@ int uhdr_hip_shutdown(void) {
     for (void* q : kv.second.retired) (void)hipFree(q);
     if (kv.second.map_ready) (void)hipEventDestroy(kv.second.map_ready);
     if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
+    for (auto& cx : kv.second.codec_sets) {   // the leased codec contexts (their tables are this state's: not freed here)
+      for (void* q : cx->pool) if (q) (void)hipFree(q);
+      for (int i = 0; i < 14; ++i)
+        if (cx->stage[i]) (void)hipFree(cx->stage[i]);
+      if (cx->map_ready) (void)hipEventDestroy(cx->map_ready);
+      if (cx->aux) (void)hipStreamDestroy(cx->aux);
+    }
   }
   g_dev.clear();
   if (prev >= 0) (void)hipSetDevice(prev);
@@ -812,7 +857,8 @@ int uhdr_hip_jpeg_encode(const uhdr_hip_image_t* image, int quality, const void*
   int rc = current_state(&st);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  std::lock_guard<std::mutex> lk(g_host_mu);   // the encoder workspace is shared
+  CodecLease lease(st);   // the encoder workspace: this call's own
+  if ((st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
 
   const size_t ls = image->luma_stride ? image->luma_stride : w;
   const size_t cs = gray ? 0 : image->chroma_stride;
@@ -928,7 +974,8 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
   int rc = current_state(&st);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  std::lock_guard<std::mutex> lk(g_host_mu);
+  CodecLease lease(st);
+  if ((st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
 
   jpeg::DecLayout l;
   const size_t ws_bytes = jpeg::dec_workspace_bytes(info, &l);
@@ -1051,7 +1098,7 @@ int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bo
   return UHDR_HIP_NO_ERROR;
 }
 
-// grow-only device buffers of the JPEG/R decode entry points (guarded by g_jpegr_mu)
+// grow-only device buffers of the JPEG/R decode entry points (the caller's leased context)
 int pool_reserve(DeviceState* st, size_t idx, size_t bytes) {
   if (st->pool.size() <= idx) { st->pool.resize(idx + 1, nullptr); st->pool_bytes.resize(idx + 1, 0); }
   if (bytes == 0) bytes = 256;
@@ -1082,7 +1129,8 @@ int uhdr_hip_jpeg_decode_rgba(const void* jpeg, size_t jpeg_size, void* out, siz
   DeviceState* st = nullptr;
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  CodecLease lease(st);
+  if ((st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
   const size_t ybytes = w * h + 2 * (w * h / 4);
   if ((rc = stage_reserve(st, 8, ybytes + 64)) != 0) return rc;
@@ -1144,7 +1192,8 @@ int uhdr_hip_jpegr_decode_batch(int n, const void* const* jpegr, const size_t* j
   int rc;
   if ((rc = current_state(&st)) != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  CodecLease lease(st);
+  if ((st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   const bool host = mem_space != UHDR_HIP_MEM_DEVICE;
   // per file: two decoder workspaces, two sets of planes, (host callers) the rendition before it goes down
   std::vector<const jpeg::DecInfo*> infos;
@@ -1386,7 +1435,7 @@ int jpeg_enqueue_device(const EncodeCtx& c, const uhdr_hip_image_t& img, int q, 
   jpeg::Layout l;
   const size_t ws_bytes = jpeg::workspace_bytes(j.nblk, &l);
   int rc;
-  if ((rc = stage_reserve(c.st, ws_slot, ws_bytes)) != 0) return rc;   // slots 12 / 13: only ever touched under g_jpegr_mu, which the caller holds
+  if ((rc = stage_reserve(c.st, ws_slot, ws_bytes)) != 0) return rc;   // slots 12 / 13 of the caller's leased context
   uint8_t* ws = static_cast<uint8_t*>(c.st->stage[ws_slot]);
   memcpy(dst.data(), header.data(), header.size());   // host memory: no copy to enqueue
   *total = 0;
@@ -1416,7 +1465,7 @@ int gainmap_to_jpeg(const EncodeCtx& c, const uhdr_hip_image_t& map, HostBytes& 
   jpeg.resize(map.width * map.height + 65536);
   if (!c.host()) {   // enqueued; *n == kPendingSize until resolve_gainmap_jpeg() (or finish_from_planes) has synchronised
     // On a stream of its own behind the kernel that wrote the map: nothing the caller's stream does next (the SDR image's BT.601
-    // re-encode and compression) depends on it, and its ~12 small launches fit next to those (g_jpegr_mu held: one call at a time).
+    // re-encode and compression) depends on it, and its ~12 small launches fit next to those (the context is this call's own).
     if (c.st->aux == nullptr) {
       HIP_TRY(hipStreamCreateWithFlags(&c.st->aux, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&c.st->map_ready, hipEventDisableTiming));
@@ -1531,7 +1580,8 @@ int uhdr_hip_jpegr_encode_api0(const uhdr_hip_image_t* p010_in, int hdr_tf, int 
   default_p010(&p010);
   EncodeCtx c{nullptr, stream, mem_space};
   if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
-  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  CodecLease lease(c.st);
+  if ((c.st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
 
   // :208-223: the tone-mapped SDR image, luma stride rounded up to the encoder's 16-column batch, zero-initialised
   const size_t w = p010.width, h = p010.height, ls = (w + 15) / 16 * 16, total = ls * h * 3 / 2;
@@ -1571,7 +1621,8 @@ int uhdr_hip_jpegr_encode_api1(const uhdr_hip_image_t* p010_in, const uhdr_hip_i
   default_yuv(&yuv);
   EncodeCtx c{nullptr, stream, mem_space};
   if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
-  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  CodecLease lease(c.st);
+  if ((c.st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   const size_t w = yuv.width, h = yuv.height;
 
   uhdr_hip_metadata_t md;
@@ -1646,7 +1697,8 @@ int uhdr_hip_jpegr_encode_api2(const uhdr_hip_image_t* p010_in, const uhdr_hip_i
   static thread_local HostBytes gm_jpeg;
   size_t gm_n = 0;
   {
-    std::lock_guard<std::mutex> lk(g_jpegr_mu);
+    CodecLease lease(c.st);
+    if ((c.st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
     if ((rc = make_gainmap_jpeg(c, yuv, p010, hdr_tf, 0, &md, gm_jpeg, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;   // :416-434
     if ((rc = resolve_gainmap_jpeg(c, &gm_n)) != UHDR_HIP_NO_ERROR) return rc;
   }
@@ -1675,7 +1727,8 @@ int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_in, const void* sdr_
   static thread_local HostBytes gm_jpeg;
   size_t gm_n = 0;
   {
-    std::lock_guard<std::mutex> lk(g_jpegr_mu);
+    CodecLease lease(c.st);
+    if ((c.st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
     std::vector<uint8_t> host_yuv;
     void* planes;
     if (c.host()) { host_yuv.resize(ybytes); planes = host_yuv.data(); }
@@ -1712,7 +1765,8 @@ int uhdr_hip_jpegr_encode_apix(const uhdr_hip_image_t* yuv_in, const uhdr_hip_im
   EncodeCtx c{nullptr, stream, mem_space};
   int rc;
   if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
-  std::lock_guard<std::mutex> lk(g_jpegr_mu);
+  CodecLease lease(c.st);
+  if ((c.st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   static thread_local HostBytes gm_jpeg;
   std::vector<uint8_t> icc;
   size_t gm_n = 0;
@@ -1796,7 +1850,8 @@ int uhdr_hip_gain_lut(const uhdr_hip_metadata_t* metadata, int with_display_boos
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   float factor = 1.0f;  // gainmapmath.h:152-159 (no display boost) | :161-169
   if (with_display_boost) factor = display_boost > 0 ? display_boost / metadata->maxContentBoost : 1.0f;
-  std::lock_guard<std::mutex> lk(g_host_mu);
+  CodecLease lease(st);
+  if ((st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   if ((rc = stage_reserve(st, 6, sizeof(float) * kGainLutN)) != 0) return rc;
   float* d = static_cast<float*>(st->stage[6]);
   HIP_TRY(launch_build_gain_lut(d, std::log2((double)metadata->minContentBoost), std::log2((double)metadata->maxContentBoost),
@@ -2288,7 +2343,8 @@ int fx_run(int kind, const uhdr_hip_image_t* in, int a, int b, int c, int d, uhd
     return UHDR_HIP_NO_ERROR;
   }
   // host memory: stage exactly the bytes the reference touches
-  std::lock_guard<std::mutex> lk(g_host_mu);
+  CodecLease lease(st);
+  if ((st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
   const bool mono = in->pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
   const size_t iw = in->width, ih = in->height;
   const size_t ls = in->luma_stride != 0 ? in->luma_stride : iw;
@@ -2362,7 +2418,8 @@ int uhdr_hip_add_effects(const uhdr_hip_image_t* in, const uhdr_hip_effect_t* ef
   int rc = current_state(&st);
   if (rc != UHDR_HIP_NO_ERROR) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  std::lock_guard<std::mutex> lk(g_host_mu);   // temporaries are shared
+  CodecLease lease(st);   // the temporaries: this call's own
+  if ((st = lease.get()) == nullptr) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
 
   auto packed = [mono](size_t w, size_t h) { return mono ? w * h : w * h * 3 / 2; };
   size_t size = packed(in->width, in->height);

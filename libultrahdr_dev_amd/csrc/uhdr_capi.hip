@@ -463,9 +463,7 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
   c.ex_ws = nullptr;
   c.ex_cap = 0;
   c.cells_per_thread = 8;
-  c.walk_blocks = 0;
   c.step_x = c.step_y = 0;
-  c.edge_rows = 4;
   return c;
 }
 AppImage app_image(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map, void* dst) {

@@ -103,8 +103,6 @@ struct AppFast {
 struct AppConsts {
   uint32_t width, height, map_w, map_h, scale;
   uint32_t cells_per_thread;      // k_apply_s4: map cells a thread walks (set by launch_apply from the size of the launch)
-  uint32_t walk_blocks;           // k_apply_s4: blocks of grid.y that walk; the blocks behind them take the last column and row
-  uint32_t edge_rows;             // k_apply_s4: pixel rows of an edge cell per thread of an edge block (1, 2 or 4)
   uint32_t step_x, step_y;        // k_apply_s4: a block's 512 cells as (rows, columns) of the map: 512 = step_y * map_w + step_x
   float display_boost, inv_display_boost, max_boost, inv_max_boost;
   double log2_min_d, log2_max_d;  // log2((double)minContentBoost), log2((double)maxContentBoost)

@@ -1156,7 +1156,7 @@ constexpr uint32_t kXchPerWave = 136;  // ... of 2176 bytes
 template <int FMT, bool MASK>
 __device__ __forceinline__ void apply_cell_piped1(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
                                                   const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
-                                                  float m1, float m2, float m3, float m4, const char* lut, uint4* xch, uint32_t dup_lane) {
+                                                  float m1, float m2, float m3, float m4, const char* lut, uint4* xch) {
   ChromaRow cr = chroma_row(uu[0], vv[0]);
   const float a255 = c.fast.A255;
   // The four per-cell scalars of the exponent travel as two register PAIRS whose halves v_pk_fma_f32 broadcasts through op_sel: a
@@ -1225,9 +1225,8 @@ __device__ __forceinline__ void apply_cell_piped1(const AppConsts& c, const AppI
             const uint4 s0 = xch[from], s1 = xch[from + 32u];
             __builtin_amdgcn_wave_barrier();
             uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + (uint32_t)__builtin_amdgcn_readfirstlane((int)pix0));
-            // (lane dup_lane, if any, holds a copy of its left neighbour's cell -- see apply_walk_cell -- and its pieces go there)
-            st_stream(o + lane - ((lane >> 1) == dup_lane ? 2u : 0u), s0);
-            st_stream(o + 64u + lane - (32u + (lane >> 1) == dup_lane ? 2u : 0u), s1);
+            st_stream(o + lane, s0);
+            st_stream(o + 64u + lane, s1);
           } else {
             uint4* o = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
             o[0] = make_uint4(a.x, a.y, bb.x, bb.y);
@@ -1269,21 +1268,21 @@ __device__ __forceinline__ void apply_load_cell(const AppConsts& c, const AppIma
   o.mb[0] = im.map[m0 + cx]; o.mb[1] = im.map[m1 + cx]; o.mb[2] = im.map[m0 + xu]; o.mb[3] = im.map[m1 + xu];
 }
 
-// Pixel rows [r0, r0 + nrows) of a cell with per-lane weights (the last column / row of the map: the NR / NB / C tables of
-// gainmapmath.h:184-228): the arithmetic of the walk's cells, row by row in a rolled loop, a row's two pixel pairs side by side.
-// Some 1500 cells of a 4K image take this path.  It is short and needs few registers -- a second copy of the pipelined cell with
-// per-lane weights, inlined next to the first, made the allocator spill in the loop they share -- and nothing in it is pipelined:
-// it runs in the edge blocks of a large launch, and in a small one in the waves that touch the last column / row.
+// A cell with per-lane weights (the last column / row of the map: the NR / NB / C tables of gainmapmath.h:184-228): the arithmetic
+// of the walk's cells, row by row in a rolled loop, a row's two pixel pairs side by side.  Some 1500 cells of a 4K frame take this
+// path, in the waves of the walk that touch the last column / row.  It is short and needs few registers -- a second copy of the
+// pipelined cell with per-lane weights, inlined next to the first, made the allocator spill in the loop they share -- and nothing
+// in it is pipelined.
 template <int FMT, bool MASK>
 __device__ __forceinline__ void apply_cell_edge(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy,
                                                 const uint32_t (&yrow)[4], const uint32_t (&uu)[2], const uint32_t (&vv)[2],
                                                 float m1, float m2, float m3, float m4, const float* wt /* the lane's table, in LDS */,
-                                                uint32_t r0, uint32_t nrows, uint32_t slot8, const char* lut) {
+                                                uint32_t slot8, const char* lut) {
   typedef ApplyTab<FMT, MASK> T;
   const float a255 = c.fast.A255;
   const float base = __builtin_fmaf(m1, a255, c.fast.B), d2 = m2 - m1, d3 = m3 - m1, d4 = m4 - m1;
 #pragma unroll 1
-  for (uint32_t oy = r0; oy < r0 + nrows; ++oy) {   // (uniform: the selects below are scalar)
+  for (uint32_t oy = 0; oy < 4u; ++oy) {   // (uniform: the selects below are scalar)
     const uint32_t yw = oy == 0u ? yrow[0] : oy == 1u ? yrow[1] : oy == 2u ? yrow[2] : yrow[3];
     const ChromaRow cr = chroma_row(oy < 2u ? uu[0] : uu[1], oy < 2u ? vv[0] : vv[1]);
     const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;  // < 2^27 pixels per image
@@ -1362,8 +1361,8 @@ __device__ __forceinline__ void apply_cell_edge(const AppConsts& c, const AppIma
 
 // The same bytes as the walk of k_apply_s4 keeps them across a cell (the next cell's are in flight while the current one is
 // computed, so every dword counts against the 128 registers of four waves per SIMD): the two taps of a map row arrive as ONE
-// 16-bit load, mrow[j] = the bytes (cx, cx + 1) of map row cy + j.  The walk only computes cells that have a right and a lower
-// neighbour.  The loads are unaligned half the time; global memory takes that.
+// 16-bit load, mrow[j] = the bytes (mx, mx + 1) of map row cy (j = 0) / cy1 (j = 1).  The loads are unaligned half the time; global
+// memory takes that.  Needs map_w >= 2 (launch_apply_t).
 struct ApplyCellPk { uint32_t yrow[4], uu[2], vv[2], mrow[2]; };
 struct __attribute__((packed)) U16Any { uint16_t v; };
 // (mx < map_w - 1: the column of the byte pairs; cy1: the row of the lower taps)
@@ -1387,85 +1386,62 @@ __device__ __forceinline__ void apply_load_cell_pk(const AppConsts& c, const App
 // together and the blocks in flight spread over the whole batch's memory (same-box A/B, round 2: 0.608 -> 0.576 ms per 64 frames).
 //
 // The walk is ONE straight line of code per cell: no memory instruction sits behind a branch (the request for the next cell is
-// issued even when there is none -- it repeats the current cell's --, no lane is masked, and where a wave chooses between two
+// issued even when there is none -- it repeats the current cell's --, no lane is masked, and where a wave chooses between the two
 // forms of the cell both issue the same memory instructions).  That is what lets s_waitcnt count: behind a branch the compiler
 // has to assume an instruction was not issued, and a wait for the inputs of the next cell then also waits for every store issued
 // after them -- round 2's loop drained its stores at every cell, reloaded six spilled registers, and waited for loads of the NEXT
 // cell through registers the allocator had placed under undefined halves of operand pairs (apply_cell_piped).  Same box, 64 x 4K:
 // 0.579 -> 0.536 ms.
 //
-// The cells of the last column and row have per-lane weights (the NR / NB / C tables of gainmapmath.h:184-228).  Two layouts:
-//   * EDGE_BLOCKS (large launches): grid.y = edge blocks, then c.walk_blocks walk blocks.  The walk covers all rows of the map but
-//     the last, every lane on sampleMap's standard weights held in SGPRs; a lane that lands on the last column computes its left
-//     neighbour once more and stores the same bytes a second time.  The map_w + map_h - 1 edge cells go to the edge blocks, a
-//     thread per cell (apply_cell_edge);
-//   * otherwise (one round of blocks, all resident at once: a few latency-bound edge blocks would be what the launch waits for --
-//     one 4K frame: 13 -> 17 us): the walk covers every cell, and a wave that touches the last column / row runs apply_cell_edge
-//     for its cell instead of the pipelined form.
+// The cells of the last column and row have per-lane weights (the NR / NB / C tables of gainmapmath.h:184-228): a wave that
+// touches one (one in fifteen on a 4K frame) runs apply_cell_edge for its 64 cells instead of the pipelined form.  Measured and
+// dropped: handing those cells to blocks of their own behind a walk on SGPR weights only (a lane on the last column recomputing
+// its left neighbour): 2 % slower on 64 x 4K (0.604 against 0.594 ms, same box), and in a one-round launch the handful of
+// latency-bound edge blocks is what the launch waits for (one 4K frame: 13 -> 17-23 us).
 constexpr uint32_t kApplyBlock = 512;
-constexpr uint32_t kApplyMaxCellsPerThread = 64;   // (64 x 4K, same box: 32 cells per thread 0.599 ms, 64: 0.592, 128: 0.607; 48 / 80 / 96: 0.63-0.65)
-__host__ __device__ inline uint32_t apply_edge_blocks(uint32_t map_w, uint32_t map_h, uint32_t edge_rows) {
-  return ((map_w + map_h - 1u) * (4u / edge_rows) + kApplyBlock - 1u) / kApplyBlock;
-}
+constexpr uint32_t kApplyMaxCellsPerThread = 32;   // (64 x 4K, same box: 32 cells per thread 0.594 ms, 64: 0.598, 128: 0.607; 48 / 80 / 96: 0.63-0.65)
 
 // One cell of the walk: requests the inputs of the thread's next cell into `nxt` (a block's waves start together, and without this
 // they would also all wait for HBM together and all compute together), computes the cell whose inputs `cur` holds, and steps
 // (cx, cy) on.  The kernel calls it with its two register sets swapped from cell to cell, so nothing is copied between them.
 // Returns whether there is a next cell; when there is none the request repeats the current cell's (issued all the same: see above).
-// EDGE_BLOCKS false (small launches): the walk covers every cell, and a wave that touches the last column / row runs the variant of
-// the cell with per-lane weights.
-template <int FMT, bool MASK, bool EDGE_BLOCKS>
+template <int FMT, bool MASK>
 __device__ __forceinline__ bool apply_walk_cell(const AppConsts& c, const AppImage& im, uint32_t& cx, uint32_t& cy, uint32_t& left,
                                                 const ApplyCellPk& cur, ApplyCellPk& nxt, uint32_t slot8, const char* lut,
                                                 const float* s_idw, uint4* s_xch) {
   typedef ApplyTab<FMT, MASK> T;
-  const uint32_t rows = EDGE_BLOCKS ? c.map_h - 1u : c.map_h;   // (with edge blocks the walk ends in front of the last row)
   // the block's next stretch of cells lies kApplyBlock = step_y * map_w + step_x cells further on
   uint32_t ncx = cx + c.step_x, ncy = cy + c.step_y;
   if (ncx >= c.map_w) { ncx -= c.map_w; ++ncy; }
   --left;
-  const bool more = left != 0u && ncy < rows;
+  const bool more = left != 0u && ncy < c.map_h;
   if (!more) { ncx = cx; ncy = cy; }
+  // In the last column sampleMap's right tap IS the left one (gainmapmath.cpp:690-703, xu == xl): the two bytes are loaded one
+  // column to the left, the right tap is byte 1 either way, the left tap byte 0 -- or byte 1 in the last column.
+  apply_load_cell_pk(c, im, ncx, ncy, ncx - (ncx + 1u == c.map_w ? 1u : 0u), min(ncy + 1u, c.map_h - 1u), nxt);
   const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
-  uint32_t ecx = cx;
-  float e1, e2, e3, e4;
-  if (EDGE_BLOCKS) {
-    // (the cell computed for a lane on the last column: its left neighbour)
-    const uint32_t lcx = ncx - (ncx + 1u == c.map_w ? 1u : 0u);
-    apply_load_cell_pk(c, im, lcx, ncy, lcx, ncy + 1u, nxt);
-    ecx = cx - (edge_x ? 1u : 0u);
-    e1 = cvt_byte<0>(cur.mrow[0]); e2 = cvt_byte<0>(cur.mrow[1]); e3 = cvt_byte<1>(cur.mrow[0]); e4 = cvt_byte<1>(cur.mrow[1]);
-  } else {
-    // In the last column sampleMap's right tap IS the left one (gainmapmath.cpp:690-703, xu == xl): the two bytes are loaded one
-    // column to the left, the right tap is byte 1 either way, the left tap byte 0 -- or byte 1 in the last column.
-    apply_load_cell_pk(c, im, ncx, ncy, ncx - (ncx + 1u == c.map_w ? 1u : 0u), min(ncy + 1u, c.map_h - 1u), nxt);
-    e3 = cvt_byte<1>(cur.mrow[0]); e4 = cvt_byte<1>(cur.mrow[1]);
-    e1 = edge_x ? e3 : cvt_byte<0>(cur.mrow[0]); e2 = edge_x ? e4 : cvt_byte<0>(cur.mrow[1]);
-  }
-  // all waves of a large launch, and of a small one all but those touching the last column / row, take the SGPR-weight variant
-  const bool interior = EDGE_BLOCKS || __builtin_amdgcn_ballot_w64(edge_x || edge_y) == 0ull;
+  const float e3 = cvt_byte<1>(cur.mrow[0]), e4 = cvt_byte<1>(cur.mrow[1]);
+  const float e1 = edge_x ? e3 : cvt_byte<0>(cur.mrow[0]), e2 = edge_x ? e4 : cvt_byte<0>(cur.mrow[1]);
+  // all waves but those touching the last column / row take the pipelined form on SGPR weights
+  const bool interior = __builtin_amdgcn_ballot_w64(edge_x || edge_y) == 0ull;
   const float* wt = s_idw + (edge_x ? (edge_y ? 192 : 64) : (edge_y ? 128 : 0));   // tables: 0 std, 1 no-right, 2 no-bottom, 3 corner
   if (T::kOetf) {
-    if (interior) apply_cell_piped<FMT>(c, im.dst, ecx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, slot8, lut);
-    else apply_cell_edge<FMT, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, wt, 0u, 4u, slot8, lut);
+    if (interior) apply_cell_piped<FMT>(c, im.dst, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, slot8, lut);
+    else apply_cell_edge<FMT, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, wt, slot8, lut);
   } else {
     // F16: a full wave on one row of cells stores through the exchange area (apply_cell_piped1)
     uint4* xch = nullptr;
-    uint32_t dup_lane = 64u;
     if (FMT == 1 && __builtin_amdgcn_ballot_w64(true) == ~0ull &&
-        __builtin_amdgcn_ballot_w64(cy != (uint32_t)__builtin_amdgcn_readfirstlane((int)cy)) == 0ull) {
+        __builtin_amdgcn_ballot_w64(cy != (uint32_t)__builtin_amdgcn_readfirstlane((int)cy)) == 0ull)
       xch = s_xch + (threadIdx.x >> 6) * kXchPerWave;
-      const uint64_t dup = __builtin_amdgcn_ballot_w64(ecx != cx);
-      if (dup) dup_lane = (uint32_t)__builtin_ctzll(dup);
-    }
-    if (interior) apply_cell_piped1<FMT, MASK>(c, im, ecx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, lut, xch, dup_lane);
-    else apply_cell_edge<FMT, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, wt, 0u, 4u, slot8, lut);
+    if (interior) apply_cell_piped1<FMT, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, lut, xch);
+    else apply_cell_edge<FMT, MASK>(c, im, cx, cy, cur.yrow, cur.uu, cur.vv, e1, e2, e3, e4, wt, slot8, lut);
   }
   cx = ncx; cy = ncy;
   return more;
 }
 
-template <int FMT, bool MASK, bool EDGE_BLOCKS>
+template <int FMT, bool MASK>
 __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, const AppBatch b) {
   typedef ApplyTab<FMT, MASK> T;
   __shared__ uint4 s_tab[T::kBytes / 16u];
@@ -1473,32 +1449,13 @@ __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, 
   __shared__ float s_idw[4 * 64];   // sampleMap's four weight tables times A / 255: per-lane weights are an LDS read, not a trip to L2 per pixel pair
   const uint32_t img_i = blockIdx.x, span = blockIdx.y;
   const AppImage& im = b.img[img_i];
-  const uint32_t edge_blocks = EDGE_BLOCKS ? gridDim.y - c.walk_blocks : 0u;
-  const bool walk = !EDGE_BLOCKS || span >= edge_blocks;   // (block-uniform; the edge blocks first: they are short and latency-bound)
-  uint32_t cx, cy, er0 = 0u;
-  bool any;
-  if (walk) {
-    const uint32_t idx = (span - edge_blocks) * c.cells_per_thread * kApplyBlock + threadIdx.x;
-    cy = idx / c.map_w;
-    cx = idx - cy * c.map_w;
-    any = cy < (EDGE_BLOCKS ? c.map_h - 1u : c.map_h);
-  } else {
-    // edge cell e: the last column top to bottom (the corner included), then the last row left to right; a thread takes
-    // c.edge_rows (1, 2 or 4) of the cell's four pixel rows
-    const uint32_t task = (span * kApplyBlock + threadIdx.x) * c.edge_rows;
-    const uint32_t e = task >> 2;
-    er0 = task & 3u;
-    any = e < c.map_w + c.map_h - 1u;
-    cx = e < c.map_h ? c.map_w - 1u : e - c.map_h;
-    cy = e < c.map_h ? e : c.map_h - 1u;
-  }
+  const uint32_t idx = span * c.cells_per_thread * kApplyBlock + threadIdx.x;
+  uint32_t cy = idx / c.map_w;
+  uint32_t cx = idx - cy * c.map_w;
+  const bool any = cy < c.map_h;
   // the first cell's pixels are requested before the tables: both trips to memory overlap
   ApplyCellPk ca, cb;
-  if (any && walk) {
-    const uint32_t mx = cx - (cx + 1u == c.map_w ? 1u : 0u);
-    if (EDGE_BLOCKS) apply_load_cell_pk(c, im, mx, cy, mx, cy + 1u, ca);
-    else apply_load_cell_pk(c, im, cx, cy, mx, min(cy + 1u, c.map_h - 1u), ca);
-  }
+  if (any) apply_load_cell_pk(c, im, cx, cy, cx - (cx + 1u == c.map_w ? 1u : 0u), min(cy + 1u, c.map_h - 1u), ca);
   {
     // all loads first, then all stores: one trip through L2's latency per block instead of one per piece
     constexpr uint32_t kN1 = T::kS1Bytes / 16u, kPer1 = (kN1 + kApplyBlock - 1u) / kApplyBlock;
@@ -1507,13 +1464,12 @@ __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, 
     const uint2* src2 = reinterpret_cast<const uint2*>(c.tab + T::kS2Float);
     uint4 t1[kPer1];
     uint2 t2[kPer2 ? kPer2 : 1u];
-    float w = 0.0f;
-    if (!EDGE_BLOCKS || !walk) w = c_idw4[threadIdx.x & 255u] * c.fast.A255;   // (before the rounding mode changes: launch_apply_t's product)
+    const float w = c_idw4[threadIdx.x & 255u] * c.fast.A255;   // (before the rounding mode changes: launch_apply_t's product)
 #pragma unroll
     for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; t1[k] = src1[i < kN1 ? i : kN1 - 1u]; }
 #pragma unroll
     for (uint32_t k = 0; k < kPer2; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; t2[k] = src2[(i < kN2 ? i : 0u) >> 5]; }
-    if ((!EDGE_BLOCKS || !walk) && threadIdx.x < 256u) s_idw[threadIdx.x] = w;
+    if (threadIdx.x < 256u) s_idw[threadIdx.x] = w;
 #pragma unroll
     for (uint32_t k = 0; k < kPer1; ++k) { const uint32_t i = k * kApplyBlock + threadIdx.x; if (i < kN1) s_tab[i] = t1[k]; }
 #pragma unroll
@@ -1529,19 +1485,11 @@ __global__ void __launch_bounds__(kApplyBlock, 4) k_apply_s4(const AppConsts c, 
     // follow are reached by addition.
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3" : "+v"(cx), "+v"(cy));
   }
-  if (!walk) {
-    const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
-    ApplyCellIn ce;
-    apply_load_cell(c, im, cx, cy, ce);
-    apply_cell_edge<FMT, MASK>(c, im, cx, cy, ce.yrow, ce.uu, ce.vv, (float)ce.mb[0], (float)ce.mb[1], (float)ce.mb[2], (float)ce.mb[3],
-                               s_idw + (edge_x ? (edge_y ? 192 : 64) : 128), er0, c.edge_rows, slot8, lut);
-    return;
-  }
   uint32_t left = c.cells_per_thread;
 #pragma unroll 1
   for (;;) {
-    if (!apply_walk_cell<FMT, MASK, EDGE_BLOCKS>(c, im, cx, cy, left, ca, cb, slot8, lut, s_idw, s_xch)) return;
-    if (!apply_walk_cell<FMT, MASK, EDGE_BLOCKS>(c, im, cx, cy, left, cb, ca, slot8, lut, s_idw, s_xch)) return;
+    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, ca, cb, slot8, lut, s_idw, s_xch)) return;
+    if (!apply_walk_cell<FMT, MASK>(c, im, cx, cy, left, cb, ca, slot8, lut, s_idw, s_xch)) return;
   }
 }
 
@@ -2182,28 +2130,19 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     hipLaunchKernelGGL((k_apply_lut<FMT>), dim3((unsigned)((total + per_block - 1u) / per_block), n), dim3(256), 0, s, c, b);
     return hipGetLastError();
   }
-  if (fast_s4 && !exact && c.map_w >= 2u && c.map_h >= 2u) {   // (apply_load_cell_pk reads two columns; the walk of a large launch two rows)
+  if (fast_s4 && !exact && c.map_w >= 2u) {   // (a map one cell wide: the per-pixel kernel; apply_load_cell_pk reads two columns)
     // Cells per thread: a block copies 15-37 KB of tables into LDS before its first pixel, so it should walk many cells -- but a
     // launch also has to fill 256 CUs x 2 resident blocks, or a single 4K image (2025 blocks of 256 cells) would leave three
     // quarters of the chip idle with 8 cells per thread.
-    // The cells of the last column and row have per-lane weights.  A large launch leaves them to edge blocks and keeps its walk
-    // one straight line of code at the register budget (k_apply_s4); in a small launch (one round of blocks, all resident at
-    // once) a handful of latency-bound edge blocks would be the blocks everything waits for (one 4K frame: 13 -> 17 us), so there
-    // the walk covers every cell and its waves on the last column / row run a second variant of the cell.
     AppConsts cc = c;
-    uint32_t total = c.map_w * c.map_h;   // the walk's cells
+    const uint32_t total = c.map_w * c.map_h;
     uint32_t cpt = kApplyMaxCellsPerThread;
     auto blocks = [&](uint32_t k) { return (uint64_t)((total + kApplyBlock * k - 1u) / (kApplyBlock * k)) * (uint64_t)n; };
     while (cpt > 1u && blocks(cpt) < 448u) cpt >>= 1;   // (a single 4K image: 507 blocks of 2 cells per thread, all resident at once)
-    // (edge blocks from two rounds of blocks on: one 8K frame -- 506 blocks of 8 cells per thread -- takes 45 us without, 51 with)
-    const bool edge_blocks = blocks(cpt) > 1024u;
-    if (edge_blocks) total = c.map_w * (c.map_h - 1u);
     cc.cells_per_thread = cpt;
-    cc.walk_blocks = (total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt);
     cc.step_x = kApplyBlock % c.map_w;
     cc.step_y = kApplyBlock / c.map_w;
-    cc.edge_rows = 4u;
-    const dim3 grid(n, cc.walk_blocks + (edge_blocks ? apply_edge_blocks(c.map_w, c.map_h, cc.edge_rows) : 0u));
+    const dim3 grid(n, (unsigned)((total + kApplyBlock * cpt - 1u) / (kApplyBlock * cpt)));
     // Channels can only exceed 1.0 (reach code 1024 and wrap through the reference's & 0x3ff; leave the stage-2 table) when the
     // display boost is capped below the content boost -- and then only if the largest factor the call can produce,
     // max(minBoost, maxBoost)^(display / max) / display, is above 1: a display boost of 2 under a content boost of 4.9 stays
@@ -2221,13 +2160,8 @@ static hipError_t launch_apply_t(const AppConsts& c, const AppBatch& b, int n, i
     // sampleMap's standard weights times A / 255: ONE float product per weight, the same one the kernel forms for the per-lane
     // tables of the last column / row (its prologue, round to nearest) -- a cell gets the same bytes whichever form computes it
     for (int i = 0; i < 4 * 2 * 3 * 2; ++i) (&cc.fast.wD[0][0][0][0])[i] *= cc.fast.A255;
-    if (mask) {
-      if (edge_blocks) hipLaunchKernelGGL((k_apply_s4<FMT, true, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
-      else hipLaunchKernelGGL((k_apply_s4<FMT, true, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
-    } else {
-      if (edge_blocks) hipLaunchKernelGGL((k_apply_s4<FMT, false, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
-      else hipLaunchKernelGGL((k_apply_s4<FMT, false, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
-    }
+    if (mask) hipLaunchKernelGGL((k_apply_s4<FMT, true>), grid, dim3(kApplyBlock), 0, s, cc, b);
+    else hipLaunchKernelGGL((k_apply_s4<FMT, false>), grid, dim3(kApplyBlock), 0, s, cc, b);
   } else {
     const dim3 grid = px_grid(c.width, c.height, n);
     if (exact && c.ex_ws != nullptr) {

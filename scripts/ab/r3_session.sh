@@ -1,7 +1,7 @@
 set -x
-bash scripts/profile_apply_pmc.sh r03 > /dev/null 2>&1
+bash scripts/final_refresh.sh r03 > gpurun_out/final_refresh_r03.log 2>&1
+tail -8 gpurun_out/final_refresh_r03.log
 cat gpurun_out/pmc_apply_progress_r03.log
-VARIANTS="A B X1 X2" STEPS=100 ROUNDS=3 bash scripts/ab/run_ab.sh > gpurun_out/r03_apply_floors.log 2>&1
-tail -5 gpurun_out/r03_apply_floors.log
-python scripts/clock_trace.py 4 > gpurun_out/r03_clock_trace.txt 2>&1
-head -5 gpurun_out/r03_clock_trace.txt
+python scripts/clock_trace.py 3 > gpurun_out/r03_clock_trace.txt 2>&1
+python scripts/kernel_times_of.sh 2>/dev/null; bash scripts/kernel_times_of.sh scripts/time_single.py > gpurun_out/r03_single_kernel_times.txt 2>&1
+tail -5 gpurun_out/r03_single_kernel_times.txt

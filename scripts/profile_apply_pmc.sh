@@ -12,16 +12,14 @@ timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CO
 echo "pass b done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
 timeout -k 10 150 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/c -- python3 $ARGS > $OUT/c.log 2>&1 || echo "pass c: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
 echo "pass c done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
-# L2: requests, hits, misses, what leaves it (round 2's 24 M hits per launch were the traffic of six spilled registers)
-timeout -k 10 150 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/d -- python3 $ARGS > $OUT/d.log 2>&1 || echo "pass d: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
-echo "pass d done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
-# instruction classes that would show scratch traffic (scratch_* count as FLAT)
+# instruction classes that would show scratch traffic (scratch_* count as FLAT: FLAT must equal VMEM_RD + VMEM_WR).  The L2 counters
+# (TCC_HIT_sum / TCC_MISS_sum) come from scripts/profile_bench.sh; a pass with TCC_REQ / TCC_EA0_* crashed rocprofv3 on this image.
 timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_FLAT SQ_INSTS_FLAT_LDS_ONLY SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_VALU --output-format csv -d $OUT/e -- python3 $ARGS > $OUT/e.log 2>&1 || echo "pass e: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
 echo "pass e done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
 python3 - $OUT $R/gpurun_out/pmc_apply_$TAG.txt <<'PY'
 import csv, glob, sys, collections
 out = open(sys.argv[2], "w")
-for d in "abcde":
+for d in "abce":
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (sys.argv[1], d), recursive=True):
         for r in csv.DictReader(open(f)):

@@ -716,10 +716,11 @@ def test_fast_apply_against_exact_apply_on_sixteen_4k_frames(hip, fmt):
 @pytest.mark.parametrize("fmt", [1, 3])
 @pytest.mark.parametrize("dims", [(3844, 2164), (2052, 1028)])
 def test_fast_apply_layouts_agree_on_ragged_frames(hip, fmt, dims):
-    """k_apply_s4 has two layouts for the cells of the last map column / row: edge blocks (launches of more than two rounds of blocks)
-    and the walk's own waves (smaller launches).  The same frames through one large call and through single-image calls must give
-    the same bytes -- map widths that are no multiple of a wave (961, 513 cells), so that waves wrap rows everywhere -- and the
-    large call stays within 1 LSB / half-ULP of the bit-exact mode."""
+    """The same frames through one large call (32 cells per thread, many rounds of blocks) and through single-image calls (2 cells
+    per thread, one round) must give the same bytes -- map widths that are no multiple of a wave (961, 513 cells), so that waves
+    wrap rows everywhere and the waves on the last column / row (the rolled form of the cell, per-lane weights) fall differently --
+    and the large call stays within 1 LSB / half-ULP of the bit-exact mode.  (Round 3 also tried a second layout, edge cells in
+    blocks of their own; this test is what found that the two forms of the cell did not multiply their weights alike.)"""
     import torch
     from libultrahdr_dev_amd import synth
     from tests.gpu_util import stream_ptr
@@ -742,7 +743,7 @@ def test_fast_apply_layouts_agree_on_ragged_frames(hip, fmt, dims):
         assert lib.uhdr_hip_apply_gainmap(C.byref(yi[i]), C.byref(mi[i]), C.byref(md), fmt, FLT_MAX, C.byref(oi), hip.APPLY_FAST, hip.MEM_DEVICE, stream_ptr()) == 0
         assert lib.uhdr_hip_apply_gainmap(C.byref(yi[i]), C.byref(mi[i]), C.byref(md), fmt, FLT_MAX, C.byref(ei), hip.APPLY_EXACT, hip.MEM_DEVICE, stream_ptr()) == 0
         torch.cuda.synchronize()
-        assert torch.equal(one, big[i]), "frame %d: the two layouts of k_apply_s4 disagree in %d bytes" % (i, int((one != big[i]).sum()))
+        assert torch.equal(one, big[i]), "frame %d: batch and single-image launches disagree in %d bytes" % (i, int((one != big[i]).sum()))
         if fmt == 3:
             x, y = big[i].view(torch.int32), ex.view(torch.int32)
             for sh in (0, 10, 20):

@@ -30,12 +30,9 @@ def test_no_kernel_uses_scratch(table):
 def test_streaming_kernels_present_and_at_their_occupancy(table):
     apply_fast = [k for k in table if "k_apply_s4<" in k]
     gen = [k for k in table if "k_generate<" in k]
-    assert len(apply_fast) == 16 and len(gen) >= 40, (len(apply_fast), len(gen))
+    assert len(apply_fast) == 8 and len(gen) >= 40, (len(apply_fast), len(gen))
     for k in apply_fast:   # two blocks of 512 threads per CU = four waves per SIMD: at most 128 registers
         assert table[k]["vgpr"] <= 128 and table[k]["occupancy"] >= 4, (k, table[k])
-    for k in apply_fast:   # the table walk of a large launch (HLG / PQ out): nothing spilled anywhere, not even scalars
-        if "<2, false, true>" in k or "<3, false, true>" in k:
-            assert table[k]["sgpr_spill"] == 0, (k, table[k])
     # the headline pair: 64 x 4K HLG, filtered generate with the exact path deferred (4 spans per block) and the HLG table walk
     g = [k for k in gen if "<1, true, false, true, 4, true, 256>" in k]
     assert len(g) == 1 and table[g[0]]["occupancy"] >= 5, (g, [table[x] for x in g])

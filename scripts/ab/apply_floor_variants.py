@@ -35,7 +35,7 @@ def main():
     if (interior) apply_cell_piped<FMT>(''', '''#if UHDR_XP == 1
   {
     const uint32_t x = cur.yrow[0] ^ cur.yrow[1] ^ cur.yrow[2] ^ cur.yrow[3] ^ cur.uu[0] ^ cur.uu[1] ^ cur.vv[0] ^ cur.vv[1] ^ __float_as_uint(e1 + e2 + e3 + e4);
-    for (int oy = 0; oy < 4; ++oy) st_stream(reinterpret_cast<uint4*>(static_cast<char*>(im.dst) + ((4u * cy + oy) * c.width + 4u * ecx) * 4u), make_uint4(x, x + oy, x ^ 1u, x ^ 2u));
+    for (int oy = 0; oy < 4; ++oy) st_stream(reinterpret_cast<uint4*>(static_cast<char*>(im.dst) + ((4u * cy + oy) * c.width + 4u * cx) * 4u), make_uint4(x, x + oy, x ^ 1u, x ^ 2u));
     cx = ncx; cy = ncy;
     return more;
   }
@@ -47,10 +47,10 @@ def main():
         if ((px[0] ^ px[1] ^ px[2] ^ px[3]) == 0x12345678u)
 #endif
         st_stream(reinterpret_cast<uint4*>(static_cast<char*>(dst) + off), make_uint4(px[0], px[1], px[2], px[3]));''')
-    s = sub(s, '''    apply_load_cell_pk(c, im, lcx, ncy, lcx, ncy + 1u, nxt);''', '''#if UHDR_XP == 3
-    apply_load_cell_pk(c, im, threadIdx.x & 63u, 0u, threadIdx.x & 63u, 1u, nxt);
+    s = sub(s, '''  apply_load_cell_pk(c, im, ncx, ncy, ncx - (ncx + 1u == c.map_w ? 1u : 0u), min(ncy + 1u, c.map_h - 1u), nxt);''', '''#if UHDR_XP == 3
+  apply_load_cell_pk(c, im, threadIdx.x & 63u, 0u, threadIdx.x & 63u, 1u, nxt);
 #else
-    apply_load_cell_pk(c, im, lcx, ncy, lcx, ncy + 1u, nxt);
+  apply_load_cell_pk(c, im, ncx, ncy, ncx - (ncx + 1u == c.map_w ? 1u : 0u), min(ncy + 1u, c.map_h - 1u), nxt);
 #endif''')
     open(p, "w").write(s)
     procs = []

@@ -933,6 +933,13 @@ int decode_device_batch(int n, const DecInfo* const info[], const DecLayout l[],
     JD_TRY(hipMemcpyAsync(flags.data(), dflags, flags.size() * 4, hipMemcpyDeviceToHost, s));
     JD_TRY(hipStreamSynchronize(s));
     JD_LAP("round batch synced");
+#ifdef UHDR_JD_TIMING
+    for (int k = 0; k < n; ++k) {   // which launches of rounds still changed an end state
+      uint32_t last = 0;
+      for (uint32_t r = 1; r < round; ++r) if (flags[(size_t)k * kFlagWords + 64u + (r & 63u)] != 0u) last = r;
+      fprintf(stderr, "[jd]   image %d: %u subsequences, last launch of rounds that changed a state: %u of %u\n", k, jobs[k].j.nsub, last, round - 1u);
+    }
+#endif
     bool any = false;
     for (int k = 0; k < n; ++k) any = any || flags[(size_t)k * kFlagWords + 64u + ((round - 1u) & 63u)] != 0u;
     if (!any) break;

@@ -139,6 +139,38 @@ def load():
     return _lib
 
 
+# include/uhdr_hip_comm.h -- libuhdr_hip_comm.so: the path's one exchange between GPUs (RCCL), apart from the pixel library
+COMM_LIB_PATH = os.path.join(_HERE, "libuhdr_hip_comm.so")
+COMM_ID_BYTES = 128
+COMM_SIGNATURES = {
+    "uhdr_hip_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "uhdr_hip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "uhdr_hip_comm_world": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "uhdr_hip_comm_allreduce_minmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "uhdr_hip_comm_destroy": (C.c_int, [C.c_void_p]),
+}
+_comm_lib = None
+
+
+def load_comm():
+    """dlopen libuhdr_hip_comm.so (links librccl.so.1: in a PyTorch process the loader hands it the copy torch has mapped)."""
+    global _comm_lib
+    if _comm_lib is None:
+        if not os.path.exists(COMM_LIB_PATH):
+            raise ImportError("libuhdr_hip_comm.so is missing: python -m libultrahdr_dev_amd.build")
+        try:
+            import torch  # noqa: F401  (same reason as in load(): one HIP runtime, one RCCL per process)
+        except ImportError:
+            pass
+        lib = C.CDLL(COMM_LIB_PATH)
+        for name, (res, args) in COMM_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _comm_lib = lib
+    return _comm_lib
+
+
 class UhdrHipError(RuntimeError):
     pass
 

@@ -15,9 +15,12 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libuhdr_hip.so")
 SHIM_LIB = os.path.join(HERE, "libultrahdr_shim.so")
+COMM_LIB = os.path.join(HERE, "libuhdr_hip_comm.so")   # include/uhdr_hip_comm.h: the RCCL side, apart from the pixel path
 
 SOURCES = ["uhdr_kernels.hip", "uhdr_capi.hip", "uhdr_jpeg.hip", "uhdr_jpeg_dec.hip", "uhdr_jpeg_hdr.cpp", "uhdr_jpeg_prog.cpp", "uhdr_jpegr.cpp"]
 DEPS = SOURCES + ["uhdr_kernels.h", "uhdr_device_math.h", "uhdr_jpeg.h", "uhdr_jpegr.h", os.path.join(ROOT, "include", "uhdr_hip.h")]
+COMM_SOURCES = ["uhdr_comm.hip"]
+COMM_DEPS = COMM_SOURCES + [os.path.join(ROOT, "include", "uhdr_hip_comm.h")]
 SHIM_SOURCES = ["ultrahdr_shim.cpp"]
 SHIM_DEPS = SHIM_SOURCES + [os.path.join(ROOT, "include", "uhdr_hip.h"),
                             os.path.join(ROOT, "include", "ultrahdr_hip", "ultrahdr_hip.h")]
@@ -39,9 +42,15 @@ def _stale(target, deps, base):
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip -> libuhdr_hip.so and the C++ shim -> libultrahdr_shim.so."""
+    """Compile csrc/*.hip -> libuhdr_hip.so, csrc/uhdr_comm.hip -> libuhdr_hip_comm.so and the C++ shim -> libultrahdr_shim.so."""
     if force or _stale(LIB, DEPS, CSRC):
         cmd = [HIPCC] + FLAGS + ["-shared", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if force or _stale(COMM_LIB, COMM_DEPS, CSRC):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib")
+        cmd = [HIPCC] + FLAGS + ["-shared", "-o", COMM_LIB] + [os.path.join(CSRC, s) for s in COMM_SOURCES] + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

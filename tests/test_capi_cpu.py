@@ -38,6 +38,40 @@ def test_library_exports_every_declared_symbol(api):
     assert exported == set(names), exported ^ set(names)
 
 
+def test_comm_library_exports_every_declared_symbol(api):
+    """include/uhdr_hip_comm.h (the RCCL side, a library of its own): every declared entry point exported and bound, nothing else;
+    argument validation needs no GPU"""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "uhdr_hip_comm.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(uhdr_hip_comm_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(api.COMM_SIGNATURES) and len(names) == 5
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.COMM_LIB_PATH]).decode()
+    assert set(re.findall(r" T (uhdr_hip_\w+)", out)) == set(names)
+    needed = subprocess.check_output(["readelf", "-d", api.COMM_LIB_PATH]).decode()
+    assert "librccl.so" in needed
+    assert "librccl" not in subprocess.check_output(["readelf", "-d", api.LIB_PATH]).decode()   # the pixel path does not depend on RCCL
+    lib = api.load_comm()
+    comm = C.c_void_p()
+    ident = (C.c_char * api.COMM_ID_BYTES)()
+    assert lib.uhdr_hip_comm_get_unique_id(None) == api.ERROR_BAD_PTR
+    assert lib.uhdr_hip_comm_init(ident, 0, 0, 0, C.byref(comm)) == api.ERROR_BAD_PTR      # world < 1
+    assert lib.uhdr_hip_comm_init(ident, 2, 2, 0, C.byref(comm)) == api.ERROR_BAD_PTR      # rank outside the world
+    assert lib.uhdr_hip_comm_init(None, 1, 0, 0, C.byref(comm)) == api.ERROR_BAD_PTR and not comm.value
+    assert lib.uhdr_hip_comm_allreduce_minmax(None, None, 0, None, None) == api.ERROR_BAD_PTR
+    assert lib.uhdr_hip_comm_destroy(None) == api.ERROR_BAD_PTR
+
+
+def test_cpp_multi_gpu_example_compiles_against_the_headers(tmp_path):
+    """examples/multi_gpu_batch.cpp (the sharded step from a C++ host, one process per GPU) builds against include/*.h and links
+    the two libraries; it runs only where there is a GPU (tests/test_gpu_comm.py)"""
+    exe = str(tmp_path / "multi_gpu_batch")
+    libdir = os.path.join(ROOT, "libultrahdr_dev_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                           "-o", exe, os.path.join(ROOT, "examples", "multi_gpu_batch.cpp"), "-L" + libdir, "-luhdr_hip", "-luhdr_hip_comm",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, "--gpus", "0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "bad arguments" in r.stderr
+
+
 def test_shim_exports_reference_member_names():
     shim = os.path.join(ROOT, "libultrahdr_dev_amd", "libultrahdr_shim.so")
     assert os.path.exists(shim), "build() did not produce the C++ shim"

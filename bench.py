@@ -577,16 +577,24 @@ def main():
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     red = torch.zeros(2, dtype=torch.float32, device="cuda")
 
+    side = torch.cuda.Stream() if world > 1 else None   # the exchange's own stream
+
     def step(ev_gen=None, ev_app=None, exchange=True):
         batch.generate(stream, ev_gen)
         work = None
         if world > 1 and exchange:
-            # the path's only exchange: batch-wide content min / max boost (8 bytes, latency-bound); it is
-            # enqueued asynchronously so that it overlaps the apply kernels, and joined at the end of the step
-            _, work = sharding.reduce_content_minmax(batch.minmax, dist, red, async_op=True)
+            # the path's only exchange: batch-wide content min / max boost (8 bytes, latency-bound).  Its small kernels (the fold of
+            # this rank's pairs) and the all-reduce go onto a stream of their own behind generate, so that apply neither waits for
+            # them nor has them in its way; the step ends when both streams have.
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _, work = sharding.reduce_content_minmax(batch.minmax, dist, red, async_op=True)
         batch.apply(stream, fmt, ev_app)
         if world > 1 and exchange:
-            sharding.finish_content_minmax(red, work)
+            if work is not None:
+                work.wait()                              # (RCCL: the current stream waits for the collective; gloo: the host does)
+            torch.cuda.current_stream().wait_stream(side)
 
     def timed_steps(evs_g=None, evs_a=None):
         """W untimed steps, then exactly K timed ones between barriers + synchronisations; -> seconds (max over ranks)"""

@@ -284,6 +284,7 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   c.stat_stride = 2;
   c.stat_ws = nullptr;
   c.stat_out = nullptr;
+  c.stat_spread = 0u;
   c.lut = nullptr;
   c.bias4096 = 4096.0f;
   // f32 pre-filter (gen_pair; error budget in DESIGN.md section 5): the fast gain is within kRel of the exact one
@@ -1927,10 +1928,13 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
     bool filter = generate_mode == UHDR_HIP_GENERATE_EXACT && c.flt_delta < 0.25f && c.min_boost >= 0.25f && c.max_boost <= 64.0f;
     // The filtered kernel of a large launch leaves its pixels in doubt and the exact extremes to k_generate_resolve.  A small
     // launch (one 4K image) would pay that second kernel's latency with nothing to hide it behind: without statistics it runs the
-    // filtered kernel that falls back to the exact path in place, with statistics the exact kernel.
+    // filtered kernel that falls back to the exact path in place.  With statistics the choice is between the two kernels and the
+    // exact kernel (every pixel on the f64 path: 5.5 us per megapixel against 0.75 + the resolve kernel's ~20 us): the pair from
+    // about half a 4K frame up (round 3: 8 x 1080p 91 -> 30 us, 8 x 4K 141 -> 80), the exact kernel below.
     const bool small = generate_is_small(c, m);
-    if (small && keys != nullptr) filter = false;
-    const bool resolve = filter && aligned && !lut && !small;
+    const bool pair = keys != nullptr ? generate_resolve_pays(c, m) : !small;
+    if (keys != nullptr && !pair) filter = false;
+    const bool resolve = filter && aligned && !lut && pair;
     std::unique_lock<std::mutex> pair_lk(g_pair_mu, std::defer_lock);
     if (resolve) pair_lk.lock();
     if (resolve) {
@@ -1941,6 +1945,7 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
       c.stat_keys = keys ? w + 4 : nullptr;
       c.stat_stride = kStatWords;
       c.stat_out = keys ? content_minmax + 2 * i : nullptr;
+      c.stat_spread = (m <= 16 && (uint64_t)((c.map_w + 1u) >> 1) * c.map_h >= 512u * 64u) ? 1u : 0u;
     } else if (keys != nullptr) {
       HIP_TRY(launch_stats_init(keys + 2 * i, m, s));
     }

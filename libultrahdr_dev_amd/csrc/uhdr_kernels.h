@@ -8,7 +8,12 @@ namespace uhdr {
 // 64 KiB per image: header, then kStatLists lists of kStatCap entries (0.2 % of a 4K map's pixels are in doubt: ~1000 entries per
 // image, ~16 per list).  Several lists per image because a wave appends with ONE returning atomic on its list's count, and atomics
 // on one address are served one after the other at the memory side (~1 us each: a single count per image cost the kernel 30 %).
-constexpr uint32_t kStatLists = 64, kStatCap = 254, kStatHdr = 8 + kStatLists, kStatWords = kStatHdr + kStatLists * kStatCap;
+// kStatEst: in launches of few images every wave of an image starts at once, finds nothing published and publishes its estimates' extremes:
+// thousands of atomics on two words, served one after the other (one 4K image: 80 us for a 10 us kernel).  Such launches
+// (GenConsts::stat_spread: at most 16 images of at least 512 waves) publish to and prune by one pair of words per LIST instead;
+// the others keep the single pair, which prunes better.
+constexpr uint32_t kStatLists = 64, kStatCap = 252, kStatEst = 8 + kStatLists, kStatHdr = kStatEst + 2 * kStatLists,
+                   kStatWords = kStatHdr + kStatLists * kStatCap;
 static_assert(kStatWords <= 16384, "statistics workspace per image");   // candidate pairs per image before the image is swept exactly
 constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4 KiB kernarg segment: 64 x 56 B + consts)
 
@@ -62,7 +67,8 @@ struct GenConsts {
   uint32_t stat_stride; // words between the key pairs of consecutive images (2 in a caller's min/max array)
   // filtered kernel (always): per image kStatWords words -- [0] ~key of the smallest ESTIMATE seen, [1] key of the largest,
   // [3] slices of k_generate_resolve that have finished, [4] [5] the exact keys (stat_keys points here, stat_stride = kStatWords),
-  // [8 + l] entries in list l, [kStatHdr + l * kStatCap ..] list l: pairs with a pixel in doubt or a statistics candidate (a block
+  // [8 + l] entries in list l, [kStatEst + 2 l], [kStatEst + 2 l + 1] words 0 and 1 once more per list (launches of few images),
+  // [kStatHdr + l * kStatCap ..] list l: pairs with a pixel in doubt or a statistics candidate (a block
   // appends to list blk % kStatLists; a count beyond kStatCap means: sweep the image).  k_generate_resolve
   // redoes them on the exact path, writes the image's (min, max) to stat_out (when not null) and clears the header for the next
   // launch: no memset and no finalize kernel around the launch.
@@ -73,6 +79,7 @@ struct GenConsts {
   // band, and the gains below / above which the clamp certainly applies
   float flt_scale, flt_delta, flt_lo, flt_hi;
   float flt_gain_rel;   // 2 x kRel: how far (relatively) a filter estimate of the gain may sit from the exact one
+  uint32_t stat_spread; // the estimates' extremes are published per list (kStatEst): launches of few, large images
 };
 struct EvalConsts {
   float min_boost, max_boost, log2_min, log2_max;
@@ -186,6 +193,7 @@ hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr
                            bool filter, hipStream_t s);
 // a launch of n images this size is too small to be worth k_generate_resolve's latency (a single 4K image: 13 us against 24)
 bool generate_is_small(const GenConsts& c, int n);
+bool generate_resolve_pays(const GenConsts& c, int n);   // a launch with statistics: the filtered kernel + k_generate_resolve beat the exact kernel
 hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s);
 // after every filtered launch: the pixels it left in doubt and its statistics candidates on the exact path
 hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, hipStream_t s);

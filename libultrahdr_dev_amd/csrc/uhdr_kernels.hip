@@ -589,15 +589,17 @@ __global__ void __launch_bounds__(BLOCK, 1) k_generate(const GenConsts c, const 
       float wmin = emin, wmax = emax;          // what this wave already knows exactly (gain := 1 of pixels without SDR luminance)
       wave_minmax(wmin, wmax);
       const float e = c.flt_gain_rel;
-      uint32_t e0 = __hip_atomic_load(&ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      uint32_t e1 = __hip_atomic_load(&ws[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the words the estimates' extremes are published in: one pair per image, or -- launches of few images, kStatEst -- per list)
+      uint32_t* est = c.stat_spread != 0u ? ws + kStatEst + 2u * (blk % kStatLists) : ws;
+      uint32_t e0 = __hip_atomic_load(&est[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t e1 = __hip_atomic_load(&est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t k0 = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t k1 = __hip_atomic_load(&keys[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (amin <= amax) {   // publish this wave's estimates (one lane; the words only grow)
         const uint32_t m0 = ~float_to_key(amin), m1 = float_to_key(amax);
         if ((threadIdx.x & 63u) == 0u) {
-          if (e0 < m0) atomicMax(&ws[0], m0);
-          if (e1 < m1) atomicMax(&ws[1], m1);
+          if (e0 < m0) atomicMax(&est[0], m0);
+          if (e1 < m1) atomicMax(&est[1], m1);
         }
         e0 = e0 < m0 ? m0 : e0; e1 = e1 < m1 ? m1 : e1;
       }
@@ -735,9 +737,10 @@ __global__ void __launch_bounds__(256) k_generate_resolve(const GenConsts c, con
       c.stat_out[2u * img_i] = mn;
       c.stat_out[2u * img_i + 1u] = mx;
     }
-#pragma unroll
-    for (uint32_t k = 0; k < 8u + kStatLists; ++k) __hip_atomic_store(&ws[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();   // (words 4 and 5 have been read)
+  if (s_last == kResolveSlices - 1u && threadIdx.x < kStatHdr)   // the header, cleared for the next launch
+    __hip_atomic_store(&ws[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int TF>
 static hipError_t launch_stats_resolve_tf(const GenConsts& c, const GenBatch& b, int n, bool aligned, hipStream_t s) {
@@ -758,7 +761,14 @@ hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, in
 bool generate_is_small(const GenConsts& c, int n) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   const uint32_t span = (uint32_t)kGenBlock * (uint32_t)kGenTiles;
-  return (uint64_t)((total + span - 1u) / span) * (uint64_t)n < 2048u;
+  return (uint64_t)((total + span - 1u) / span) * (uint64_t)n < 1024u;
+}
+
+// a launch WITH statistics: is the filtered kernel + k_generate_resolve faster than the exact kernel?  (from 128 spans of 1024 pairs)
+bool generate_resolve_pays(const GenConsts& c, int n) {
+  const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
+  const uint32_t span = (uint32_t)kGenBlock * (uint32_t)kGenTiles;
+  return (uint64_t)((total + span - 1u) / span) * (uint64_t)n >= 128u;
 }
 
 template <int TF, bool ALIGNED, bool LUT, bool FILTER>

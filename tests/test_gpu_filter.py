@@ -153,3 +153,22 @@ def test_filtered_equals_unfiltered_on_64_4k_frames(hip, tf):
     a, b = res[hip.GENERATE_EXACT], res[hip.GENERATE_UNFILTERED]
     assert torch.equal(a[0], b[0]), int((a[0] != b[0]).sum())
     assert torch.equal(a[1].view(torch.int32), b[1].view(torch.int32))
+
+
+@pytest.mark.parametrize("w,h,n", [(3840, 2160, 1), (1920, 1080, 3), (1280, 720, 20), (3840, 2160, 12), (1024, 512, 2)])
+@pytest.mark.parametrize("kind", ["random", "flat", "ramp"])
+def test_statistics_routes_of_small_and_medium_launches(hip, kind, w, h, n):
+    """A launch with statistics takes one of three routes by its size (uhdr_capi.hip): the exact kernel (tiny), the filtered
+    kernel with one span per block + k_generate_resolve, or the four-span kernel + resolve; launches of few large images publish
+    their estimates per list (GenConsts::stat_spread).  Every route, twice in a row on one stream (the resolve kernel leaves the
+    header -- per-list words included -- cleared), on content that fills the lists (flat: every pixel a candidate or in doubt)
+    and content that does not: bytes and statistics of the unfiltered kernel."""
+    lib = hip.load()
+    rng = np.random.RandomState(w + n)
+    frames = _frames(kind, w, h, n, rng)
+    um, _, ustat = _run(lib, hip, frames, w, h, 0, 2, 1, hip.GENERATE_UNFILTERED)
+    for _ in range(2):
+        fm, fm2, fstat = _run(lib, hip, frames, w, h, 0, 2, 1, hip.GENERATE_EXACT)
+        for i in range(n):
+            assert np.array_equal(fm[i], um[i]) and np.array_equal(fm2[i], um[i]), (kind, w, h, n, i)
+        assert np.array_equal(fstat, ustat), (kind, w, h, n)

@@ -82,6 +82,18 @@ for _f in ("uhdr_kernels.hip", "uhdr_kernels.h", "uhdr_device_math.h"):
     _h.update(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "libultrahdr_dev_amd", "csrc", _f), "rb").read())
 traffic["sources_sha16"] = _h.hexdigest()[:16]   # bench.py reports these bytes only while the kernels are the ones profiled
 summary["traffic"] = traffic
+# the JSON line the traced process itself printed: HIP events around the same launches the trace has timed (tracing serialises the
+# kernels -- each dispatch begins when the one before has retired --, so a plain run of the same command can be faster than both:
+# profiles/README.md, "the tracer and the boxes")
+try:
+    for line in open(os.path.join(prof, "stats.log")):
+        if line.startswith("{"):
+            d = json.loads(line)
+            summary["traced_process_bench_line"] = {"value": d["value"], "ms_per_step": d["ms_per_step"],
+                                                    "generate_avg_launch_ms": d["kernels"]["generate"]["avg_launch_ms"],
+                                                    "apply_avg_launch_ms": d["kernels"]["apply"]["avg_launch_ms"]}
+except Exception:
+    pass
 json.dump(traffic, open(outp + "_traffic.json", "w"), indent=1)
 json.dump(summary, open(outp + ".json", "w"), indent=1)
 with open(outp + ".txt", "w") as o:
@@ -91,6 +103,8 @@ with open(outp + ".txt", "w") as o:
     o.write("\n== the last %d dispatches of each hot kernel = the K timed steps of `bench.py --steps 20 --warmup 5` (the averages above include the ~450 launches of the 0.5 s clock ramp, made while the clocks are still rising) ==\n" % TIMED)
     for n, v in summary["timed_steps"].items():
         o.write("%-112s avg=%10.1f us  min=%8.1f  max=%8.1f\n" % (n, v["avg_ns"] / 1e3, v["min_ns"] / 1e3, v["max_ns"] / 1e3))
+    if "traced_process_bench_line" in summary:
+        o.write("\n== the bench line of this traced process (HIP events in the same run) ==\n%s\n" % json.dumps(summary["traced_process_bench_line"]))
     o.write("\n== our kernels (per dispatch) ==\n")
     for n, v in summary["our_kernels_trace"].items():
         o.write("%s\n   %s\n" % (n, json.dumps(v)))

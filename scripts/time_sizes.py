@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """batched generate + apply (FAST -> HLG 1010102) for other frame sizes than the bench's 64 x 4K: ms per launch and TB/s of algorithmic bytes"""
-import ctypes as C, os, sys
+import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -13,6 +13,12 @@ s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def timed(fn, iters=30):
     for _ in range(5):
         fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15:   # (clocks: the card raises them only under load)
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):

@@ -27,7 +27,8 @@ typedef struct uhdr_hip_comm uhdr_hip_comm;
 /* id: UHDR_HIP_COMM_ID_BYTES bytes, written (ncclGetUniqueId).  Call on ONE rank. */
 int uhdr_hip_comm_get_unique_id(void* id);
 
-/* Collective over all `world` ranks: joins the communicator the id names, on HIP device `device` (made current for the call).
+/* Collective over all `world` ranks: joins the communicator the id names, on HIP device `device` (current inside every call on
+ * the communicator, the caller's current device again when the call returns).
  * world == 1 is valid (a single-GPU run of a multi-GPU program). */
 int uhdr_hip_comm_init(const void* id, int world, int rank, int device, uhdr_hip_comm** comm);
 

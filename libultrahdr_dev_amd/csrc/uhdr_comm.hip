@@ -35,6 +35,17 @@ __global__ void __launch_bounds__(256) k_fold_minmax(const float* __restrict__ p
     red[1] = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
   }
 }
+// the communicator's device is current inside a call and the caller's again afterwards
+struct DeviceGuard {
+  int before = -1;
+  bool ok = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&before) != hipSuccess) before = -1;
+    ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() { if (before >= 0) (void)hipSetDevice(before); }
+};
+
 __global__ void k_unfold_minmax(const float* __restrict__ red, float* __restrict__ out) {
   out[0] = -red[0];
   out[1] = red[1];
@@ -60,7 +71,8 @@ int uhdr_hip_comm_get_unique_id(void* id) {
 int uhdr_hip_comm_init(const void* id, int world, int rank, int device, uhdr_hip_comm** out) {
   if (id == nullptr || out == nullptr || world < 1 || rank < 0 || rank >= world || device < 0) return kInvalidParam;
   *out = nullptr;
-  if (hipSetDevice(device) != hipSuccess) return kInvalidParam;
+  DeviceGuard on(device);
+  if (!on.ok) return kInvalidParam;
   uhdr_hip_comm* c = new (std::nothrow) uhdr_hip_comm();
   if (c == nullptr) return kInsufficientResource;
   c->world = world; c->rank = rank; c->device = device; c->red = nullptr; c->comm = nullptr;
@@ -82,6 +94,8 @@ int uhdr_hip_comm_world(const uhdr_hip_comm* c, int* world, int* rank) {
 int uhdr_hip_comm_allreduce_minmax(uhdr_hip_comm* c, const float* per_image, int images, float* batch_minmax, void* stream) {
   if (c == nullptr || batch_minmax == nullptr || images < 0 || (images > 0 && per_image == nullptr)) return kInvalidParam;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  DeviceGuard on(c->device);
+  if (!on.ok) return kUnknown;
   hipLaunchKernelGGL(k_fold_minmax, dim3(1), dim3(256), 0, s, per_image, images, c->red);
   if (hipGetLastError() != hipSuccess) return kUnknown;
   if (ncclAllReduce(c->red, c->red, 2, ncclFloat, ncclMax, c->comm, s) != ncclSuccess) return kUnknown;
@@ -91,6 +105,7 @@ int uhdr_hip_comm_allreduce_minmax(uhdr_hip_comm* c, const float* per_image, int
 
 int uhdr_hip_comm_destroy(uhdr_hip_comm* c) {
   if (c == nullptr) return kInvalidParam;
+  DeviceGuard on(c->device);
   const bool ok = ncclCommDestroy(c->comm) == ncclSuccess;
   (void)hipFree(c->red);
   delete c;

@@ -49,7 +49,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="4K frame pairs resident per GPU")
+    ap.add_argument("--frames", type=int, default=64, help="4K frame pairs per step and GPU (one batch)")
+    ap.add_argument("--rotate", type=int, default=3, help="resident batches per GPU: step k works on batch k mod R, so that no step "
+                    "reads what the step before it touched (a fixed batch leaves part of its 8-bit chroma planes in the 256 MB Infinity "
+                    "Cache for the next step's generate: ~2 %% of the rate, VERDICT r03).  `value` is this protocol; the fixed-batch "
+                    "figure (R = 1) is reported beside it as fixed_batch")
     ap.add_argument("--ramp-ms", type=float, default=500.0, help="keep the GPU busy with the same step for this long before the W "
                     "warmup steps: the card raises its clocks only under sustained load (a 5-step warmup is 6 ms; measured 5 %% "
                     "between a cold and a ramped card).  Reported as clock_ramp_ms; 0 switches it off")
@@ -103,7 +107,7 @@ def workload_name(a, world, dry=False):
     return ("dry run, no GPU work: " if dry else "") + name
 
 
-def collective_report(dist, backend, rank, world, device_label, local_mm, reduced, dev=None, iters=50):
+def collective_report(dist, backend, rank, world, device_label, local_mm, reduced, dev=None, iters=50, path="torch.distributed"):
     """What lets a reader of rank 0's line check that the N ranks were real and that the path's one exchange crossed all of them:
     every rank's identity (host, pid, device), the reduced (min, max) checked against the ranks' own contributions gathered on the
     side, and the time of the 8-byte all-reduce by itself (median over `iters`, max over ranks).  Collective: every rank calls it."""
@@ -129,6 +133,7 @@ def collective_report(dist, backend, rank, world, device_label, local_mm, reduce
     med = torch.tensor([statistics.median(times)], dtype=torch.float64, device=dev if dev is not None else "cpu")
     dist.all_reduce(med, op=dist.ReduceOp.MAX)
     return {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world": dist.get_world_size(), "ranks": idents,
+            "path": path,
             "devices": [i["device"] for i in idents], "distinct_processes": len({(i["host"], i["pid"]) for i in idents}),
             "distinct_devices": len({(i["host"], i["device"]) for i in idents}),
             "allreduce_us": round(float(med.item()), 1), "allreduce_bytes": 8,
@@ -172,7 +177,7 @@ def dry_run(a, world, rank):
 class Batch:
     """`frames` 4K pairs + their maps and 1010102 outputs, all resident in this rank's HBM."""
 
-    def __init__(self, lib, frames, rank):
+    def __init__(self, lib, frames, rank, seed_offset=0):
         self.lib, self.n = lib, frames
         self.stats = True
         self.p010, self.yuv, self.maps, self.outs = [], [], [], []
@@ -185,7 +190,7 @@ class Batch:
         self.p010, self.yuv = arena(W * H * 3, False), arena(W * H * 3 // 2, False)
         self.maps, self.outs = arena((W // 4) * (H // 4), True), arena(W * H * 4, True)
         for i in range(frames):
-            synth.lcg_frame(W, H, sharding.image_seed(rank * frames + i), out=(self.p010[i], self.yuv[i]))   # seed = 1234 + global image index
+            synth.lcg_frame(W, H, sharding.image_seed(seed_offset + rank * frames + i), out=(self.p010[i], self.yuv[i]))   # seed = 1234 + global image index
         self.minmax = torch.zeros(2 * frames, dtype=torch.float32, device="cuda")
         self.yi = api.image_array([api.yuv420_image(y.data_ptr(), W, H, api.CG_BT709) for y in self.yuv])
         self.pi = api.image_array([api.p010_image(p.data_ptr(), W, H, api.CG_BT2100) for p in self.p010])
@@ -572,14 +577,22 @@ def main():
     lib = api.init(dev)
     fmt = api.OUTPUT_HDR_HLG if a.apply_format == "hlg" else api.OUTPUT_HDR_PQ
 
-    batch = Batch(lib, a.frames, rank)
-    batch.stats = not a.no_stats
+    # R resident batches (R x 4.55 GB of the 288 GB): the timed steps rotate over them.  Batch 0 holds SURVEY 8(d)'s seeds
+    # (1234 + global image index: what cpu_baseline cross-checks), the others the same generator 65536 seeds further on.
+    R = max(1, a.rotate)
+    batches = [Batch(lib, a.frames, rank, seed_offset=65536 * r) for r in range(R)]
+    for bt in batches:
+        bt.stats = not a.no_stats
+    batch = batches[0]
+    turn = [0]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     red = torch.zeros(2, dtype=torch.float32, device="cuda")
 
     side = torch.cuda.Stream() if world > 1 else None   # the exchange's own stream
 
-    def step(ev_gen=None, ev_app=None, exchange=True):
+    def step(ev_gen=None, ev_app=None, exchange=True, rotate=True):
+        batch = batches[turn[0] % R] if rotate else batches[0]
+        turn[0] += 1
         batch.generate(stream, ev_gen)
         work = None
         if world > 1 and exchange:
@@ -596,17 +609,17 @@ def main():
                 work.wait()                              # (RCCL: the current stream waits for the collective; gloo: the host does)
             torch.cuda.current_stream().wait_stream(side)
 
-    def timed_steps(evs_g=None, evs_a=None):
+    def timed_steps(evs_g=None, evs_a=None, rotate=True):
         """W untimed steps, then exactly K timed ones between barriers + synchronisations; -> seconds (max over ranks)"""
         for _ in range(a.warmup):
-            step()
+            step(rotate=rotate)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            step(evs_g, evs_a)
+            step(evs_g, evs_a, rotate=rotate)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -629,6 +642,8 @@ def main():
         torch.cuda.synchronize()
     ev_gen, ev_app = [], []
     elapsed = timed_steps(ev_gen, ev_app)
+    # the same protocol on ONE batch, step after step (rounds 1-3's `value`): reported beside `value`, never as it
+    fixed_elapsed = timed_steps(rotate=False) if R > 1 else None
 
     def avg_ms_per_launch(evs):   # every event pair brackets exactly one kernel launch of <= CHUNK frames
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
@@ -683,13 +698,24 @@ def main():
                 "value": round(a.frames * world * a.steps * (W * H / 1e6) / cold_elapsed, 1), "ms_per_step": round(cold_elapsed / a.steps * 1e3, 4),
                 "what": "the same W warmup + K timed steps run first, on the card as the setup leaves it (idle clocks); `value` is the same "
                         "measurement after the step has kept the card busy for clock_ramp_ms"},
+            "protocol": {"resident_batches": R, "what": "step k works on batch k mod %d (each %d frames with inputs, maps and outputs of its own, all "
+                         "resident in HBM before the timed region): no step reads or writes what the step before it touched" % (R, a.frames)},
+            "fixed_batch": None if fixed_elapsed is None else {
+                "value": round(a.frames * world * a.steps * (W * H / 1e6) / fixed_elapsed, 1), "ms_per_step": round(fixed_elapsed / a.steps * 1e3, 4),
+                "what": "the same W + K steps over ONE batch (rounds 1-3's protocol), measured right after `value`: the next step's generate then "
+                        "finds part of the chroma planes apply read in the 256 MB Infinity Cache"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 in, f32+f64 math, u8/u32 out",
             "data": "synthetic",
             "config": {"workload": workload_name(a, world),
-                       "frames_per_gpu": a.frames, "global_frames": a.frames * world, "width": W, "height": H, "images_per_launch": min(CHUNK, a.frames),
+                       "frames_per_gpu": a.frames, "global_frames": a.frames * world, "resident_batches_per_gpu": R, "width": W, "height": H,
+                       "images_per_launch": min(CHUNK, a.frames),
                        "parallelism": "one image batch per GPU, no pixel traffic between GPUs"},
             "roofline": {"bound": "hbm", "kernel": "k_apply_s4<HLG>" if dominant == "apply" else "k_generate<HLG,aligned>",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "frac_note": "HIP events on the launch stream around each launch of the dominant kernel, plain run: consecutive kernels "
+                                      "overlap at their boundaries by ~30 us per step, so per-kernel event times sum to less than the step "
+                                      "(profiles/r03_trace_vs_events.txt); frac_whole_step is the number to quote",
+                         "frac_whole_step": round((GEN_BYTES + APP_BYTES) * total_frames / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_launch,
                          "avg_launch_ms": round(app_ms if dominant == "apply" else gen_ms, 4),

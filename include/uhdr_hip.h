@@ -167,8 +167,10 @@ int uhdr_hip_shutdown(void);
  * exact_images images of width x height pixels (at most 64 per launch; 0 for width / height with exact_images == 0), and the
  * sampleMap weight table of `map_scale_factor` (0: none; 4 is always resident).  After this the calls it covers only enqueue. */
 int uhdr_hip_stream_reserve(void* stream, int exact_images, size_t width, size_t height, int map_scale_factor);
-/* Free what the library holds for `stream` (waits for the stream first).  A service that creates and destroys streams calls this
- * before hipStreamDestroy: workspaces are keyed by the stream handle, and a recycled handle would inherit the old one. */
+/* Free what the library holds for `stream` (waits for the stream first): its statistics workspace, its EXACT-apply lists and the
+ * smaller lists those outgrew.  A service that creates and destroys streams calls this before hipStreamDestroy: workspaces are
+ * keyed by the stream handle, and a recycled handle would inherit the old one.  NOT returned: what belongs to the device rather
+ * than to a stream (staging sets of host-memory calls, codec contexts, weight tables) -- uhdr_hip_shutdown() frees those. */
 int uhdr_hip_stream_release(void* stream);
 /* last HIP error text seen by the library on this thread ("" if none) */
 const char* uhdr_hip_last_error(void);
@@ -270,7 +272,9 @@ int uhdr_hip_jpeg_progressive_coefficients(const void* jpeg, size_t jpeg_size, i
  * run on the device; restart intervals (DRI / RSTn) are read.  Progressive files (SOF2) are read too: their scans are entropy-decoded
  * on the host, dequantisation and IDCT run on the device (complete files; the planes are libjpeg's).  ERROR_UNSUPPORTED_FEATURE:
  * arithmetic-coded / lossless files (libjpeg reads some of them, this decoder does not); UNKNOWN_ERROR: malformed file, or a sampling other than 4:2:0 / single plane, where the reference's call
- * returns false as well (:283-289).  The call waits for the stream. */
+ * returns false as well (:283-289) -- and a host allocation that failed while parsing (a progressive file's coefficient array).
+ * ERROR_INSUFFICIENT_RESOURCE with out == NULL is therefore always the size probe's answer: the header parsed and *desc holds the
+ * size; on every status returned before that point *desc is zeroed.  The call waits for the stream. */
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
                          int mem_space, void* stream);
 

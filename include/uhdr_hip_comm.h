@@ -38,7 +38,10 @@ int uhdr_hip_comm_world(const uhdr_hip_comm* comm, int* world, int* rank);
  * uhdr_hip_generate_gainmap_batch wrote them; images may be 0 (a rank without images contributes nothing).  batch_minmax: device
  * pointer to 2 floats, written: (min over all images of all ranks, max over them); (+inf, -inf) when no rank had an image.
  * Asynchronous on `stream` (a hipStream_t, NULL = the null stream): a fold kernel, one ncclAllReduce of 2 floats, a store; the
- * caller's next kernels on other streams overlap it.  Collective: every rank calls it once per batch, in the same order. */
+ * caller's next kernels on other streams overlap it.  Collective: every rank calls it once per batch, in the same order.
+ * batch_minmax itself is the reduction buffer (it holds intermediate values until the call's work on `stream` is done; it must
+ * not alias per_image_minmax), the communicator keeps no scratch: exchanges in flight on different streams, each with its own
+ * batch_minmax, do not meet -- as long as every rank issues them in one order, which RCCL requires of a communicator. */
 int uhdr_hip_comm_allreduce_minmax(uhdr_hip_comm* comm, const float* per_image_minmax, int images, float* batch_minmax, void* stream);
 
 /* Collective (ncclCommDestroy), frees the handle. */

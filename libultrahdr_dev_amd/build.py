@@ -48,12 +48,6 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    if force or _stale(COMM_LIB, COMM_DEPS, CSRC):
-        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib")
-        cmd = [HIPCC] + FLAGS + ["-shared", "-o", COMM_LIB] + [os.path.join(CSRC, s) for s in COMM_SOURCES] + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
     shim_src = [os.path.join(CSRC, s) for s in SHIM_SOURCES]
     if all(os.path.exists(s) for s in shim_src) and (force or _stale(SHIM_LIB, SHIM_DEPS, CSRC)):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
@@ -61,6 +55,17 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # last, and not fatal: the pixel path does not depend on RCCL, so neither does its build.  Without librccl the comm library
+    # is skipped (load_comm() then raises its ImportError; nothing else needs it)
+    if force or _stale(COMM_LIB, COMM_DEPS, CSRC):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib")
+        cmd = [HIPCC] + FLAGS + ["-shared", "-o", COMM_LIB] + [os.path.join(CSRC, s) for s in COMM_SOURCES] + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+        except (subprocess.CalledProcessError, OSError) as e:
+            print("libuhdr_hip_comm.so skipped (is RCCL installed under %s?): %s" % (rocm_lib, e), file=sys.stderr)
     return LIB
 
 

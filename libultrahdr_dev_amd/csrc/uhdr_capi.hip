@@ -53,7 +53,7 @@ struct DeviceState : StageSet {
   float* lut = nullptr;       // the five static transfer-function tables (kLutTotal floats), built at init
   std::vector<std::unique_ptr<StageSet>> sets;   // every set ever leased ...
   std::vector<StageSet*> free_sets;              // ... and those not in use (both under g_mu)
-  std::vector<void*> retired;                    // workspaces that were outgrown while a launch may still have named them
+  std::vector<std::pair<hipStream_t, void*>> retired;   // workspaces that were outgrown while a launch may still have named them, by stream
   // uhdr_hip_jpegr_decode[_batch]: per-file decoder workspaces and planes
   std::vector<void*> pool;
   std::vector<size_t> pool_bytes;
@@ -679,8 +679,15 @@ int stat_workspace(DeviceState* st, hipStream_t s, uint32_t** out) {
   try { wp = &st->stat_ws[s]; } catch (const std::bad_alloc&) { return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE; }
   uint32_t*& w = *wp;
   if (w == nullptr) {   // cleared once, in stream order: every launch leaves the headers cleared behind it
-    HIP_TRY(hipMalloc(&w, kStatWsBytes));
-    HIP_TRY(hipMemsetAsync(w, 0, kStatWsBytes, s));
+    uint32_t* fresh = nullptr;
+    HIP_TRY(hipMalloc(&fresh, kStatWsBytes));
+    const hipError_t me = hipMemsetAsync(fresh, 0, kStatWsBytes, s);
+    if (me != hipSuccess) {   // never publish a workspace whose headers were not cleared
+      (void)hipFree(fresh);
+      set_err("hipMemsetAsync(statistics workspace)", me);
+      return UHDR_HIP_UNKNOWN_ERROR;
+    }
+    w = fresh;
   }
   *out = w;
   return UHDR_HIP_NO_ERROR;
@@ -698,12 +705,19 @@ int exact_workspace(DeviceState* st, hipStream_t s, int images, uint32_t cap, ui
   DeviceState::ExWs& w = *wp;
   if (w.bytes < need) {
     // another caller of this stream may be about to launch with the old one: it stays allocated (sizes at least double)
-    if (w.p) { st->retired.push_back(w.p); w.p = nullptr; }
+    if (w.p) { st->retired.emplace_back(s, static_cast<void*>(w.p)); w.p = nullptr; }
     const size_t grown = std::max(need, 2 * w.bytes);
     w.bytes = 0;
-    HIP_TRY(hipMalloc(&w.p, grown));
+    uint32_t* fresh = nullptr;
+    HIP_TRY(hipMalloc(&fresh, grown));
+    const hipError_t me = hipMemsetAsync(fresh, 0, (size_t)kMaxChunk * kExHdrWords * 4u, s);   // the headers: cleared once, left cleared by every launch
+    if (me != hipSuccess) {                                                                    // (never published uncleared)
+      (void)hipFree(fresh);
+      set_err("hipMemsetAsync(EXACT workspace)", me);
+      return UHDR_HIP_UNKNOWN_ERROR;
+    }
+    w.p = fresh;
     w.bytes = grown;
-    HIP_TRY(hipMemsetAsync(w.p, 0, (size_t)kMaxChunk * kExHdrWords * 4u, s));   // the headers: cleared once, left cleared by every launch
   }
   *out = w.p;
   return UHDR_HIP_NO_ERROR;
@@ -738,13 +752,22 @@ int uhdr_hip_stream_release(void* stream) {
   const int rc0 = current_state(&st);
   if (rc0 != UHDR_HIP_NO_ERROR) return rc0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // the pair lock first, THEN the wait: a generate / EXACT-apply pair another thread enqueues on `s` holds g_pair_mu from the moment
+  // it takes its workspace until its kernels are enqueued, so whatever names a workspace of `s` is on the stream before the wait
+  std::lock_guard<std::mutex> pl(g_pair_mu);
   HIP_TRY(hipStreamSynchronize(s));
-  std::lock_guard<std::mutex> pl(g_pair_mu);   // no launch of a generate / apply pair is between its workspace and its kernels
   std::lock_guard<std::mutex> lk(g_mu);
   auto a = st->stat_ws.find(s);
   if (a != st->stat_ws.end()) { if (a->second) (void)hipFree(a->second); st->stat_ws.erase(a); }
   auto b = st->ex_ws.find(s);
   if (b != st->ex_ws.end()) { if (b->second.p) (void)hipFree(b->second.p); st->ex_ws.erase(b); }
+  // ... and the lists of this stream that EXACT launches outgrew (kept allocated until nothing on the stream can name them: now)
+  size_t keep = 0;
+  for (size_t i = 0; i < st->retired.size(); ++i) {
+    if (st->retired[i].first == s) (void)hipFree(st->retired[i].second);
+    else st->retired[keep++] = st->retired[i];
+  }
+  st->retired.resize(keep);
   return UHDR_HIP_NO_ERROR;
 }
 
@@ -765,7 +788,7 @@ int uhdr_hip_shutdown(void) {
     for (auto& set : kv.second.sets)
       for (int i = 0; i < 14; ++i)
         if (set->stage[i]) (void)hipFree(set->stage[i]);
-    for (void* q : kv.second.retired) (void)hipFree(q);
+    for (auto& q : kv.second.retired) (void)hipFree(q.second);
     if (kv.second.map_ready) (void)hipEventDestroy(kv.second.map_ready);
     if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
     for (auto& cx : kv.second.codec_sets) {   // the leased codec contexts (their tables are this state's: not freed here)
@@ -927,7 +950,7 @@ int uhdr_hip_jpeg_progressive_coefficients(const void* jpeg, size_t jpeg_size, i
   if (jpeg == nullptr || blocks == nullptr || width == nullptr || height == nullptr || gray == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   jpeg::DecInfo info;
   const int prc = jpeg::parse_header(static_cast<const uint8_t*>(jpeg), jpeg_size, &info);
-  if (prc == -3) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  if (prc == -3) return UHDR_HIP_UNKNOWN_ERROR;   // host allocation failed; INSUFFICIENT_RESOURCE is the size-probe answer (*blocks set)
   if (prc == -2 || (prc == 0 && !info.progressive)) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
   if (prc != 0) return UHDR_HIP_UNKNOWN_ERROR;
   *width = info.w; *height = info.h; *gray = info.gray;
@@ -947,6 +970,10 @@ int uhdr_hip_jpeg_progressive_coefficients(const void* jpeg, size_t jpeg_size, i
 int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc,
                          int mem_space, void* stream) {
   if (jpeg == nullptr || desc == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  // INSUFFICIENT_RESOURCE is this call's size-probe answer (out == NULL / capacity too small: the header parsed and *desc is
+  // filled); every status returned before that point leaves *desc zeroed, and a host allocation failure inside the parser
+  // (std::bad_alloc, -3: a progressive file's coefficient array) is reported as UNKNOWN_ERROR so that it cannot be taken for it
+  memset(desc, 0, sizeof(*desc));
   jpeg::DecInfo info;
 #ifdef UHDR_JD_TIMING
   const auto T0 = std::chrono::steady_clock::now();
@@ -955,9 +982,9 @@ int uhdr_hip_jpeg_decode(const void* jpeg, size_t jpeg_size, void* out, size_t o
 #ifdef UHDR_JD_TIMING
   const auto T1 = std::chrono::steady_clock::now();
 #endif
-  if (prc == -3) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  if (prc == -3) return UHDR_HIP_UNKNOWN_ERROR;
   if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
-  if (prc != 0) return UHDR_HIP_UNKNOWN_ERROR;
+  if (prc != 0 || info.w <= 0 || info.h <= 0) return UHDR_HIP_UNKNOWN_ERROR;
   const size_t w = (size_t)info.w, h = (size_t)info.h;
   if (w > 8192 || h > 8192) return UHDR_HIP_ERROR_RESOLUTION_MISMATCH;   // kMaxWidth / kMaxHeight, jpegdecoderhelper.h:42-43
   const size_t luma = w * h, chroma = luma / 4, need = info.gray ? luma : luma + 2 * chroma;
@@ -1077,7 +1104,7 @@ int parse_jpegr_file(const void* jpegr, size_t jpegr_size, int output_format, bo
     f->jpg[k] = file + img[k].begin; f->len[k] = img[k].len;
     const bool parsed = by_header || (k == 0 && have0 && img[0].begin == 0 && img[0].len == len0);
     const int prc = parsed ? 0 : jpeg::parse_header(f->jpg[k], f->len[k], &f->info[k]);
-    if (prc == -3) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+    if (prc == -3) return UHDR_HIP_UNKNOWN_ERROR;   // host allocation failed (never the capacity-probe status)
     if (prc == -2) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
     if (prc != 0 || f->info[k].w > 8192 || f->info[k].h > 8192) return UHDR_HIP_ERROR_DECODE_ERROR;
   }
@@ -1116,8 +1143,10 @@ extern "C" {
 int uhdr_hip_jpeg_decode_rgba(const void* jpeg, size_t jpeg_size, void* out, size_t out_capacity, uhdr_hip_image_t* desc, int mem_space, void* stream) {
   if (jpeg == nullptr || desc == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
   uhdr_hip_image_t planes;
+  memset(&planes, 0, sizeof(planes));
   int rc = uhdr_hip_jpeg_decode(jpeg, jpeg_size, nullptr, 0, &planes, UHDR_HIP_MEM_DEVICE, stream);   // header probe
   if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return rc;
+  if (planes.width == 0 || planes.height == 0) return UHDR_HIP_UNKNOWN_ERROR;                        // (a probe answer always carries the size)
   if (planes.pixelFormat != UHDR_HIP_PIX_FMT_YUV420) return UHDR_HIP_UNKNOWN_ERROR;                    // :258-270: YCbCr 4:2:0 only
   const size_t w = planes.width, h = planes.height, need = w * h * 4;
   memset(desc, 0, sizeof(*desc));
@@ -1716,9 +1745,11 @@ int uhdr_hip_jpegr_encode_api3(const uhdr_hip_image_t* p010_in, const void* sdr_
 
   // :457-462 decode; a header probe first for the size (host work: an unreadable file is reported without a device)
   uhdr_hip_image_t ydesc;
+  memset(&ydesc, 0, sizeof(ydesc));
   rc = uhdr_hip_jpeg_decode(pj, sdr_jpeg_size, nullptr, 0, &ydesc, UHDR_HIP_MEM_DEVICE, stream);
   if (rc == UHDR_HIP_ERROR_UNSUPPORTED_FEATURE) return rc;
-  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE || ydesc.pixelFormat != UHDR_HIP_PIX_FMT_YUV420) return UHDR_HIP_ERROR_DECODE_ERROR;
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE || ydesc.pixelFormat != UHDR_HIP_PIX_FMT_YUV420 || ydesc.width == 0 || ydesc.height == 0)
+    return UHDR_HIP_ERROR_DECODE_ERROR;
   EncodeCtx c{nullptr, stream, mem_space};
   if ((rc = current_state(&c.st)) != UHDR_HIP_NO_ERROR) return rc;
   const size_t w = ydesc.width, h = ydesc.height, ybytes = w * h + 2 * (w * h / 4);

@@ -46,16 +46,12 @@ struct DeviceGuard {
   ~DeviceGuard() { if (before >= 0) (void)hipSetDevice(before); }
 };
 
-__global__ void k_unfold_minmax(const float* __restrict__ red, float* __restrict__ out) {
-  out[0] = -red[0];
-  out[1] = red[1];
-}
+__global__ void k_unfold_minmax(float* red) { red[0] = -red[0]; }   // (-min, max) -> (min, max), in place
 }  // namespace
 
 struct uhdr_hip_comm {
   ncclComm_t comm;
   int world, rank, device;
-  float* red;   // 2 floats of device memory: (-min, max) on the way through the all-reduce
 };
 
 extern "C" {
@@ -75,11 +71,10 @@ int uhdr_hip_comm_init(const void* id, int world, int rank, int device, uhdr_hip
   if (!on.ok) return kInvalidParam;
   uhdr_hip_comm* c = new (std::nothrow) uhdr_hip_comm();
   if (c == nullptr) return kInsufficientResource;
-  c->world = world; c->rank = rank; c->device = device; c->red = nullptr; c->comm = nullptr;
+  c->world = world; c->rank = rank; c->device = device; c->comm = nullptr;
   ncclUniqueId u;
   memcpy(&u, id, sizeof u);
-  if (hipMalloc(&c->red, 2 * sizeof(float)) != hipSuccess) { delete c; return kInsufficientResource; }
-  if (ncclCommInitRank(&c->comm, world, u, rank) != ncclSuccess) { (void)hipFree(c->red); delete c; return kUnknown; }
+  if (ncclCommInitRank(&c->comm, world, u, rank) != ncclSuccess) { delete c; return kUnknown; }
   *out = c;
   return kOk;
 }
@@ -93,13 +88,17 @@ int uhdr_hip_comm_world(const uhdr_hip_comm* c, int* world, int* rank) {
 
 int uhdr_hip_comm_allreduce_minmax(uhdr_hip_comm* c, const float* per_image, int images, float* batch_minmax, void* stream) {
   if (c == nullptr || batch_minmax == nullptr || images < 0 || (images > 0 && per_image == nullptr)) return kInvalidParam;
+  if (images > 0 && batch_minmax + 2 > per_image && batch_minmax < per_image + 2 * (size_t)images) return kInvalidParam;   // (the result may not lie inside the input)
   hipStream_t s = static_cast<hipStream_t>(stream);
   DeviceGuard on(c->device);
   if (!on.ok) return kUnknown;
-  hipLaunchKernelGGL(k_fold_minmax, dim3(1), dim3(256), 0, s, per_image, images, c->red);
+  // the caller's two floats are the reduction buffer all the way -- (-min, max) folded into them, reduced in place, the sign put
+  // back in place --, so the communicator holds no state a second exchange could meet: calls on different streams with different
+  // batch_minmax are independent (RCCL itself wants a communicator's collectives issued in one order on every rank)
+  hipLaunchKernelGGL(k_fold_minmax, dim3(1), dim3(256), 0, s, per_image, images, batch_minmax);
   if (hipGetLastError() != hipSuccess) return kUnknown;
-  if (ncclAllReduce(c->red, c->red, 2, ncclFloat, ncclMax, c->comm, s) != ncclSuccess) return kUnknown;
-  hipLaunchKernelGGL(k_unfold_minmax, dim3(1), dim3(1), 0, s, c->red, batch_minmax);
+  if (ncclAllReduce(batch_minmax, batch_minmax, 2, ncclFloat, ncclMax, c->comm, s) != ncclSuccess) return kUnknown;
+  hipLaunchKernelGGL(k_unfold_minmax, dim3(1), dim3(1), 0, s, batch_minmax);
   return hipGetLastError() == hipSuccess ? kOk : kUnknown;
 }
 
@@ -107,7 +106,6 @@ int uhdr_hip_comm_destroy(uhdr_hip_comm* c) {
   if (c == nullptr) return kInvalidParam;
   DeviceGuard on(c->device);
   const bool ok = ncclCommDestroy(c->comm) == ncclSuccess;
-  (void)hipFree(c->red);
   delete c;
   return ok ? kOk : kUnknown;
 }

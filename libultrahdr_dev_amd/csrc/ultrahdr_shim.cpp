@@ -235,9 +235,10 @@ bool JpegDecoderHelperHip::decompressImage(const void* image, int length, decode
   mResultBuffer.clear();
   mWidth = mHeight = 0;
   if (image == nullptr || length <= 0 || uhdr_hip_init(0) != UHDR_HIP_NO_ERROR) return false;
-  uhdr_hip_image_t desc;
+  uhdr_hip_image_t desc = {};
   if (decodeTo == DECODE_TO_RGBA) {
     if (uhdr_hip_jpeg_decode_rgba(image, (size_t)length, nullptr, 0, &desc, UHDR_HIP_MEM_HOST, nullptr) != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return false;
+    if (desc.width == 0 || desc.height == 0) return false;   // (a probe answer always carries the size)
     mResultBuffer.resize(desc.width * desc.height * 4);   // jpegdecoderhelper.cpp:274
     if (uhdr_hip_jpeg_decode_rgba(image, (size_t)length, mResultBuffer.data(), mResultBuffer.size(), &desc, UHDR_HIP_MEM_HOST, nullptr) != UHDR_HIP_NO_ERROR) {
       mResultBuffer.clear();
@@ -247,7 +248,7 @@ bool JpegDecoderHelperHip::decompressImage(const void* image, int length, decode
     return true;
   }
   int rc = uhdr_hip_jpeg_decode(image, (size_t)length, nullptr, 0, &desc, UHDR_HIP_MEM_HOST, nullptr);
-  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE) return false;   // unreadable header, unsupported process, too large
+  if (rc != UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE || desc.width == 0 || desc.height == 0) return false;   // unreadable header, unsupported process, too large, out of memory
   mSingleChannel = desc.pixelFormat == UHDR_HIP_PIX_FMT_MONOCHROME;
   const size_t luma = desc.width * desc.height;
   mResultBuffer.resize(mSingleChannel ? luma : luma + 2 * (luma / 4));   // jpegdecoderhelper.cpp:264,266

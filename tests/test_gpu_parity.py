@@ -142,10 +142,10 @@ def test_lcg_frames_against_reference_checksums(hip, orc, key):
     oyi = orc.yuv420_image(yuv, w, h, orc.CG_BT709)
     omd = orc.Metadata(md.maxContentBoost, 1.0, 1.0, 0.0, 0.0, 1.0, md.maxContentBoost, 1)
     for fmt, gi in ((hip.OUTPUT_HDR_HLG, 1), (hip.OUTPUT_HDR_PQ, 2)):
-        if w <= 640:  # EXACT (double) path at full size is only run on the small frame: bit-exact
-            st, out, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, FLT_MAX, hip.APPLY_EXACT)
-            assert st == 0
-            assert "%016x" % olib.orc_checksum_u32(out.ctypes.data, out.size // 4) == LCG_GOLDEN[key][gi]
+        # the HIP EXACT kernels against the reference's own checksum at every size (4K and 8K included: 40-200 us per frame)
+        st, out, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, FLT_MAX, hip.APPLY_EXACT)
+        assert st == 0
+        assert "%016x" % olib.orc_checksum_u32(out.ctypes.data, out.size // 4) == LCG_GOLDEN[key][gi], "EXACT apply differs from the reference's checksum"
         st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, FLT_MAX, hip.APPLY_FAST)
         assert st == 0
         st2, ref, _ = orc.apply("orc_", oyi, gmap, omd, fmt, FLT_MAX, threads=16)
@@ -154,6 +154,33 @@ def test_lcg_frames_against_reference_checksums(hip, orc, key):
         worst, frac, alpha_ok = diff_1010102(fast.view(np.uint32), ref.view(np.uint32))
         assert alpha_ok and worst <= LSB_TOL
         print("LCG %dx%d %s apply fmt %d FAST: worst=%d LSB, differing fraction=%.5f" % (w, h, tfname, fmt, worst, frac))
+
+
+def test_8k_apply_to_linear_f16_exact_and_fast(hip, orc):
+    """BASELINE configs[4]'s "fp16 tolerance vs CPU" clause at its own size: 7680x4320, metadata max = 10000/203,
+    applyGainMap -> ULTRAHDR_OUTPUT_HDR_LINEAR (RGBA F16, ultrahdr.cpp:454-459, gainmapmath.h:136-147).  EXACT mode returns the
+    oracle's bytes; FAST mode stays within one half-precision ULP of them."""
+    from tests.gpu_util import gpu_apply, to_dev, half_ulp_diff
+    lib = hip.load()
+    w, h = 7680, 4320
+    _, yuv = orc.lcg_frame(w, h, 1234)
+    rng = np.random.RandomState(45)
+    gmap = rng.randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    maxb = np.float32(10000.0) / np.float32(203.0)
+    dy, dmap = to_dev(yuv), to_dev(gmap)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    md = hip.metadata(float(maxb))
+    omd = orc.Metadata(float(maxb), 1.0, 1.0, 0.0, 0.0, 1.0, float(maxb), 1)
+    st, ref, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, orc.CG_BT709), gmap, omd, hip.OUTPUT_HDR_LINEAR, FLT_MAX, threads=16)
+    assert st == 0
+    st, exact, dest = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, hip.OUTPUT_HDR_LINEAR, FLT_MAX, hip.APPLY_EXACT)
+    assert st == 0 and (dest.width, dest.height) == (w, h)
+    assert np.array_equal(exact, ref.view(np.uint8).reshape(-1)), "EXACT 8K F16 apply differs from the oracle"
+    st, fast, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, hip.OUTPUT_HDR_LINEAR, FLT_MAX, hip.APPLY_FAST)
+    assert st == 0
+    worst, frac = half_ulp_diff(fast.view(np.uint16), ref.view(np.uint16).reshape(-1))
+    assert worst <= HALF_ULP_TOL, worst
+    print("8K F16 FAST: worst=%d half-ULP, differing fraction=%.6f" % (worst, frac))
 
 
 # --------------------------------------------------------------------------------------------------

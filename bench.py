@@ -60,6 +60,13 @@ def parse():
     ap.add_argument("--apply-format", default="hlg", choices=["hlg", "pq"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "capi"], help="who issues the step's one exchange for N>1: torch.distributed "
+                    "(default; the path the gloo rehearsals cover) or the C library (libuhdr_hip_comm.so: uhdr_hip_comm_allreduce_minmax, "
+                    "the RCCL id carried to the ranks through torch.distributed's store).  capi needs backend nccl and one GPU per rank; "
+                    "where it cannot be set up on EVERY rank the run falls back to torch and says why in collective.path_note")
+    ap.add_argument("--exchange-with-one-rank", action="store_true", help="testing aid: with --gpus 1, still create the process group "
+                    "(a world of one) and run the per-step exchange and the collective report -- the one way a one-GPU box can put "
+                    "--comm capi's path through the bench on hardware.  Not the driver's protocol: the N = 1 headline has no exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra configs[1]/[4] timings (profiling runs)")
     ap.add_argument("--no-stats", action="store_true", help="experiment: generate without the per-image content min/max pass")
@@ -107,7 +114,7 @@ def workload_name(a, world, dry=False):
     return ("dry run, no GPU work: " if dry else "") + name
 
 
-def collective_report(dist, backend, rank, world, device_label, local_mm, reduced, dev=None, iters=50, path="torch.distributed"):
+def collective_report(dist, backend, rank, world, device_label, local_mm, reduced, dev=None, iters=50, path="torch.distributed", exchange=None):
     """What lets a reader of rank 0's line check that the N ranks were real and that the path's one exchange crossed all of them:
     every rank's identity (host, pid, device), the reduced (min, max) checked against the ranks' own contributions gathered on the
     side, and the time of the 8-byte all-reduce by itself (median over `iters`, max over ranks).  Collective: every rank calls it."""
@@ -126,7 +133,10 @@ def collective_report(dist, backend, rank, world, device_label, local_mm, reduce
         if dev is not None:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if exchange is not None:
+            exchange()                     # (--comm capi: the C library's fold + ncclAllReduce + store, on the current stream)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if dev is not None:
             torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e6)
@@ -139,6 +149,43 @@ def collective_report(dist, backend, rank, world, device_label, local_mm, reduce
             "allreduce_us": round(float(med.item()), 1), "allreduce_bytes": 8,
             "content_minmax": [float(reduced[0]), float(reduced[1])], "content_minmax_of_gathered_contributions": want,
             "reduction_checked": [float(reduced[0]), float(reduced[1])] == want}
+
+
+def init_capi_comm(dist, backend, rank, world, dev):
+    """--comm capi: one communicator of libuhdr_hip_comm.so per rank (include/uhdr_hip_comm.h), rank 0's RCCL id carried to the others
+    through torch.distributed.  Collective: every rank calls it; every rank gets the same answer -- (lib, handle, None) or
+    (None, None, reason) when ANY rank cannot take the path (the ranks agree before anything collective of RCCL's is called, so no
+    rank waits in ncclCommInitRank for one that never comes).  Nothing is re-executed and no process is replaced."""
+    def all_ok(ok):
+        votes = [None] * world
+        dist.all_gather_object(votes, bool(ok))
+        return all(votes)
+
+    lib, note = None, None
+    if backend != "nccl":
+        note = "--comm capi needs one GPU per rank (backend nccl); this run's backend is %s: the exchange stays on torch.distributed" % backend
+    else:
+        try:
+            lib = api.load_comm()
+        except (ImportError, OSError) as e:
+            note = "libuhdr_hip_comm.so could not be loaded (%s): the exchange stays on torch.distributed" % e
+    if not all_ok(note is None):
+        return None, None, note or "another rank could not take the C library path: the exchange stays on torch.distributed"
+    ident = (C.c_char * api.COMM_ID_BYTES)()
+    box = [None]
+    if rank == 0 and lib.uhdr_hip_comm_get_unique_id(ident) == 0:
+        box[0] = bytes(ident.raw)
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        return None, None, "uhdr_hip_comm_get_unique_id failed on rank 0: the exchange stays on torch.distributed"
+    ident = (C.c_char * api.COMM_ID_BYTES).from_buffer_copy(box[0])
+    handle = C.c_void_p()
+    rc = lib.uhdr_hip_comm_init(ident, world, rank, dev, C.byref(handle))
+    if not all_ok(rc == 0):
+        if rc == 0:
+            lib.uhdr_hip_comm_destroy(handle)
+        return None, None, "uhdr_hip_comm_init failed on a rank (status %d on rank %d): the exchange stays on torch.distributed" % (rc, rank)
+    return lib, handle, None
 
 
 def dry_run(a, world, rank):
@@ -162,7 +209,11 @@ def dry_run(a, world, rank):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        note = None
+        if getattr(a, "comm", "torch") == "capi":
+            _, _, note = init_capi_comm(dist, "gloo", rank, world, 0)
         coll = collective_report(dist, "gloo", rank, world, "cpu", (1.0 + rank, 4.0 + rank), (float(red[0]), float(-red[1])))
+        coll["path_note"] = note
     if rank == 0:
         print(json.dumps({"metric": "MPixels/sec gain-map generate+apply, 4K P010 batch", "value": None, "unit": "MPix/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "dry_run": True, "scaling": "weak",
@@ -558,9 +609,17 @@ def main():
     assert a.gpus in (1, world), "--gpus %d but torch.distributed.run started %d ranks" % (a.gpus, world)
     if a.dry_run:
         return dry_run(a, world, rank)
+    multi = world > 1 or a.exchange_with_one_rank
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
+        if world == 1:   # (--exchange-with-one-rank outside a launcher: a rendezvous of one)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
@@ -568,7 +627,7 @@ def main():
     dev = local if local < ndev else local % ndev     # rehearsal on fewer GPUs than ranks shares devices (gloo only)
     assert a.backend != "nccl" or local < ndev, "RCCL needs one GPU per rank"
     torch.cuda.set_device(dev)
-    if world > 1:
+    if multi:
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
@@ -588,23 +647,32 @@ def main():
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     red = torch.zeros(2, dtype=torch.float32, device="cuda")
 
-    side = torch.cuda.Stream() if world > 1 else None   # the exchange's own stream
+    side = torch.cuda.Stream() if multi else None   # the exchange's own stream
+    clib, chandle, comm_note = (None, None, None)
+    if multi and a.comm == "capi":
+        clib, chandle, comm_note = init_capi_comm(dist, a.backend, rank, world, dev)
+    red_capi = torch.zeros(2, dtype=torch.float32, device="cuda")   # (min, max) as the C library leaves them
 
     def step(ev_gen=None, ev_app=None, exchange=True, rotate=True):
         batch = batches[turn[0] % R] if rotate else batches[0]
         turn[0] += 1
         batch.generate(stream, ev_gen)
         work = None
-        if world > 1 and exchange:
+        if multi and exchange:
             # the path's only exchange: batch-wide content min / max boost (8 bytes, latency-bound).  Its small kernels (the fold of
             # this rank's pairs) and the all-reduce go onto a stream of their own behind generate, so that apply neither waits for
             # them nor has them in its way; the step ends when both streams have.
             main = torch.cuda.current_stream()
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _, work = sharding.reduce_content_minmax(batch.minmax, dist, red, async_op=True)
+            if clib is not None:
+                rc = clib.uhdr_hip_comm_allreduce_minmax(chandle, C.c_void_p(batch.minmax.data_ptr()), batch.n, C.c_void_p(red_capi.data_ptr()),
+                                                         C.c_void_p(side.cuda_stream))
+                assert rc == 0, rc
+            else:
+                with torch.cuda.stream(side):
+                    _, work = sharding.reduce_content_minmax(batch.minmax, dist, red, async_op=True)
         batch.apply(stream, fmt, ev_app)
-        if world > 1 and exchange:
+        if multi and exchange:
             if work is not None:
                 work.wait()                              # (RCCL: the current stream waits for the collective; gloo: the host does)
             torch.cuda.current_stream().wait_stream(side)
@@ -614,18 +682,18 @@ def main():
         for _ in range(a.warmup):
             step(rotate=rotate)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step(evs_g, evs_a, rotate=rotate)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -653,13 +721,25 @@ def main():
     gen_ms, gen_tot, gen_frames = avg_ms_per_launch(ev_gen)
     app_ms, app_tot, app_frames = avg_ms_per_launch(ev_app)
     coll = None
-    if world > 1:   # (outside the timed region; every rank takes part)
+    if multi:   # (outside the timed region; every rank takes part)
         mine = sharding.reduce_content_minmax(batch.minmax)             # this rank's own (min, max): no collective
         glob = sharding.reduce_content_minmax(batch.minmax, dist)       # the step's exchange once more, joined
+        exch = None
+        if clib is not None:   # ... through the C library when that is the path the steps took
+            cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            exch = lambda: clib.uhdr_hip_comm_allreduce_minmax(chandle, C.c_void_p(batch.minmax.data_ptr()), batch.n, C.c_void_p(red_capi.data_ptr()), cur)
+            assert exch() == 0
+            torch.cuda.synchronize()
+            glob = red_capi.clone()
         props = torch.cuda.get_device_properties(dev)
         label = "cuda:%d %s%s" % (dev, props.name, (" pci " + str(getattr(props, "pci_bus_id", ""))) if hasattr(props, "pci_bus_id") else "")
         coll = collective_report(dist, a.backend, rank, world, label, (float(mine[0]), float(mine[1])), (float(glob[0]), float(glob[1])),
-                                 dev=torch.device("cuda", dev) if a.backend == "nccl" else None)
+                                 dev=torch.device("cuda", dev) if a.backend == "nccl" else None, exchange=exch,
+                                 path="capi: libuhdr_hip_comm.so (uhdr_hip_comm_allreduce_minmax -> ncclAllReduce), id through torch.distributed" if clib is not None
+                                 else "torch.distributed")
+        coll["path_note"] = comm_note
+        if clib is not None:
+            clib.uhdr_hip_comm_destroy(chandle)
 
     if rank == 0:
         mpix_frame = W * H / 1e6
@@ -739,7 +819,7 @@ def main():
         if world == 1 and not a.no_other_configs:
             out["other_configs"] = other_configs(lib, stream)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

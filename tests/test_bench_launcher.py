@@ -32,7 +32,20 @@ def test_gpus_2_launches_two_ranks_and_reports_them():
     assert c["distinct_processes"] == 2 and len({r["pid"] for r in c["ranks"]}) == 2 and len(c["devices"]) == 2
     assert c["reduction_checked"] is True and c["content_minmax"] == c["content_minmax_of_gathered_contributions"] == [1.0, 5.0]
     assert c["allreduce_us"] > 0 and c["allreduce_bytes"] == 8
+    assert c["path"] == "torch.distributed" and c["path_note"] is None   # which exchange a reader of the line is looking at
     assert d["config"]["global_frames"] == 8 and "2 GPUs" in d["config"]["workload"]
+
+
+def test_comm_capi_falls_back_to_torch_with_a_stated_reason_where_it_cannot_run():
+    """--comm capi (the exchange issued by libuhdr_hip_comm.so over RCCL) needs one GPU per rank.  Two CPU ranks over gloo cannot
+    take it: every rank must agree on that BEFORE anything collective of RCCL's is called (nobody hangs), the run continues on
+    torch.distributed, and the line says so -- no re-exec, no error."""
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--frames", "4", "--comm", "capi"])
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    c = d["collective"]
+    assert c["path"] == "torch.distributed" and "capi" in c["path_note"] and "gloo" in c["path_note"]
+    assert c["reduction_checked"] is True and d["content_minmax"] == [1.0, 5.0]
 
 
 def test_workload_names_the_baseline_configs():

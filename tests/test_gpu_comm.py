@@ -106,3 +106,23 @@ def test_cpp_host_program_one_rank(tmp_path):
     v = mm.cpu().numpy().reshape(n, 2)
     # (printed with nine significant digits: enough to name a float exactly)
     assert [np.float32(x) for x in d["content_minmax"]] == [v[:, 0].min(), v[:, 1].max()]
+
+
+def test_bench_takes_the_c_library_path_with_comm_capi():
+    """bench.py --comm capi on the one rank a one-GPU box allows (--exchange-with-one-rank: a process group and an RCCL communicator
+    of one): the RCCL id travels through torch.distributed, every step's exchange is uhdr_hip_comm_allreduce_minmax on the side
+    stream, and the line says which path ran and that the reduced pair equals the rank's own contribution."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "4", "--steps", "3", "--warmup", "1", "--ramp-ms", "0", "--rotate", "2",
+                        "--exchange-with-one-rank", "--comm", "capi", "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    c = d["collective"]
+    assert c["path"].startswith("capi") and c["path_note"] is None and c["world"] == 1 and c["backend"].startswith("nccl")
+    assert c["reduction_checked"] is True and c["content_minmax"][0] < c["content_minmax"][1] and c["allreduce_us"] > 0
+    assert d["n_gpus"] == 1 and d["value"] > 0

@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--exchange-with-one-rank", action="store_true", help="testing aid: with --gpus 1, still create the process group "
                     "(a world of one) and run the per-step exchange and the collective report -- the one way a one-GPU box can put "
                     "--comm capi's path through the bench on hardware.  Not the driver's protocol: the N = 1 headline has no exchange")
+    ap.add_argument("--no-fixed-batch", action="store_true", help="skip the fixed-batch measurement behind `value` (profiling runs: the last "
+                    "K dispatches of the process are then the K timed steps of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the extra configs[1]/[4] timings (profiling runs)")
     ap.add_argument("--no-stats", action="store_true", help="experiment: generate without the per-image content min/max pass")
@@ -711,7 +713,7 @@ def main():
     ev_gen, ev_app = [], []
     elapsed = timed_steps(ev_gen, ev_app)
     # the same protocol on ONE batch, step after step (rounds 1-3's `value`): reported beside `value`, never as it
-    fixed_elapsed = timed_steps(rotate=False) if R > 1 else None
+    fixed_elapsed = timed_steps(rotate=False) if R > 1 and not a.no_fixed_batch else None
 
     def avg_ms_per_launch(evs):   # every event pair brackets exactly one kernel launch of <= CHUNK frames
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# one box: profile passes + bench line + apply counters -> gpurun_out/*_$1.*   (scripts/final_refresh.sh TAG)
+# ONE box: the plain bench line, the profile passes (kernel trace with the traced process's own line, PMC passes), the apply
+# counters, and every fraction recomputed from those files -> gpurun_out/*_$1.*   (scripts/final_refresh.sh TAG; copy to profiles/)
 T=$1
-bash scripts/profile_bench.sh $T > gpurun_out/prof_$T.log 2>&1
-cp gpurun_out/prof_${T}_traffic.json profiles/traffic_latest.json
 python bench.py > gpurun_out/bench_$T.json 2> gpurun_out/bench_$T.err
+bash scripts/profile_bench.sh $T > gpurun_out/prof_$T.log 2>&1
+python bench.py --no-cpu-baseline --no-other-configs > gpurun_out/bench_${T}_after.json 2>> gpurun_out/bench_$T.err
 bash scripts/profile_apply_pmc.sh $T > /dev/null 2>&1
-python -c "
-import json; d=json.load(open('gpurun_out/bench_$T.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['kernels']['apply']['avg_launch_ms'], d['kernels']['generate']['avg_launch_ms'])"
-grep -A5 "== the last" gpurun_out/prof_$T.txt | cut -c1-175
+python scripts/recompute_fractions.py gpurun_out/bench_$T.json gpurun_out/prof_$T.json > gpurun_out/onebox_$T.txt 2>&1
+cat gpurun_out/onebox_$T.txt

@@ -67,6 +67,11 @@ def parse():
     ap.add_argument("--exchange-with-one-rank", action="store_true", help="testing aid: with --gpus 1, still create the process group "
                     "(a world of one) and run the per-step exchange and the collective report -- the one way a one-GPU box can put "
                     "--comm capi's path through the bench on hardware.  Not the driver's protocol: the N = 1 headline has no exchange")
+    ap.add_argument("--events", default="apply", choices=["all", "apply", "none"], help="which launches of the TIMED region are bracketed by HIP "
+                    "events: the dominant kernel's (apply: what roofline.avg_launch_ms needs; default), both kernels', or none.  An event "
+                    "record between two kernels keeps the second from starting while the first drains: bracketing both kernels costs the "
+                    "step 1.6 %%, apply alone 0.6 %% (profiles/r04_bench_protocol.txt).  With `apply`, generate's launch time comes from a "
+                    "pass of its own behind the timed region (both kernels bracketed there; kernels.generate says so)")
     ap.add_argument("--no-fixed-batch", action="store_true", help="skip the fixed-batch measurement behind `value` (profiling runs: the last "
                     "K dispatches of the process are then the K timed steps of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -711,9 +716,14 @@ def main():
             step(exchange=False)   # (a time-bounded loop: ranks run different counts, so nothing collective in it)
         torch.cuda.synchronize()
     ev_gen, ev_app = [], []
-    elapsed = timed_steps(ev_gen, ev_app)
+    elapsed = timed_steps(ev_gen if a.events == "all" else None, ev_app if a.events != "none" else None)
     # the same protocol on ONE batch, step after step (rounds 1-3's `value`): reported beside `value`, never as it
     fixed_elapsed = timed_steps(rotate=False) if R > 1 and not a.no_fixed_batch else None
+    gen_from_side_pass = False
+    if a.events == "apply":   # generate's launch time: a pass of its own, both kernels bracketed (never part of `value`)
+        side_gen, side_app = [], []
+        timed_steps(side_gen, side_app)
+        ev_gen, gen_from_side_pass = side_gen, True
 
     def avg_ms_per_launch(evs):   # every event pair brackets exactly one kernel launch of <= CHUNK frames
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
@@ -747,9 +757,9 @@ def main():
         mpix_frame = W * H / 1e6
         total_frames = a.frames * world * a.steps
         value = total_frames * mpix_frame / elapsed
-        gen_gbs = GEN_BYTES * gen_frames / (gen_tot * 1e-3) / 1e9
-        app_gbs = APP_BYTES * app_frames / (app_tot * 1e-3) / 1e9
-        dominant = "apply" if app_tot >= gen_tot else "generate"
+        gen_gbs = GEN_BYTES * gen_frames / (gen_tot * 1e-3) / 1e9 if gen_tot else 0.0   # (--events apply / none: not measured)
+        app_gbs = APP_BYTES * app_frames / (app_tot * 1e-3) / 1e9 if app_tot else 0.0
+        dominant = "apply" if app_tot >= gen_tot or a.events != "all" else "generate"
         ach = app_gbs if dominant == "apply" else gen_gbs
         per_launch = (APP_BYTES if dominant == "apply" else GEN_BYTES) * min(CHUNK, a.frames)
         traffic, traffic_src = None, None
@@ -794,9 +804,11 @@ def main():
                        "parallelism": "one image batch per GPU, no pixel traffic between GPUs"},
             "roofline": {"bound": "hbm", "kernel": "k_apply_s4<HLG>" if dominant == "apply" else "k_generate<HLG,aligned>",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                         "frac_note": "HIP events on the launch stream around each launch of the dominant kernel, plain run: consecutive kernels "
-                                      "overlap at their boundaries by ~30 us per step, so per-kernel event times sum to less than the step "
-                                      "(profiles/r03_trace_vs_events.txt); frac_whole_step is the number to quote",
+                         "frac_note": "HIP events on the launch stream around each launch of the dominant kernel inside the timed region; consecutive "
+                                      "kernels overlap at their boundaries where no event record sits between them, so per-kernel times do not "
+                                      "add up to the step (profiles/r03_trace_vs_events.txt, profiles/r04_bench_protocol.txt); frac_whole_step "
+                                      "is the number to quote",
+                         "events_in_timed_region": a.events,
                          "frac_whole_step": round((GEN_BYTES + APP_BYTES) * total_frames / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": per_launch,
@@ -807,7 +819,9 @@ def main():
                          "measured_ceilings_this_box_GBs": ceilings},
             "kernels": {
                 "generate": {"avg_launch_ms": round(gen_ms, 4), "GB/s": round(gen_gbs, 1), "frac_of_8TBs": round(gen_gbs / HBM_PEAK_GBS, 4),
-                             "bytes_per_frame": GEN_BYTES},
+                             "bytes_per_frame": GEN_BYTES,
+                             "measured_in": "a pass of its own behind the timed region, both kernels bracketed by events" if gen_from_side_pass
+                                            else "the timed region"},
                 "apply": {"avg_launch_ms": round(app_ms, 4), "GB/s": round(app_gbs, 1), "frac_of_8TBs": round(app_gbs / HBM_PEAK_GBS, 4),
                           "bytes_per_frame": APP_BYTES},
                 "generate+apply_GB/s": round((GEN_BYTES + APP_BYTES) * total_frames / world / elapsed / 1e9, 1),

@@ -7,6 +7,9 @@
   AN   apply loads Y, U, V all non-temporally (the last use of those bytes inside a step)
   GTAN GT + AN: first use temporal, last use non-temporal
 
+  R / GTR / GTANR   the shipped kernels / GT / GTAN with apply walking every image from its last span of cells to its first (what generate
+       read last is what apply then reads first: the tail of the 8-bit planes may still be on-die WITHIN a step)
+
 compiled into scripts/ab/libvar_<name>.so.  VERDICT r03 item 1(b); scripts/time_step_pipeline.py runs them, profiles/r04_pipeline_ab.txt
 has the numbers.
 """
@@ -59,7 +62,18 @@ APP_C_NT = [
   }
   o.mrow[0] = reinterpret_cast<const U16Any*>(im.map + (cy * c.map_w + mx))->v;"""),
 ]
-VARIANTS = {"GT": GEN_T, "GTA": GEN_T + APP_Y_PLAIN, "AN": APP_C_NT, "GTAN": GEN_T + APP_C_NT}
+# apply walks every image from its LAST span of cells to its first: what generate (whose blocks sweep the images top to bottom,
+# all images together) read last -- and, with GT, left in the Infinity Cache -- is what apply then reads first
+APP_REVERSE = [
+    ("""  const uint32_t img_i = blockIdx.x, span = blockIdx.y;
+  const AppImage& im = b.img[img_i];
+  const uint32_t idx = span * c.cells_per_thread * kApplyBlock + threadIdx.x;""",
+     """  const uint32_t img_i = blockIdx.x, span = gridDim.y - 1u - blockIdx.y;
+  const AppImage& im = b.img[img_i];
+  const uint32_t idx = span * c.cells_per_thread * kApplyBlock + threadIdx.x;"""),
+]
+VARIANTS = {"GT": GEN_T, "GTA": GEN_T + APP_Y_PLAIN, "AN": APP_C_NT, "GTAN": GEN_T + APP_C_NT,
+            "R": APP_REVERSE, "GTR": GEN_T + APP_REVERSE, "GTANR": GEN_T + APP_C_NT + APP_REVERSE}
 
 
 def main():

@@ -217,22 +217,24 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
     f2 uf[2], vf[2], huf[2], hvf[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      // float(u - 128) == float(u) - 128.0f exactly (small integers)   gainmapmath.cpp:579-580
+      // float(u - 128) * (1/255.0f)   (gainmapmath.cpp:579-580): ONE rounding of an exact product -- which is what
+      // fma(float(u), k, -128 k) computes as well: 128 k is exact (a power of two times k), so the fma's unrounded value is
+      // (u - 128) k exactly.  One packed fma in place of a packed subtract and a packed multiply, the same float.
       const f2 ub = (f2){(float)((u8[0][r] >> (8 * k)) & 0xffu), (float)((u8[1][r] >> (8 * k)) & 0xffu)};
       const f2 vb = (f2){(float)((v8[0][r] >> (8 * k)) & 0xffu), (float)((v8[1][r] >> (8 * k)) & 0xffu)};
-      uf[k] = (ub - splat(c.bias4096 * 0.03125f)) * splat(k255);   // 128.0f, opaque like the P010 bias below
-      vf[k] = (vb - splat(c.bias4096 * 0.03125f)) * splat(k255);
+      uf[k] = pk_fma(ub, splat(k255), splat(-128.0f * k255));
+      vf[k] = pk_fma(vb, splat(k255), splat(-128.0f * k255));
       // float((x >> 6) - 64) * (1/896) - 0.5   (gainmapmath.cpp:593-600), evaluated as
-      // (float(x & 0xFFC0) - 4096) * (1/896/64) - 0.5: the masked 16-bit word is 64 * (x >> 6), so one mask per
-      // two samples and one SDWA word->float conversion per sample replace shift + mask + subtract + convert;
-      // scaling by 2^-6 commutes with the rounding of the product, so the float is the same.  The bias comes from a
-      // kernel argument (always 4096.0f) so that hipcc keeps it a packed float subtract instead of folding it back
-      // into an integer add in front of every conversion.
+      // fma(float(x & 0xFFC0), (1/896)/64, -64 (1/896)) - 0.5: the masked 16-bit word is 64 * (x >> 6), so one mask per
+      // two samples and one SDWA word->float conversion per sample replace shift + mask + subtract + convert; both
+      // constants are exact scalings of 1/896 by powers of two, so the fma rounds the reference's exact product
+      // ((x >> 6) - 64) * (1/896) -- once, like the reference's multiply.  (Round 4: the fma form; a subtract and a
+      // multiply before, 32 packed instructions more per pixel pair over the three places it applies.)
       const uint32_t m0 = huv[0][r][k] & 0xFFC0FFC0u, m1 = huv[1][r][k] & 0xFFC0FFC0u;
       const f2 hu = (f2){cvt_word0(m0), cvt_word0(m1)};
       const f2 hv = (f2){cvt_word1(m0), cvt_word1(m1)};
-      huf[k] = (hu - splat(c.bias4096)) * splat(k896 * 0.015625f) - splat(0.5f);
-      hvf[k] = (hv - splat(c.bias4096)) * splat(k896 * 0.015625f) - splat(0.5f);
+      huf[k] = pk_fma(hu, splat(k896 * 0.015625f), splat(-64.0f * k896)) - splat(0.5f);
+      hvf[k] = pk_fma(hv, splat(k896 * 0.015625f), splat(-64.0f * k896)) - splat(0.5f);
     }
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
@@ -245,7 +247,7 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
         sv += vf[dx >> 1];
         const uint32_t w0 = hy[0][dy][dx >> 1] & 0xFFC0FFC0u, w1 = hy[1][dy][dx >> 1] & 0xFFC0FFC0u;
         const f2 hb = (dx & 1) ? (f2){cvt_word1(w0), cvt_word1(w1)} : (f2){cvt_word0(w0), cvt_word0(w1)};
-        hsy += (hb - splat(c.bias4096)) * splat(k876 * 0.015625f);
+        hsy += pk_fma(hb, splat(k876 * 0.015625f), splat(-64.0f * k876));   // ((x >> 6) - 64) * (1/876), one rounding (see above)
         hsu += huf[dx >> 1];
         hsv += hvf[dx >> 1];
       }

@@ -448,6 +448,15 @@ AppConsts apply_consts(const uhdr_hip_image_t& yuv, const uhdr_hip_image_t& map,
   c.idw = idw;
   c.lut = nullptr;
   c.lut_boost_factor = c.display_boost > 0 ? c.display_boost / md.maxContentBoost : 1.0f;  // gainmapmath.h:162
+  // LUT-mode apply divides (sRGB table value x GainLUT entry) by display_boost.  The table values are 0 or lie in [7e-5, 1], the
+  // GainLUT entries between 2^(log2 min x factor) and 2^(log2 max x factor): with the divisor in [2^-20, 2^20] and those exponents
+  // within +-40 no operand, quotient or remainder of the division's IEEE expansion leaves the normal range, v_div_scale_f32 rescales
+  // nothing and the expansion can run as it stands, two quotients per instruction (k_apply_lut_s4: lut_cell_pk).
+  // The quotient is then at most 2^(the larger exponent) / display_boost; below 32768 its index product into a 65536-entry table
+  // stays under 2^31 (lut_index_pos: no test for the wild range).
+  const double lut_top = std::exp2(std::fmax(c.log2_min_d, c.log2_max_d) * (double)c.lut_boost_factor) / (double)c.display_boost;
+  c.lut_plain_div = (c.display_boost >= 0x1p-20f && c.display_boost <= 0x1p20f && std::fabs(c.log2_min_d * (double)c.lut_boost_factor) <= 40.0 &&
+                     std::fabs(c.log2_max_d * (double)c.lut_boost_factor) <= 40.0 && lut_top <= 32768.0) ? 1u : 0u;
   // FAST scale-4 kernel: factor/display_boost = 2^(gain*A + B); weights pre-multiplied by A / 255 (k_apply_s4)
   const double ratio = (double)c.display_boost / (double)md.maxContentBoost;
   c.fast.A = (float)((c.log2_max_d - c.log2_min_d) * ratio);

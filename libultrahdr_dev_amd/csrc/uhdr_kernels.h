@@ -117,6 +117,8 @@ struct AppConsts {
   const float* lut;               // device LUT buffer (LUT mode only)
   const float* tab;               // device: the LUT buffer (line-segment tables at kTabS1* / kTabS2*), FAST scale-4 kernel
   float lut_boost_factor;         // GainLUT(metadata, displayBoost): displayBoost > 0 ? displayBoost / max : 1 (gainmapmath.h:162)
+  uint32_t lut_plain_div;         // LUT mode: x / display_boost may run as the IEEE expansion WITHOUT its operand scaling (lut_cell_pk):
+                                  // the operands of this call cannot reach the ranges in which v_div_scale_f32 rescales them
   uint32_t* ex_ws;                // EXACT mode behind the f32 pre-filter: the lists of pixels in doubt (layout below), or nullptr
   uint32_t ex_cap;                // entries per list
   AppFast fast;

@@ -120,9 +120,13 @@ __device__ __forceinline__ uint32_t lut_index(float e, uint32_t n) {
   else v = lut_index_wild(t);
   return min(v, n - 1u);
 }
-// e in [0, 1]: no clip can bite
+// e in [0, 1] (what clampPixelFloat returns: the sRGB lookups of apply): no clip can bite and the conversion is in range
 __device__ __forceinline__ uint32_t lut_index_unit(float e, uint32_t n) {
   return (uint32_t)((double)(e * (float)(n - 1u)) + 0.5);
+}
+// +0 <= e * (n - 1) < 2^32 known (lut_cell_pk: the host has bounded the call's values): the index without the test for the wild range
+__device__ __forceinline__ uint32_t lut_index_pos(float t, uint32_t n) {
+  return min((uint32_t)((double)t + 0.5), n - 1u);
 }
 // GainLUT::mGainTable[idx] (gainmapmath.h:153-168); boost_factor == 1.0f reproduces the one-argument constructor
 __device__ __forceinline__ float gain_lut_entry(uint32_t idx, double log2_min, double log2_max, float boost_factor) {
@@ -1998,9 +2002,9 @@ __global__ void __launch_bounds__(256) k_apply_lut(const AppConsts c, const AppB
     const float* w = c.idw + (size_t)tbl * s * s * 4u + (size_t)oy * s * 4u + ox * 4u;
     const float gain = e1 * w[0] + e2 * w[1] + e3 * w[2] + e4 * w[3];
 
-    const float r = s_srgb[lut_index(clamp01(yf + kP3Cr * v), kLutSrgbInvN)];
-    const float g = s_srgb[lut_index(clamp01(yf - kP3GCb * u - kP3GCr * v), kLutSrgbInvN)];
-    const float bl = s_srgb[lut_index(clamp01(yf + kP3Cb * u), kLutSrgbInvN)];
+    const float r = s_srgb[lut_index_unit(clamp01(yf + kP3Cr * v), kLutSrgbInvN)];
+    const float g = s_srgb[lut_index_unit(clamp01(yf - kP3GCb * u - kP3GCr * v), kLutSrgbInvN)];
+    const float bl = s_srgb[lut_index_unit(clamp01(yf + kP3Cb * u), kLutSrgbInvN)];
     const float factor = s_gain[lut_index(gain, kGainLutN)];       // GainLUT::getGainFactor, gainmapmath.h:173-178
     F3 e;
     e.x = (r * factor) / c.display_boost;                          // applyGainLUT, then ultrahdr.cpp:451
@@ -2050,9 +2054,9 @@ __device__ __forceinline__ void lut_cell(const AppConsts& c, const AppImage& im,
       const float factor = s_gain[lut_index(gain, kGainLutN)];
       const float yf = (float)((in.yrow[oy] >> (8 * ox)) & 0xffu) * k255;
       const int r2 = oy >> 1, k2 = ox >> 1;
-      const float r = s_srgb[lut_index(clamp01(yf + crv[r2][k2]), kLutSrgbInvN)];
-      const float g = s_srgb[lut_index(clamp01(yf - gcbu[r2][k2] - gcrv[r2][k2]), kLutSrgbInvN)];
-      const float bl = s_srgb[lut_index(clamp01(yf + cbu[r2][k2]), kLutSrgbInvN)];
+      const float r = s_srgb[lut_index_unit(clamp01(yf + crv[r2][k2]), kLutSrgbInvN)];
+      const float g = s_srgb[lut_index_unit(clamp01(yf - gcbu[r2][k2] - gcrv[r2][k2]), kLutSrgbInvN)];
+      const float bl = s_srgb[lut_index_unit(clamp01(yf + cbu[r2][k2]), kLutSrgbInvN)];
       o[ox][0] = (r * factor) / c.display_boost;
       o[ox][1] = (g * factor) / c.display_boost;
       o[ox][2] = (bl * factor) / c.display_boost;
@@ -2079,6 +2083,90 @@ __device__ __forceinline__ void lut_cell(const AppConsts& c, const AppImage& im,
       for (int p = 0; p < 3; ++p) {
         const uint32_t q0 = 0x3ffu & (uint32_t)(o[0][p] * 1023.0f), q1 = 0x3ffu & (uint32_t)(o[1][p] * 1023.0f);
         const uint32_t q2 = 0x3ffu & (uint32_t)(o[2][p] * 1023.0f), q3 = 0x3ffu & (uint32_t)(o[3][p] * 1023.0f);
+        *reinterpret_cast<uint2*>(base16 + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+      }
+    }
+  }
+}
+
+// The same cell for interior waves of calls whose division cannot need operand scaling (AppConsts::lut_plain_div), two horizontally
+// adjacent pixels per instruction: every float operation is lut_cell's, in its order, on both pixels at once (v_pk_mul / add / fma;
+// clampPixelFloat through the packed clamp modifier: the same value but for the sign of a zero, which indexes the same table
+// entry).  The division x / display_boost is the IEEE expansion hipcc emits for it --
+//     y0 = rcp(b), e0 = fma(-b, y0, 1), y1 = fma(e0, y0, y0);  q0 = x y1, r0 = fma(-b, q0, x), q1 = fma(r0, y1, q0),
+//     r1 = fma(-b, q1, x), q = fma(r1, y1, q1)
+// -- without v_div_scale_f32 / v_div_fixup_f32 around it: for operands in the ranges the host has checked those change nothing
+// (no rescaling, no special case but x = 0, which the chain maps to +0 by itself), so the quotient is the correctly rounded one,
+// bit for bit what the scalar cell computes.  y1 is formed once per thread; a quotient costs five packed instructions per two
+// values where the expansion spends eleven per value, a quarter-rate v_rcp_f32 among them.
+template <int FMT>
+__device__ __forceinline__ void lut_cell_pk(const AppConsts& c, const AppImage& im, uint32_t cx, uint32_t cy, const ApplyCellIn& in,
+                                            const float* s_srgb, const float* s_gain, const uint16_t* s_code) {
+  const f2 e1 = splat(map_to_float_fast(in.mb[0])), e2 = splat(map_to_float_fast(in.mb[1]));
+  const f2 e3 = splat(map_to_float_fast(in.mb[2])), e4 = splat(map_to_float_fast(in.mb[3]));
+  float crv[2][2], gcbu[2][2], gcrv[2][2], cbu[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float u = (float)((int)((in.uu[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      const float v = (float)((int)((in.vv[r] >> (8 * k)) & 0xffu) - 128) * k255;
+      crv[r][k] = kP3Cr * v; gcbu[r][k] = kP3GCb * u; gcrv[r][k] = kP3GCr * v; cbu[r][k] = kP3Cb * u;
+    }
+  const float db = c.display_boost, y0 = __builtin_amdgcn_rcpf(db), e0 = __builtin_fmaf(-db, y0, 1.0f), y1 = __builtin_fmaf(e0, y0, y0);
+  const f2 nb = splat(-db), yy = splat(y1);
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy) {
+    f2 o[2][3];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const float* w = c_idw4p + (oy * 2 + pr) * 8;
+      f2 gain = e1 * (f2){w[0], w[1]};
+      gain = gain + e2 * (f2){w[2], w[3]};
+      gain = gain + e3 * (f2){w[4], w[5]};
+      gain = gain + e4 * (f2){w[6], w[7]};
+      const f2 tg = gain * splat((float)(kGainLutN - 1u));       // (0 <= gain <= 1 + a few ulps: weights that sum to 1, taps in [0, 1])
+      const f2 factor = (f2){s_gain[lut_index_pos(tg.x, kGainLutN)], s_gain[lut_index_pos(tg.y, kGainLutN)]};
+      const f2 yf = (pr ? (f2){cvt_byte<2>(in.yrow[oy]), cvt_byte<3>(in.yrow[oy])} : (f2){cvt_byte<0>(in.yrow[oy]), cvt_byte<1>(in.yrow[oy])}) * splat(k255);
+      const int r2 = oy >> 1;
+      const f2 rr = pk_add_sat(yf, splat(crv[r2][pr])), gg = pk_add_sat(yf - splat(gcbu[r2][pr]), splat(-gcrv[r2][pr]));
+      const f2 bb = pk_add_sat(yf, splat(cbu[r2][pr]));
+      const f2 ch[3] = {(f2){s_srgb[lut_index_unit(rr.x, kLutSrgbInvN)], s_srgb[lut_index_unit(rr.y, kLutSrgbInvN)]},
+                        (f2){s_srgb[lut_index_unit(gg.x, kLutSrgbInvN)], s_srgb[lut_index_unit(gg.y, kLutSrgbInvN)]},
+                        (f2){s_srgb[lut_index_unit(bb.x, kLutSrgbInvN)], s_srgb[lut_index_unit(bb.y, kLutSrgbInvN)]}};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const f2 x = ch[q] * factor;                           // applyGainLUT
+        const f2 q0 = x * yy, r0 = pk_fma(nb, q0, x), q1 = pk_fma(r0, yy, q0), r1 = pk_fma(nb, q1, x);
+        o[pr][q] = pk_fma(r1, yy, q1);                         // / display_boost (ultrahdr.cpp:451)
+        if (FMT == 2 || FMT == 3) o[pr][q] = o[pr][q] * splat((float)(kLutHlgN - 1u));   // the OETF tables' index product (the host has bounded it below 2^31)
+      }
+    }
+    const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;
+    if (FMT == 2 || FMT == 3) {
+      uint4 qv;
+      uint32_t* qq = &qv.x;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        qq[2 * pr] = (uint32_t)s_code[lut_index_pos(o[pr][0].x, kLutHlgN)] | ((uint32_t)s_code[lut_index_pos(o[pr][1].x, kLutHlgN)] << 10) |
+                     ((uint32_t)s_code[lut_index_pos(o[pr][2].x, kLutHlgN)] << 20) | (0x3u << 30);
+        qq[2 * pr + 1] = (uint32_t)s_code[lut_index_pos(o[pr][0].y, kLutHlgN)] | ((uint32_t)s_code[lut_index_pos(o[pr][1].y, kLutHlgN)] << 10) |
+                         ((uint32_t)s_code[lut_index_pos(o[pr][2].y, kLutHlgN)] << 20) | (0x3u << 30);
+      }
+      st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), qv);
+    } else if (FMT == 1) {
+      const uint2 a = pack_f16(o[0][0].x, o[0][1].x, o[0][2].x), b2 = pack_f16(o[0][0].y, o[0][1].y, o[0][2].y);
+      const uint2 cc = pack_f16(o[1][0].x, o[1][1].x, o[1][2].x), d = pack_f16(o[1][0].y, o[1][1].y, o[1][2].y);
+      uint4* dst = reinterpret_cast<uint4*>(static_cast<uint2*>(im.dst) + pix0);
+      dst[0] = make_uint4(a.x, a.y, b2.x, b2.y);
+      dst[1] = make_uint4(cc.x, cc.y, d.x, d.y);
+    } else {
+      const size_t plane = (size_t)c.width * c.height;
+      uint16_t* base16 = static_cast<uint16_t*>(im.dst);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const uint32_t q0 = 0x3ffu & (uint32_t)(o[0][p].x * 1023.0f), q1 = 0x3ffu & (uint32_t)(o[0][p].y * 1023.0f);
+        const uint32_t q2 = 0x3ffu & (uint32_t)(o[1][p].x * 1023.0f), q3 = 0x3ffu & (uint32_t)(o[1][p].y * 1023.0f);
         *reinterpret_cast<uint2*>(base16 + p * plane + pix0) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
       }
     }
@@ -2115,8 +2203,9 @@ __global__ void __launch_bounds__(1024) k_apply_lut_s4(const AppConsts c, const 
     apply_load_cell(c, im, cx, cy, in);
     const bool edge_x = cx + 1u == c.map_w, edge_y = cy + 1u == c.map_h;
     const int tbl = edge_x ? (edge_y ? 3 : 1) : (edge_y ? 2 : 0);
-    if (__builtin_amdgcn_ballot_w64(tbl != 0) == 0ull) lut_cell<FMT, true>(c, im, cx, cy, in, 0, s_srgb, s_gain, s_code);
-    else lut_cell<FMT, false>(c, im, cx, cy, in, tbl, s_srgb, s_gain, s_code);
+    if (__builtin_amdgcn_ballot_w64(tbl != 0) != 0ull) lut_cell<FMT, false>(c, im, cx, cy, in, tbl, s_srgb, s_gain, s_code);
+    else if (c.lut_plain_div != 0u) lut_cell_pk<FMT>(c, im, cx, cy, in, s_srgb, s_gain, s_code);
+    else lut_cell<FMT, true>(c, im, cx, cy, in, 0, s_srgb, s_gain, s_code);
   }
 }
 

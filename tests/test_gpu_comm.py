@@ -33,6 +33,20 @@ def test_world_of_one_reduces_this_ranks_images():
         stream.synchronize()
         got = out.cpu().numpy()
         assert got[0] == mm[:, 0].min() and got[1] == mm[:, 1].max(), (images, got)
+    # the result may not lie inside the input: batch_minmax is the reduction buffer from the fold on (no scratch of the
+    # communicator's that two exchanges in flight could meet in)
+    d = torch.from_numpy(np.arange(8, dtype=np.float32)).cuda()
+    assert lib.uhdr_hip_comm_allreduce_minmax(comm, C.c_void_p(d.data_ptr()), 4, C.c_void_p(d.data_ptr() + 8), None) == api.ERROR_BAD_PTR
+    # ... and two exchanges on two streams at once, each with its own result, do not disturb each other
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    a, b2 = torch.tensor([3., 9., 2., 5.], device="cuda"), torch.tensor([7., 8., 6., 11.], device="cuda")
+    ra, rb = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(20):
+        assert lib.uhdr_hip_comm_allreduce_minmax(comm, C.c_void_p(a.data_ptr()), 2, C.c_void_p(ra.data_ptr()), C.c_void_p(s1.cuda_stream)) == 0
+        assert lib.uhdr_hip_comm_allreduce_minmax(comm, C.c_void_p(b2.data_ptr()), 2, C.c_void_p(rb.data_ptr()), C.c_void_p(s2.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert ra.tolist() == [2.0, 9.0] and rb.tolist() == [6.0, 11.0]
     # a rank without images contributes nothing: with no image anywhere the result is (+inf, -inf)
     out = torch.zeros(2, dtype=torch.float32, device="cuda")
     assert lib.uhdr_hip_comm_allreduce_minmax(comm, None, 0, C.c_void_p(out.data_ptr()), None) == 0

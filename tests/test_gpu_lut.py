@@ -156,6 +156,33 @@ def test_apply_lut_is_bit_exact(hip, orc, fmt, boost):
         assert np.array_equal(got, want), (fmt, boost, scale, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("fmt", [1, 3, 4])
+def test_apply_lut_division_by_the_display_boost_over_many_divisors(hip, orc, fmt):
+    """Round 4: interior waves of the scale-4 LUT kernel divide by display_boost with the IEEE expansion run WITHOUT its operand
+    scaling, two quotients per instruction (lut_cell_pk), where the host has bounded the operands (AppConsts::lut_plain_div); other
+    calls keep hipcc's full expansion.  Both must be the oracle's true division, bit for bit: a sweep of divisors -- round and
+    awkward ones, significands of all ones and of one, below 1, large, and calls on which the guard switches the plain form off
+    (divisor beyond 2^20, a quotient beyond 32768, minContentBoost above maxContentBoost) -- on a frame wide enough for interior waves."""
+    from tests.gpu_util import gpu_apply, to_dev
+    lib = hip.load()
+    w, h = 1024, 256
+    _, yuv = orc.lcg_frame(w, h, 900 + fmt)
+    gmap = np.random.RandomState(50 + fmt).randint(0, 256, (h // 4, w // 4)).astype(np.uint8)
+    dy, dmap = to_dev(yuv), to_dev(gmap)
+    yi = hip.yuv420_image(dy.data_ptr(), w, h, hip.CG_BT709)
+    ones = float(np.frombuffer(np.uint32(0x40FFFFFF).tobytes(), np.float32)[0])       # 7.9999995: a significand of all ones
+    cases = [(4.9261084, 1.0, b) for b in (FLT_MAX, 1.0, 1.5, 2.0, 3.1415927, 4.0, 4.5, ones / 2, 1.0000001, 0.75, 0.001)]
+    cases += [(49.261086, 1.0, b) for b in (FLT_MAX, 7.77, ones, 33.333332, 48.0)]
+    cases += [(64.0, 0.25, FLT_MAX), (8.0, 0.5, 3.0), (1.0e6, 1.0, 2.0e6), (3.0e6, 1.0, FLT_MAX), (1000.0, 1.0, 0.01), (2.0, 8.0, FLT_MAX), (16.0, 1.0, 1.0e-5)]
+    for maxb, minb, boost in cases:
+        md = hip.metadata(np.float32(maxb), np.float32(minb))
+        omd = orc.Metadata(float(np.float32(maxb)), float(np.float32(minb)), 1.0, 0.0, 0.0, float(np.float32(minb)), float(np.float32(maxb)), 1)
+        st, got, _ = gpu_apply(lib, yi, dmap, w // 4, h // 4, md, fmt, boost, hip.APPLY_LUT)
+        ost, want, _ = orc.apply("orc_", orc.yuv420_image(yuv, w, h, orc.CG_BT709), gmap, omd, fmt, boost, threads=8, lut=True)
+        assert st == ost == 0
+        assert np.array_equal(got, want), (fmt, maxb, minb, boost, int((got != want).sum()))
+
+
 def test_lut_modes_through_host_entry_points_and_batches(hip, orc):
     """MEM_HOST single calls and a mixed-size batch take the same LUT kernels"""
     from tests.gpu_util import dev_empty, stream_ptr, to_dev, to_host

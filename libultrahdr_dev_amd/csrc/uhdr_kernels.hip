@@ -466,13 +466,24 @@ __device__ __forceinline__ void load_pair(const GenConsts& c, const GenImage& im
   }
 }
 
-// wave64 butterfly: every lane ends up with the wave's min / max
+// wave64 reduction: every lane ends up with the wave's min / max.  Six DPP steps -- the lane exchanges ride on the VALU operand
+// path: quad_perm (xor 1, xor 2), row_half_mirror, row_mirror put a row's extreme into its 16 lanes, row_bcast:15 / row_bcast:31
+// carry it across the four rows into lane 63 -- and one v_readlane.  (Round 4.  __shfl_xor compiles to ds_bpermute_b32: six
+// dependent trips through the LDS crossbar per value, 36 of them in k_generate's tail, ~0.6 us during which a wave that has
+// finished its pixels still holds its slot.)  All 64 lanes are active wherever this is called.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWS, 0xF, false));
+}
 __device__ __forceinline__ void wave_minmax(float& vmin, float& vmax) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    vmin = fminf(vmin, __shfl_xor(vmin, off, 64));
-    vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-  }
+  vmin = fminf(vmin, dpp_move<0xB1, 0xF>(vmin));  vmax = fmaxf(vmax, dpp_move<0xB1, 0xF>(vmax));    // quad_perm:[1,0,3,2]
+  vmin = fminf(vmin, dpp_move<0x4E, 0xF>(vmin));  vmax = fmaxf(vmax, dpp_move<0x4E, 0xF>(vmax));    // quad_perm:[2,3,0,1]
+  vmin = fminf(vmin, dpp_move<0x141, 0xF>(vmin)); vmax = fmaxf(vmax, dpp_move<0x141, 0xF>(vmax));   // row_half_mirror
+  vmin = fminf(vmin, dpp_move<0x140, 0xF>(vmin)); vmax = fmaxf(vmax, dpp_move<0x140, 0xF>(vmax));   // row_mirror
+  vmin = fminf(vmin, dpp_move<0x142, 0xA>(vmin)); vmax = fmaxf(vmax, dpp_move<0x142, 0xA>(vmax));   // row_bcast:15 -> rows 1, 3
+  vmin = fminf(vmin, dpp_move<0x143, 0xC>(vmin)); vmax = fmaxf(vmax, dpp_move<0x143, 0xC>(vmax));   // row_bcast:31 -> rows 2, 3
+  vmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vmin), 63));
+  vmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vmax), 63));
 }
 // one lane per wave publishes; keys[0] holds ~key(min), keys[1] holds key(max); both only grow, both start at 0
 __device__ __forceinline__ void publish_minmax(float gmin, float gmax, uint32_t* keys) {

@@ -29,7 +29,7 @@
  *      UHDR_HIP_MEM_DEVICE  device pointers; the call only enqueues kernels on `stream`
  *                           (asynchronous; graph-capturable; nothing is allocated or copied -- with three
  *                           exceptions, each the FIRST use of a stream's workspace: a generate launch of more
- *                           than a few images allocates the stream's 4 MiB statistics workspace, an EXACT apply
+ *                           than a few images allocates the stream's 21 MiB statistics workspace, an EXACT apply
  *                           its lists of pixels in doubt (first call, and again for larger images), and an apply
  *                           with a map scale factor the device holds no weight table for uploads one and waits.
  *                           uhdr_hip_stream_reserve() does all of that ahead of time -- call it before capturing

@@ -285,6 +285,7 @@ GenConsts generate_consts(int sdr_gamut, int hdr_gamut, int hdr_tf, int sdr_is_6
   c.stat_ws = nullptr;
   c.stat_out = nullptr;
   c.stat_spread = 0u;
+  c.stat_slots = 0u;
   c.lut = nullptr;
   c.bias4096 = 4096.0f;
   // f32 pre-filter (gen_pair; error budget in DESIGN.md section 5): the fast gain is within kRel of the exact one
@@ -1986,6 +1987,7 @@ int uhdr_hip_generate_gainmap_batch_ex(int n, const uhdr_hip_image_t* yuvs, cons
       c.stat_stride = kStatWords;
       c.stat_out = keys ? content_minmax + 2 * i : nullptr;
       c.stat_spread = (m <= 16 && (uint64_t)((c.map_w + 1u) >> 1) * c.map_h >= 512u * 64u) ? 1u : 0u;
+      c.stat_slots = generate_slot_waves(c, m);
     } else if (keys != nullptr) {
       HIP_TRY(launch_stats_init(keys + 2 * i, m, s));
     }

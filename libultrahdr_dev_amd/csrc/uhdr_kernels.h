@@ -5,16 +5,27 @@
 
 namespace uhdr {
 
-// 64 KiB per image: header, then kStatLists lists of kStatCap entries (0.2 % of a 4K map's pixels are in doubt: ~1000 entries per
+// Per image (321 KiB since round 4, 64 KiB before): header, then EITHER kStatLists lists of kStatCap entries (0.2 % of a 4K map's pixels are in doubt: ~1000 entries per
 // image, ~16 per list).  Several lists per image because a wave appends with ONE returning atomic on its list's count, and atomics
 // on one address are served one after the other at the memory side (~1 us each: a single count per image cost the kernel 30 %).
 // kStatEst: in launches of few images every wave of an image starts at once, finds nothing published and publishes its estimates' extremes:
 // thousands of atomics on two words, served one after the other (one 4K image: 80 us for a 10 us kernel).  Such launches
 // (GenConsts::stat_spread: at most 16 images of at least 512 waves) publish to and prune by one pair of words per LIST instead;
 // the others keep the single pair, which prunes better.
+// Round 4: launches whose images have at most kStatSlotWaves waves each (a 4K frame at four spans per block: 1016) need no
+// atomic at all -- every wave owns kStatSlotWords words behind the header, word 0 its count (written by every wave of every launch,
+// so nothing has to be cleared), the others its entries; a wave with more entries than fit sets word 6 of the header and the image
+// is swept.  The returning atomic cost the streaming kernel 17 us per 64 x 4K launch (0.435 ms against 0.418 with it compiled out,
+// profiles/r02_generate_ab.txt): a wave waits a trip to the memory side for it before it can exit.  Other launches keep the lists.
+// A wave's words: [0] plain entries | saved entries << 8; [1, kStatSlotPlain]: plain entries (pair index << 3 | flags: the resolve
+// kernel samples the pair again); then kStatSlotSaved entries of 16 words (64 B): (pair index << 3 | flags) and the pair AS SAMPLED --
+// r, g, b, hr, hg, hb of both pixels, what the transfer functions start from -- written by the streaming kernel the moment its
+// filter finds a pixel in doubt (the twelve floats are still in registers then), so that the resolve kernel reads one contiguous
+// line per such pair instead of fourteen scattered ones (that round of reads was 14 of its 24 us).
+constexpr uint32_t kStatSlotWaves = 1024, kStatSlotPlain = 15, kStatSlotSaved = 4, kStatSlotWords = 16 + 16 * kStatSlotSaved;
 constexpr uint32_t kStatLists = 64, kStatCap = 252, kStatEst = 8 + kStatLists, kStatHdr = kStatEst + 2 * kStatLists,
-                   kStatWords = kStatHdr + kStatLists * kStatCap;
-static_assert(kStatWords <= 16384, "statistics workspace per image");   // candidate pairs per image before the image is swept exactly
+                   kStatWords = kStatHdr + (kStatLists * kStatCap > kStatSlotWaves * kStatSlotWords ? kStatLists * kStatCap : kStatSlotWaves * kStatSlotWords);
+static_assert(kStatHdr % 4u == 0u && kStatSlotWords % 4u == 0u && kStatWords % 4u == 0u, "saved entries are read and written as 16-byte pieces");
 constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4 KiB kernarg segment: 64 x 56 B + consts)
 
 // ---- LUT mode (gainmapmath.cpp:21-64 static tables; opt-in) --------------------
@@ -80,6 +91,7 @@ struct GenConsts {
   float flt_scale, flt_delta, flt_lo, flt_hi;
   float flt_gain_rel;   // 2 x kRel: how far (relatively) a filter estimate of the gain may sit from the exact one
   uint32_t stat_spread; // the estimates' extremes are published per list (kStatEst): launches of few, large images
+  uint32_t stat_slots;  // != 0: the waves of an image (this many, <= kStatSlotWaves) append to slots of their own, no atomics (above)
 };
 struct EvalConsts {
   float min_boost, max_boost, log2_min, log2_max;
@@ -196,6 +208,7 @@ hipError_t launch_generate(const GenConsts& c, const GenBatch& b, int n, int hdr
 // a launch of n images this size is too small to be worth k_generate_resolve's latency (a single 4K image: 13 us against 24)
 bool generate_is_small(const GenConsts& c, int n);
 bool generate_resolve_pays(const GenConsts& c, int n);   // a launch with statistics: the filtered kernel + k_generate_resolve beat the exact kernel
+uint32_t generate_slot_waves(const GenConsts& c, int n);  // waves per image of the filtered + deferred launch of n such images, or 0 when they exceed kStatSlotWaves
 hipError_t launch_stats_init(uint32_t* keys, int n, hipStream_t s);
 // after every filtered launch: the pixels it left in doubt and its statistics candidates on the exact path
 hipError_t launch_stats_resolve(const GenConsts& c, const GenBatch& b, int n, int hdr_tf, bool aligned, hipStream_t s);

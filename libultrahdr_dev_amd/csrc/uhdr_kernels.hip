@@ -209,11 +209,22 @@ __device__ __forceinline__ float cvt_word1(uint32_t w) {
 // Returns a mask: bit k (k = 0, 1) set <=> gain[k] is the exact (reference) unclamped gain; a clear bit means gain[k] is the
 // filter's estimate, within GenConsts::flt_gain_rel of it -- unless bit 2 + k is set: that pixel is in doubt (FILTER only), its
 // byte and gain are provisional.
-template <int TF, bool LUT, bool FILTER, bool DEFER = false>
+// PART: the function in two halves, for the pairs the streaming kernel hands to k_generate_resolve WITH their sampled values:
+// kGenFront stops in front of the transfer functions and returns their inputs in *mid (both pixels' r, g, b, hr, hg, hb -- what the
+// filter and the exact path both start from), kGenBack takes them from *mid instead of sampling; kGenWhole with mid != nullptr runs
+// as ever and leaves a copy in *mid.
+constexpr int kGenWhole = 0, kGenFront = 1, kGenBack = 2;
+struct GenMid { f2 r, g, b, hr, hg, hb; };
+template <int TF, bool LUT, bool FILTER, bool DEFER = false, int PART = kGenWhole>
 __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t (&hy)[2][4][2],
                                              const uint32_t (&huv)[2][2][2], const uint32_t (&y8)[2][4],
                                              const uint32_t (&u8)[2][2], const uint32_t (&v8)[2][2],
-                                             uint8_t (&out)[2], float (&gain)[2], const float* s_srgb, const float* s_hdr) {
+                                             uint8_t (&out)[2], float (&gain)[2], const float* s_srgb, const float* s_hdr,
+                                             GenMid* mid = nullptr) {
+  f2 r, g, b, hr, hg, hb;
+  if (PART == kGenBack) {
+    r = mid->r; g = mid->g; b = mid->b; hr = mid->hr; hg = mid->hg; hb = mid->hb;
+  } else {
   f2 sy = splat(0.0f), su = splat(0.0f), sv = splat(0.0f);
   f2 hsy = splat(0.0f), hsu = splat(0.0f), hsv = splat(0.0f);
 #pragma unroll
@@ -265,13 +276,16 @@ __device__ __forceinline__ uint32_t gen_pair(const GenConsts& c, const uint32_t 
   // clampPixelFloat (gainmapmath.cpp:115-118) rides on the last add of each expression: the sum is the same IEEE
   // operation, and min(max(x,0),1) differs from the reference's compare chain only in the sign of a zero,
   // which no later step can observe
-  f2 r = pk_add_sat(sy, splat(c.sdr_cr) * sv);
-  f2 g = pk_add_sat(sy - splat(c.sdr_gcb) * su, -(splat(c.sdr_gcr) * sv));
-  f2 b = pk_add_sat(sy, splat(c.sdr_cb) * su);
+  r = pk_add_sat(sy, splat(c.sdr_cr) * sv);
+  g = pk_add_sat(sy - splat(c.sdr_gcb) * su, -(splat(c.sdr_gcr) * sv));
+  b = pk_add_sat(sy, splat(c.sdr_cb) * su);
   // HDR: YUV->RGB (ultrahdr.cpp:326-327)
-  f2 hr = pk_add_sat(hsy, splat(c.hdr_cr) * hsv);
-  f2 hg = pk_add_sat(hsy - splat(c.hdr_gcb) * hsu, -(splat(c.hdr_gcr) * hsv));
-  f2 hb = pk_add_sat(hsy, splat(c.hdr_cb) * hsu);
+  hr = pk_add_sat(hsy, splat(c.hdr_cr) * hsv);
+  hg = pk_add_sat(hsy - splat(c.hdr_gcb) * hsu, -(splat(c.hdr_gcr) * hsv));
+  hb = pk_add_sat(hsy, splat(c.hdr_cb) * hsu);
+  }
+  if (PART != kGenBack && mid != nullptr) { mid->r = r; mid->g = g; mid->b = b; mid->hr = hr; mid->hg = hg; mid->hb = hb; }
+  if (PART == kGenFront) return 0u;
 
   if (FILTER && !LUT) {
     const f2 fr = (f2){srgb_inv_oetf_fast(r.x), srgb_inv_oetf_fast(r.y)};
@@ -541,6 +555,10 @@ __global__ void __launch_bounds__(BLOCK, 1) k_generate(const GenConsts c, const 
   float emin = __builtin_inff(), emax = -__builtin_inff();   // over gains known exactly
   float amin = __builtin_inff(), amax = -__builtin_inff();   // over all gains (estimates included)
   uint32_t kept_exact = 0u, kept_valid = 0u, kept_doubt = 0u;   // 2 bits per tile
+  uint32_t n_saved = 0u;   // slot mode: pairs of this wave that have left with their sampled values (wave-uniform count)
+  uint32_t* wslot = (FILTER && DEFER && c.stat_slots != 0u)
+                        ? c.stat_ws + (size_t)kStatWords * blockIdx.x + kStatHdr + (blockIdx.y * (uint32_t)(BLOCK / 64) + (threadIdx.x >> 6)) * kStatSlotWords
+                        : nullptr;
 
   // each block walks TILES consecutive spans of BLOCK pairs: fewer, longer-lived waves
   // (wave launch + descriptor fetch is a measurable share of a ~10 us wave)
@@ -559,17 +577,35 @@ __global__ void __launch_bounds__(BLOCK, 1) k_generate(const GenConsts c, const 
     uint8_t o[2];
     float gn[2];
     // a missing second pixel is computed on zeros and dropped
-    const uint32_t ex = gen_pair<TF, LUT, FILTER, DEFER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);
+    GenMid mid;
+    const uint32_t ex = gen_pair<TF, LUT, FILTER, DEFER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr, (FILTER && DEFER) ? &mid : nullptr);
     const uint8_t o0 = o[0], o1 = o[1];
     if (FILTER && DEFER) {
       // pixels in doubt: their bytes are provisional -- the pair goes onto the image's list once the wave has finished its tiles,
       // flags = which of its two pixels k_generate_resolve has to redo -- and their gains take no part in the statistics here
-      const uint32_t dm = (ex >> 2) & (two ? 3u : 1u);
+      uint32_t dm = (ex >> 2) & (two ? 3u : 1u);
+      if (c.stat_slots != 0u) {
+        // slot mode: the pair leaves WITH its sampled values, now, while they are still in registers (one tile in five holds such a
+        // pair; the wave's first kStatSlotSaved go this way, any beyond that onto the plain list below)
+        const unsigned long long dmask = __builtin_amdgcn_ballot_w64(dm != 0u);
+        if (dmask != 0ull) {
+          const uint32_t pos = n_saved + (uint32_t)__builtin_popcountll(dmask & ((1ull << (threadIdx.x & 63u)) - 1ull));
+          n_saved += (uint32_t)__builtin_popcountll(dmask);
+          if (dm != 0u && pos < kStatSlotSaved) {
+            float4* e = reinterpret_cast<float4*>(wslot + 16u + pos * 16u);
+            e[0] = make_float4(__uint_as_float((idx << 3) | dm), mid.r.x, mid.r.y, mid.g.x);
+            e[1] = make_float4(mid.g.y, mid.b.x, mid.b.y, mid.hr.x);
+            e[2] = make_float4(mid.hr.y, mid.hg.x, mid.hg.y, mid.hb.x);
+            e[3] = make_float4(mid.hb.y, 0.0f, 0.0f, 0.0f);
+            dm = 0u;   // (not onto the plain list; its gains stay out of the statistics here all the same: `valid` below)
+          }
+        }
+      }
       kept_doubt |= dm << (2u * t);
       if (stats) {
         s_kept[(2u * t) * BLOCK + threadIdx.x] = gn[0];
         s_kept[(2u * t + 1u) * BLOCK + threadIdx.x] = gn[1];
-        const uint32_t valid = (two ? 3u : 1u) & ~dm;
+        const uint32_t valid = (two ? 3u : 1u) & ~((ex >> 2) & 3u);
         kept_exact |= (ex & 3u) << (2u * t);
         kept_valid |= valid << (2u * t);
         if (valid & 1u) { amin = fminf(amin, gn[0]); amax = fmaxf(amax, gn[0]); }
@@ -647,17 +683,30 @@ __global__ void __launch_bounds__(BLOCK, 1) k_generate(const GenConsts c, const 
       mask[t] = __builtin_amdgcn_ballot_w64((((kept_doubt >> (2u * t)) & 3u) | ((cand >> t) & 1u)) != 0u);
       total += (uint32_t)__builtin_popcountll(mask[t]);
     }
-    if (total != 0u) {
+    if (total != 0u || c.stat_slots != 0u) {
       const uint32_t lane = threadIdx.x & 63u, list = blk % kStatLists;
-      uint32_t base = 0u;
-      if (lane == 0u) base = atomicAdd(&ws[8u + list], total);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      uint32_t base = 0u, cap = kStatCap;
       uint32_t* lw = ws + kStatHdr + list * kStatCap;
+      if (c.stat_slots != 0u) {
+        // the wave's own slots: plain stores, nothing to wait for (every wave of the launch writes its count, also a zero)
+        lw = wslot;
+        const bool over = total > kStatSlotPlain;
+        const uint32_t ns = n_saved < kStatSlotSaved ? n_saved : kStatSlotSaved;
+        if (lane == 0u) {
+          lw[0] = over ? 0u : (total | (ns << 8));
+          if (over) __hip_atomic_store(&ws[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sweep this image
+        }
+        ++lw;
+        cap = over ? 0u : kStatSlotPlain;
+      } else {
+        if (lane == 0u) base = atomicAdd(&ws[8u + list], total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      }
 #pragma unroll
       for (uint32_t t = 0; t < (uint32_t)TILES; ++t) {
         const uint32_t flags = ((kept_doubt >> (2u * t)) & 3u) | (((cand >> t) & 1u) << 2);
         const uint32_t pos = base + (uint32_t)__builtin_popcountll(mask[t] & ((1ull << lane) - 1ull));
-        if (flags != 0u && pos < kStatCap) lw[pos] = (((blk * (uint32_t)TILES + t) * (uint32_t)BLOCK + threadIdx.x) << 3) | flags;
+        if (flags != 0u && pos < cap) lw[pos] = (((blk * (uint32_t)TILES + t) * (uint32_t)BLOCK + threadIdx.x) << 3) | flags;
         base += (uint32_t)__builtin_popcountll(mask[t]);
       }
     }
@@ -695,9 +744,31 @@ __global__ void __launch_bounds__(256) k_generate_resolve(const GenConsts c, con
   float emin = __builtin_inff(), emax = -__builtin_inff();
   // one loop for both forms (the exact path is large): thread g of the image takes pair g (sweep) or entry g of the image's lists
   // laid end to end (their exclusive prefix sums in LDS), so that the few entries fill whole waves
-  __shared__ uint32_t s_first[kStatLists + 1u];
+  __shared__ uint32_t s_first[kStatSlotWaves + 1u];
+  __shared__ uint8_t s_ns[kStatSlotWaves];   // slot mode: the saved entries among a wave's entries (they come first)
   __shared__ uint32_t s_sweep;
-  if (threadIdx.x < 64u) {   // the counts in one trip to memory (kStatLists == 64), prefix sums by wave shuffles
+  const bool slots = c.stat_slots != 0u;
+  if (slots) {
+    // slot mode: the counts of the image's waves (word 0 of every wave's slots), four per thread, prefix sums over the block
+    static_assert(kStatSlotWaves == 4u * 256u, "four waves' counts per thread");
+    __shared__ uint32_t s_part[4];
+    uint32_t n4[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+      const uint32_t w = 4u * threadIdx.x + j;
+      const uint32_t cw = w < c.stat_slots ? ws[kStatHdr + w * kStatSlotWords] : 0u;   // plain entries | saved entries << 8
+      s_ns[w] = (uint8_t)(cw >> 8);
+      n4[j] = (cw & 0xFFu) + (cw >> 8);
+    }
+    const uint32_t over = __hip_atomic_load(&ws[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t mine = n4[0] + n4[1] + n4[2] + n4[3];
+    const uint32_t before = block_exclusive_sum<256>(mine, s_part);
+    s_first[4u * threadIdx.x] = before;
+    s_first[4u * threadIdx.x + 1u] = before + n4[0];
+    s_first[4u * threadIdx.x + 2u] = before + n4[0] + n4[1];
+    s_first[4u * threadIdx.x + 3u] = before + n4[0] + n4[1] + n4[2];
+    if (threadIdx.x == 255u) { s_first[kStatSlotWaves] = before + mine; s_sweep = over; }
+  } else if (threadIdx.x < 64u) {   // the counts in one trip to memory (kStatLists == 64), prefix sums by wave shuffles
     const uint32_t cnt = ws[8u + threadIdx.x];
     const bool over = __builtin_amdgcn_ballot_w64(cnt > kStatCap) != 0ull;
     uint32_t inc = min(cnt, kStatCap);
@@ -711,22 +782,45 @@ __global__ void __launch_bounds__(256) k_generate_resolve(const GenConsts c, con
   }
   __syncthreads();
   const bool sweep = s_sweep != 0u;
-  const uint32_t n = sweep ? total : s_first[kStatLists];
+  const uint32_t nl = slots ? kStatSlotWaves : kStatLists;
+  const uint32_t n = sweep ? total : s_first[nl];
 #pragma unroll 1
   for (uint32_t g = blockIdx.y * 256u + threadIdx.x; g < n; g += kResolveSlices * 256u) {
     uint32_t entry = (g << 3) | 7u;
+    GenMid mid;
+    bool have = false;   // the pair came with its sampled values
     if (!sweep) {
       uint32_t l = 0u;
-#pragma unroll
-      for (uint32_t s2 = kStatLists / 2u; s2 != 0u; s2 >>= 1) if (s_first[l + s2] <= g) l += s2;   // the list that holds entry g
-      entry = ws[kStatHdr + l * kStatCap + (g - s_first[l])];
+      for (uint32_t s2 = nl / 2u; s2 != 0u; s2 >>= 1) if (s_first[l + s2] <= g) l += s2;   // the list (the wave's slots) that holds entry g
+      const uint32_t k = g - s_first[l];
+      if (!slots) {
+        entry = ws[kStatHdr + l * kStatCap + k];
+      } else if (k >= (uint32_t)s_ns[l]) {
+        entry = ws[kStatHdr + l * kStatSlotWords + 1u + (k - (uint32_t)s_ns[l])];
+      } else {
+        const uint4* e = reinterpret_cast<const uint4*>(ws + kStatHdr + l * kStatSlotWords + 16u + k * 16u);
+        const uint4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+        entry = e0.x;
+        mid.r = (f2){__uint_as_float(e0.y), __uint_as_float(e0.z)};
+        mid.g = (f2){__uint_as_float(e0.w), __uint_as_float(e1.x)};
+        mid.b = (f2){__uint_as_float(e1.y), __uint_as_float(e1.z)};
+        mid.hr = (f2){__uint_as_float(e1.w), __uint_as_float(e2.x)};
+        mid.hg = (f2){__uint_as_float(e2.y), __uint_as_float(e2.z)};
+        mid.hb = (f2){__uint_as_float(e2.w), __uint_as_float(e3.x)};
+        have = true;
+      }
     }
     const uint32_t idx = entry >> 3;
     const uint32_t my = idx / pairs_per_row, pr = idx - my * pairs_per_row;
     const bool two = ALIGNED || (pr * 2u + 1u < c.map_w);
     uint8_t o[2];
     float gn[2];
-    exact_pair<TF, ALIGNED, false>(c, im, im_v, my, pr, two, nullptr, nullptr, o, gn);
+    uint32_t hy[2][4][2], huv[2][2][2], y8[2][4], u8[2][2], v8[2][2];
+    if (!have) {   // sample the pair (again): fourteen scattered lines
+      load_pair<ALIGNED>(c, im, im_v, my, pr, two, hy, huv, y8, u8, v8);
+      gen_pair<TF, false, false, false, kGenFront>(c, hy, huv, y8, u8, v8, o, gn, nullptr, nullptr, &mid);
+    }
+    gen_pair<TF, false, false, false, kGenBack>(c, hy, huv, y8, u8, v8, o, gn, nullptr, nullptr, &mid);
     uint8_t* mp = im.map + (size_t)my * c.map_w + 2u * pr;
     if (entry & 1u) mp[0] = o[0];
     if ((entry & 2u) && two) mp[1] = o[1];
@@ -779,6 +873,15 @@ bool generate_is_small(const GenConsts& c, int n) {
   const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
   const uint32_t span = (uint32_t)kGenBlock * (uint32_t)kGenTiles;
   return (uint64_t)((total + span - 1u) / span) * (uint64_t)n < 1024u;
+}
+
+// waves per image of the filtered + deferred launch launch_generate_t makes of n such images (one span per block when the launch is
+// small, kGenTiles otherwise); 0 when they do not fit the per-wave slots of the statistics workspace
+uint32_t generate_slot_waves(const GenConsts& c, int n) {
+  const uint32_t total = ((c.map_w + 1u) >> 1) * c.map_h;
+  const uint32_t per = (uint32_t)kGenBlock * (generate_is_small(c, n) ? 1u : (uint32_t)kGenTiles);
+  const uint64_t waves = (uint64_t)((total + per - 1u) / per) * (uint64_t)(kGenBlock / 64);
+  return waves <= kStatSlotWaves ? (uint32_t)waves : 0u;
 }
 
 // a launch WITH statistics: is the filtered kernel + k_generate_resolve faster than the exact kernel?  (from 128 spans of 1024 pairs)

@@ -17,13 +17,15 @@ namespace uhdr {
 // so nothing has to be cleared), the others its entries; a wave with more entries than fit sets word 6 of the header and the image
 // is swept.  The returning atomic cost the streaming kernel 17 us per 64 x 4K launch (0.435 ms against 0.418 with it compiled out,
 // profiles/r02_generate_ab.txt): a wave waits a trip to the memory side for it before it can exit.  Other launches keep the lists.
-// A wave's words: [0] plain entries | saved entries << 8; [1, kStatSlotPlain]: plain entries (pair index << 3 | flags: the resolve
+// A wave's count word (kStatSlotCnt + wave): plain entries | saved entries << 8.  Its slots: [1, kStatSlotPlain]: plain entries (pair index << 3 | flags: the resolve
 // kernel samples the pair again); then kStatSlotSaved entries of 16 words (64 B): (pair index << 3 | flags) and the pair AS SAMPLED --
 // r, g, b, hr, hg, hb of both pixels, what the transfer functions start from -- written by the streaming kernel the moment its
 // filter finds a pixel in doubt (the twelve floats are still in registers then), so that the resolve kernel reads one contiguous
 // line per such pair instead of fourteen scattered ones (that round of reads was 14 of its 24 us).
 constexpr uint32_t kStatSlotWaves = 1024, kStatSlotPlain = 15, kStatSlotSaved = 4, kStatSlotWords = 16 + 16 * kStatSlotSaved;
-constexpr uint32_t kStatLists = 64, kStatCap = 252, kStatEst = 8 + kStatLists, kStatHdr = kStatEst + 2 * kStatLists,
+// (slot mode keeps the waves' count words side by side in front of the slots, kStatSlotCnt: the resolve kernel reads them as 4 KiB)
+constexpr uint32_t kStatLists = 64, kStatCap = 252, kStatEst = 8 + kStatLists, kStatSlotCnt = kStatEst + 2 * kStatLists,
+                   kStatHdr = kStatSlotCnt + kStatSlotWaves,
                    kStatWords = kStatHdr + (kStatLists * kStatCap > kStatSlotWaves * kStatSlotWords ? kStatLists * kStatCap : kStatSlotWaves * kStatSlotWords);
 static_assert(kStatHdr % 4u == 0u && kStatSlotWords % 4u == 0u && kStatWords % 4u == 0u, "saved entries are read and written as 16-byte pieces");
 constexpr int kMaxChunk = 64;  // images per launch (descriptors travel in the 4 KiB kernarg segment: 64 x 56 B + consts)

@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(BLOCK, 1) k_generate(const GenConsts c, const 
         const bool over = total > kStatSlotPlain;
         const uint32_t ns = n_saved < kStatSlotSaved ? n_saved : kStatSlotSaved;
         if (lane == 0u) {
-          lw[0] = over ? 0u : (total | (ns << 8));
+          ws[kStatSlotCnt + blk * (uint32_t)(BLOCK / 64) + (threadIdx.x >> 6)] = over ? 0u : (total | (ns << 8));
           if (over) __hip_atomic_store(&ws[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sweep this image
         }
         ++lw;
@@ -753,10 +753,12 @@ __global__ void __launch_bounds__(256) k_generate_resolve(const GenConsts c, con
     static_assert(kStatSlotWaves == 4u * 256u, "four waves' counts per thread");
     __shared__ uint32_t s_part[4];
     uint32_t n4[4];
+    const uint4 cw4 = *reinterpret_cast<const uint4*>(ws + kStatSlotCnt + 4u * threadIdx.x);   // plain entries | saved entries << 8, four waves'
+    const uint32_t cws[4] = {cw4.x, cw4.y, cw4.z, cw4.w};
 #pragma unroll
     for (uint32_t j = 0; j < 4u; ++j) {
       const uint32_t w = 4u * threadIdx.x + j;
-      const uint32_t cw = w < c.stat_slots ? ws[kStatHdr + w * kStatSlotWords] : 0u;   // plain entries | saved entries << 8
+      const uint32_t cw = w < c.stat_slots ? cws[j] : 0u;
       s_ns[w] = (uint8_t)(cw >> 8);
       n4[j] = (cw & 0xFFu) + (cw >> 8);
     }
@@ -850,7 +852,8 @@ __global__ void __launch_bounds__(256) k_generate_resolve(const GenConsts c, con
     }
   }
   __syncthreads();   // (words 4 and 5 have been read)
-  if (s_last == kResolveSlices - 1u && threadIdx.x < kStatHdr)   // the header, cleared for the next launch
+  static_assert(kStatSlotCnt <= 256u, "one header word per thread");
+  if (s_last == kResolveSlices - 1u && threadIdx.x < kStatSlotCnt)   // the header, cleared for the next launch (the waves' count words behind it are rewritten by every launch)
     __hip_atomic_store(&ws[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <int TF>

@@ -113,20 +113,25 @@ __device__ __attribute__((noinline)) uint32_t lut_index_wild(float t) {
   if (__builtin_fabs(pos) < 9223372036854775808.0) v = (uint32_t)(long long)pos;
   return v;
 }
+// floor(t + 0.5) in ONE instruction: v_cvt_rpi_i32_f32 rounds to the nearest integer, ties toward +infinity, with no intermediate
+// rounding -- for every float in [0, 2^31) and for -0 the value of (uint32_t)((double)t + 0.5), the reference's expression
+// (scripts/ab/cvt_rpi_check.hip compares all 1.3e9 of them; tests/test_gpu_lut.py through eval case 40).  The f64 form costs
+// v_cvt_f64_f32 + v_add_f64 + v_cvt_u32_f64.
+__device__ __forceinline__ uint32_t round_half_up(float t) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(t));
+  return (uint32_t)r;
+}
 __device__ __forceinline__ uint32_t lut_index(float e, uint32_t n) {
   const float t = e * (float)(n - 1u);
   uint32_t v;
-  if (__builtin_expect(__float_as_uint(t) < 0x4F800000u, 1)) v = (uint32_t)((double)t + 0.5);  // +0 <= t < 2^32
+  if (__builtin_expect(__float_as_uint(t) < 0x4F000000u, 1)) v = round_half_up(t);  // +0 <= t < 2^31
   else v = lut_index_wild(t);
   return min(v, n - 1u);
 }
 // e in [0, 1] (what clampPixelFloat returns: the sRGB lookups of apply): no clip can bite and the conversion is in range
 __device__ __forceinline__ uint32_t lut_index_unit(float e, uint32_t n) {
-  return (uint32_t)((double)(e * (float)(n - 1u)) + 0.5);
-}
-// +0 <= e * (n - 1) < 2^32 known (lut_cell_pk: the host has bounded the call's values): the index without the test for the wild range
-__device__ __forceinline__ uint32_t lut_index_pos(float t, uint32_t n) {
-  return min((uint32_t)((double)t + 0.5), n - 1u);
+  return round_half_up(e * (float)(n - 1u));
 }
 // GainLUT::mGainTable[idx] (gainmapmath.h:153-168); boost_factor == 1.0f reproduces the one-argument constructor
 __device__ __forceinline__ float gain_lut_entry(uint32_t idx, double log2_min, double log2_max, float boost_factor) {
@@ -2242,21 +2247,25 @@ __device__ __forceinline__ void lut_cell_pk(const AppConsts& c, const AppImage& 
       gain = gain + e2 * (f2){w[2], w[3]};
       gain = gain + e3 * (f2){w[4], w[5]};
       gain = gain + e4 * (f2){w[6], w[7]};
-      const f2 tg = gain * splat((float)(kGainLutN - 1u));       // (0 <= gain <= 1 + a few ulps: weights that sum to 1, taps in [0, 1])
-      const f2 factor = (f2){s_gain[lut_index_pos(tg.x, kGainLutN)], s_gain[lut_index_pos(tg.y, kGainLutN)]};
+      // (0 <= gain <= 1 + a few ulps -- weights that sum to 1, taps in [0, 1] -- so the product stays below N - 1/2: CLIP3 cannot bite)
+      const f2 tg = gain * splat((float)(kGainLutN - 1u));
+      const f2 factor = (f2){s_gain[round_half_up(tg.x)], s_gain[round_half_up(tg.y)]};
       const f2 yf = (pr ? (f2){cvt_byte<2>(in.yrow[oy]), cvt_byte<3>(in.yrow[oy])} : (f2){cvt_byte<0>(in.yrow[oy]), cvt_byte<1>(in.yrow[oy])}) * splat(k255);
       const int r2 = oy >> 1;
       const f2 rr = pk_add_sat(yf, splat(crv[r2][pr])), gg = pk_add_sat(yf - splat(gcbu[r2][pr]), splat(-gcrv[r2][pr]));
       const f2 bb = pk_add_sat(yf, splat(cbu[r2][pr]));
-      const f2 ch[3] = {(f2){s_srgb[lut_index_unit(rr.x, kLutSrgbInvN)], s_srgb[lut_index_unit(rr.y, kLutSrgbInvN)]},
-                        (f2){s_srgb[lut_index_unit(gg.x, kLutSrgbInvN)], s_srgb[lut_index_unit(gg.y, kLutSrgbInvN)]},
-                        (f2){s_srgb[lut_index_unit(bb.x, kLutSrgbInvN)], s_srgb[lut_index_unit(bb.y, kLutSrgbInvN)]}};
+      const f2 tr = rr * splat((float)(kLutSrgbInvN - 1u)), tgr = gg * splat((float)(kLutSrgbInvN - 1u)), tb = bb * splat((float)(kLutSrgbInvN - 1u));
+      const f2 ch[3] = {(f2){s_srgb[round_half_up(tr.x)], s_srgb[round_half_up(tr.y)]},
+                        (f2){s_srgb[round_half_up(tgr.x)], s_srgb[round_half_up(tgr.y)]},
+                        (f2){s_srgb[round_half_up(tb.x)], s_srgb[round_half_up(tb.y)]}};
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const f2 x = ch[q] * factor;                           // applyGainLUT
         const f2 q0 = x * yy, r0 = pk_fma(nb, q0, x), q1 = pk_fma(r0, yy, q0), r1 = pk_fma(nb, q1, x);
-        o[pr][q] = pk_fma(r1, yy, q1);                         // / display_boost (ultrahdr.cpp:451)
-        if (FMT == 2 || FMT == 3) o[pr][q] = o[pr][q] * splat((float)(kLutHlgN - 1u));   // the OETF tables' index product (the host has bounded it below 2^31)
+        // / display_boost (ultrahdr.cpp:451).  HLG / PQ: the quotient only indexes the OETF table, where everything from 1.0 up
+        // lands on the last entry (CLIP3): saturating it to 1.0 -- the instruction's clamp bit -- stands in for the clip of the index
+        if (FMT == 2 || FMT == 3) o[pr][q] = pk_fma_sat(r1, yy, q1) * splat((float)(kLutHlgN - 1u));
+        else o[pr][q] = pk_fma(r1, yy, q1);
       }
     }
     const uint32_t pix0 = (4u * cy + oy) * c.width + 4u * cx;
@@ -2265,10 +2274,10 @@ __device__ __forceinline__ void lut_cell_pk(const AppConsts& c, const AppImage& 
       uint32_t* qq = &qv.x;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        qq[2 * pr] = (uint32_t)s_code[lut_index_pos(o[pr][0].x, kLutHlgN)] | ((uint32_t)s_code[lut_index_pos(o[pr][1].x, kLutHlgN)] << 10) |
-                     ((uint32_t)s_code[lut_index_pos(o[pr][2].x, kLutHlgN)] << 20) | (0x3u << 30);
-        qq[2 * pr + 1] = (uint32_t)s_code[lut_index_pos(o[pr][0].y, kLutHlgN)] | ((uint32_t)s_code[lut_index_pos(o[pr][1].y, kLutHlgN)] << 10) |
-                         ((uint32_t)s_code[lut_index_pos(o[pr][2].y, kLutHlgN)] << 20) | (0x3u << 30);
+        qq[2 * pr] = (uint32_t)s_code[round_half_up(o[pr][0].x)] | ((uint32_t)s_code[round_half_up(o[pr][1].x)] << 10) |
+                     ((uint32_t)s_code[round_half_up(o[pr][2].x)] << 20) | (0x3u << 30);
+        qq[2 * pr + 1] = (uint32_t)s_code[round_half_up(o[pr][0].y)] | ((uint32_t)s_code[round_half_up(o[pr][1].y)] << 10) |
+                         ((uint32_t)s_code[round_half_up(o[pr][2].y)] << 20) | (0x3u << 30);
       }
       st_stream(reinterpret_cast<uint4*>(static_cast<uint32_t*>(im.dst) + pix0), qv);
     } else if (FMT == 1) {
@@ -2854,6 +2863,7 @@ __global__ void __launch_bounds__(256) k_eval_transfer(int fn, const float* in, 
     case 44: y = ec.lut[kLutHlg + lut_index(x, kLutHlgN)]; break;
     case 45: y = ec.lut[kLutPq + lut_index(x, kLutPqN)]; break;
     case 46: y = gain_lut_entry(lut_index(x, kGainLutN), ec.log2_min_d, ec.log2_max_d, 1.0f); break;
+    case 47: y = round_half_up(x) == (uint32_t)((double)x + 0.5) ? 1.0f : 0.0f; break;   // (the accessors' one-instruction index: +0 <= x < 2^31 and -0)
     // FAST apply's line-segment tables, read from the device buffer with the kernel's own index arithmetic.  50 / 53 / 54: stage 1,
     // T(x) = srgbInvOetf(x)^g for g = 1, 1/2, m1.  51 / 52: the 10-bit code stage 2 yields for u in [0, 1] (HLG: u = sqrt(e), PQ:
     // u = e^m1); the kernel's fma rounds toward zero, which is the truncation of the exact sum formed here in double.

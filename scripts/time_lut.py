@@ -1,5 +1,5 @@
 """LUT-mode apply: one 4K frame and a 32-frame launch, every output format"""
-import sys, os, ctypes as C
+import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from libultrahdr_dev_amd import api, synth
@@ -12,14 +12,37 @@ ya = api.image_array([api.yuv420_image(f.data_ptr(), W, H, 0) for f in frames])
 ma = api.image_array([api.mono_image(m.data_ptr(), W // 4, H // 4) for m in maps])
 oa = api.image_array([api.out_image(o.data_ptr()) for o in outs])
 md = api.metadata(float(np.float32(1000.0) / np.float32(203.0)))
-for n in (1, N):
-    for fmt, fn in ((api.OUTPUT_HDR_HLG, "HLG"), (api.OUTPUT_HDR_PQ, "PQ"), (api.OUTPUT_HDR_LINEAR, "F16"), (api.OUTPUT_HDR_LINEAR_RGB_10BIT, "planar 10-bit")):
-        f = lambda: lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), fmt, api.FLT_MAX, oa, api.APPLY_LUT, None)
-        for _ in range(3): assert f() == 0
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10): f()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        print("LUT mode, %2d frame(s), %-14s %.3f ms = %.1f us per frame" % (n, fn, ms, ms * 1e3 / n))
+
+
+def smooth_content():
+    """frames and maps of slowly varying content (what a photograph mostly is): neighbouring pixels fall on neighbouring table entries,
+    where the LCG frames above -- white noise -- spread every wave's 64 lookups over the whole table (LDS bank conflicts)"""
+    yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    for i, f in enumerate(frames):
+        lum = ((xx * 3 + yy * 2 + 37 * i) // 40 % 220 + 16).to(torch.uint8)
+        f[:W * H] = lum.reshape(-1)
+        cyy, cxx = yy[::2, ::2], xx[::2, ::2]
+        f[W * H:W * H + W * H // 4] = ((cxx // 64 + cyy // 48) % 60 + 98).to(torch.uint8).reshape(-1)
+        f[W * H + W * H // 4:W * H * 3 // 2] = ((cxx // 80 + cyy // 32 + 11 * i) % 60 + 98).to(torch.uint8).reshape(-1)
+        maps[i][:] = ((xx[::4, ::4] // 16 + yy[::4, ::4] // 12) % 256).to(torch.uint8).reshape(-1)
+
+
+for content in ("white noise (LCG frames, random maps)", "smooth content"):
+  if content.startswith("smooth"):
+    smooth_content()
+  print(content)
+  for n in (1, N):
+      for fmt, fn in ((api.OUTPUT_HDR_HLG, "HLG"), (api.OUTPUT_HDR_PQ, "PQ"), (api.OUTPUT_HDR_LINEAR, "F16"), (api.OUTPUT_HDR_LINEAR_RGB_10BIT, "planar 10-bit")):
+          f = lambda: lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), fmt, api.FLT_MAX, oa, api.APPLY_LUT, None)
+          for _ in range(3): assert f() == 0
+          torch.cuda.synchronize()
+          t0 = time.perf_counter()
+          while time.perf_counter() - t0 < 0.1:   # (the card raises its clocks only under load)
+              for _ in range(5): f()
+              torch.cuda.synchronize()
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          for _ in range(10): f()
+          e1.record(); torch.cuda.synchronize()
+          ms = e0.elapsed_time(e1) / 10
+          print("LUT mode, %2d frame(s), %-14s %.3f ms = %.1f us per frame" % (n, fn, ms, ms * 1e3 / n))

@@ -67,6 +67,29 @@ def test_accessor_index_rounding_for_every_float_in_0_2(hip, which, n, fn, exact
     assert total == 0x40000001 and bad == 0, (bad, total)
 
 
+def test_one_instruction_index_equals_the_reference_expression_for_every_float_below_2_31(hip):
+    """The accessors form `static_cast<uint32_t>(e * (N - 1) + 0.5)` (float product, double sum, truncation: gainmapmath.cpp:162-171)
+    with v_cvt_rpi_i32_f32 -- nearest integer, ties toward +infinity, no intermediate rounding.  Every float in [+0, 2^31) and -0
+    through both forms inside the library (eval 47), and a second time against torch's float64 arithmetic on the indices read back
+    through the gain table's accessor for the floats around every half-integer up to 2^24, where a sum rounded in float would slip."""
+    lib = hip.load()
+    total = 0
+    chunk = 1 << 27
+    for b in range(0, 0x4F000000, chunk):
+        cnt = min(chunk, 0x4F000000 - b)
+        x = (torch.arange(cnt, dtype=torch.int32, device="cuda") + b).view(torch.float32)
+        ok = _eval(lib, 47, x)
+        assert float(ok.min().item()) == 1.0, hex(b + int(ok.argmin().item()))
+        total += cnt
+    assert total == 0x4F000000
+    assert float(_eval(lib, 47, torch.tensor([-0.0], device="cuda")).item()) == 1.0
+    # the neighbours of k + 0.5 (the tie itself rounds up; its lower neighbour must not)
+    k = torch.arange(0, 1 << 22, dtype=torch.float64, device="cuda") + 0.5
+    for step in (-1, 0, 1):
+        x = (k.float().view(torch.int32) + step).view(torch.float32)
+        assert float(_eval(lib, 47, x).min().item()) == 1.0, step
+
+
 def test_accessors_and_gain_factor_equal_the_oracle_including_out_of_range_inputs(hip, orc):
     lib = hip.load()
     rng = np.random.RandomState(5)

@@ -1,6 +1,7 @@
 """-m gpu: randomized parity sweep in the spirit of the reference's fuzzers (fuzzer/ultrahdr_enc_fuzzer.cpp:87-319:
 random even dimensions, gamuts, transfer function, strides, separate chroma planes): every draw runs generate ->
-apply (random output format, display boost, EXACT or FAST) -> toneMap -> convertYuv on the GPU and on the oracle."""
+apply (random output format, display boost, EXACT or FAST; two draws in three also through the opt-in LUT pipelines) -> toneMap ->
+convertYuv on the GPU and on the oracle."""
 import ctypes as C
 import os
 
@@ -55,6 +56,14 @@ def test_random_configuration(hip, orc, seed):
     st, omap, omd = orc.generate("orc_", oyi, opi, tf, is601)
     gmap = to_host(dmap, mw * mh).reshape(mh, mw)
     assert st == 0 and np.array_equal(gmap, omap), (w, h, sg, hg, tf, is601, int((gmap != omap).sum()))
+    if seed % 3 == 1:   # the opt-in LUT pipeline on the same draw (ultrahdr.cpp's USE_*_LUT branches: DESIGN 4.3)
+        lmap = dev_empty(mw * mh, 0xCD)
+        ldest, lmd = hip.out_image(lmap.data_ptr()), hip.Metadata()
+        assert lib.uhdr_hip_generate_gainmap_ex(C.byref(yi), C.byref(pi), tf, C.byref(lmd), C.byref(ldest), int(is601), hip.GENERATE_LUT,
+                                                hip.MEM_DEVICE, s) == 0
+        lst, lomap, _ = orc.generate("orc_", oyi, opi, tf, is601, lut=True)
+        lg = to_host(lmap, mw * mh).reshape(mh, mw)
+        assert lst == 0 and np.array_equal(lg, lomap), ("LUT generate", w, h, sg, hg, tf, is601, int((lg != lomap).sum()))
     # apply on a map whose size divides the image (random integer scale)
     scale = int(rng.choice([1, 2, 4, 4, 4]))
     aw, ah = (w // (2 * scale)) * 2 * scale, (h // (2 * scale)) * 2 * scale
@@ -83,6 +92,13 @@ def test_random_configuration(hip, orc, seed):
         else:
             worst, _, ok = diff_1010102(got.view(np.uint32), ref.view(np.uint32), wrap=boost < omd.maxContentBoost)
             assert ok and worst <= 1
+        if seed % 3 != 0:   # LUT-mode apply of the same call: bit-exact against the oracle's LUT pipeline
+            lout = dev_empty(hip.output_bytes(fmt, aw, ah), 0xCD)
+            lod = hip.out_image(lout.data_ptr())
+            assert lib.uhdr_hip_apply_gainmap(C.byref(ayi), C.byref(mi), C.byref(amd), fmt, boost, C.byref(lod), hip.APPLY_LUT, hip.MEM_DEVICE, s) == 0
+            lst, lref, _ = orc.apply("orc_", oayi, amap, orc.Metadata(omd.maxContentBoost, 1.0, 1.0, 0.0, 0.0, 1.0, omd.maxContentBoost, 1), fmt, boost, lut=True)
+            lgot = to_host(lout, lref.size)
+            assert lst == 0 and np.array_equal(lgot, lref), ("LUT apply", fmt, scale, boost, aw, ah, int((lgot != lref).sum()))
     # toneMap into a padded destination, convertYuv in place
     dls, dcs = w + int(rng.choice([0, 16, 3])), w // 2 + int(rng.choice([0, 8, 1]))
     d_ty, d_tc = dev_empty(dls * h, 0xEE), dev_empty(dcs * h + dcs, 0xEE)

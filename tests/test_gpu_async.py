@@ -332,3 +332,47 @@ def test_two_threads_decode_jpegr_side_by_side(hip, orc):
     print("one thread %.1f ms, two threads side by side %.1f ms for twice the work" % (t_one * 1e3, t_two * 1e3))
     # (no bound asserted: serialised calls would need 2.0 x one thread's time, 1.6-1.7 x was measured with warm contexts -- but a
     # context that changes roles between leases grows its buffers, and a hipMalloc waits for the whole device)
+
+
+def test_a_stream_per_request_does_not_grow_device_memory(hip, orc):
+    """A service that takes a stream per request and hands it back (uhdr_hip_stream_release) must not grow: every kind of call that
+    keeps something per stream -- generate with statistics (its 21 MiB workspace), EXACT apply (its lists), the host-memory forms
+    (staging leases) and a JPEG/R encode + decode (codec contexts) -- over 96 requests on torch's pool of streams (32 distinct handles:
+    three passes); after the first pass free device memory may not fall again."""
+    from tests.gpu_util import to_dev
+    lib = hip.load()
+    n, w, h = 40, 256, 128
+    keep, ya, pa, ma, oa, host = _batch(hip, orc, n, w, h, 1700)
+    md = hip.Metadata()
+    mm = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+    p010, yuv = orc.lcg_frame(w, h, 1701)
+    hy, hp = hip.yuv420_image(yuv.ctypes.data, w, h, hip.CG_BT709), hip.p010_image(p010.ctypes.data, w, h, hip.CG_BT2100)
+    hmap, hout = np.zeros((w // 4) * (h // 4), np.uint8), np.zeros(w * h * 4, np.uint8)
+    hm, ho = hip.out_image(hmap.ctypes.data), hip.out_image(hout.ctypes.data)
+    jpg = np.zeros(w * h * 2, np.uint8)
+    jlen = C.c_size_t(0)
+    rend = np.zeros(w * h * 4, np.uint8)
+    free_after_first_pass = None
+    for it in range(96):
+        side = torch.cuda.Stream()
+        s = C.c_void_p(side.cuda_stream)
+        assert lib.uhdr_hip_generate_gainmap_batch(n, ya, pa, hip.TF_HLG, C.byref(md), ma, 0, C.c_void_p(mm.data_ptr()), s) == 0
+        assert lib.uhdr_hip_apply_gainmap_batch(n, ya, ma, C.byref(md), hip.OUTPUT_HDR_HLG, FLT_MAX, oa, hip.APPLY_EXACT, s) == 0
+        hmd = hip.Metadata()
+        assert lib.uhdr_hip_generate_gainmap(C.byref(hy), C.byref(hp), hip.TF_HLG, C.byref(hmd), C.byref(hm), 0, hip.MEM_HOST, s) == 0
+        mi = hip.mono_image(hmap.ctypes.data, w // 4, h // 4)
+        assert lib.uhdr_hip_apply_gainmap(C.byref(hy), C.byref(mi), C.byref(hmd), hip.OUTPUT_HDR_HLG, FLT_MAX, C.byref(ho), hip.APPLY_EXACT,
+                                          hip.MEM_HOST, s) == 0
+        assert lib.uhdr_hip_jpegr_encode_api1(C.byref(hp), C.byref(hy), hip.TF_HLG, 90, None, 0, C.c_void_p(jpg.ctypes.data), jpg.size,
+                                              C.byref(jlen), hip.MEM_HOST, s) == 0
+        dimg, dmd = hip.Image(), hip.Metadata()
+        assert lib.uhdr_hip_jpegr_decode(C.c_void_p(jpg.ctypes.data), jlen.value, hip.OUTPUT_HDR_HLG, FLT_MAX, C.c_void_p(rend.ctypes.data),
+                                         rend.size, C.byref(dimg), C.byref(dmd), hip.APPLY_FAST, hip.MEM_HOST, s) == 0
+        assert (dimg.width, dimg.height) == (w, h)
+        side.synchronize()
+        assert lib.uhdr_hip_stream_release(s) == 0
+        if it == 31:
+            torch.cuda.synchronize()
+            free_after_first_pass = torch.cuda.mem_get_info()[0]
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free_after_first_pass - (1 << 20), (free_after_first_pass, torch.cuda.mem_get_info()[0])

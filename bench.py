@@ -72,6 +72,11 @@ def parse():
                     "record between two kernels keeps the second from starting while the first drains: bracketing both kernels costs the "
                     "step 1.6 %%, apply alone 0.6 %% (profiles/r04_bench_protocol.txt).  With `apply`, generate's launch time comes from a "
                     "pass of its own behind the timed region (both kernels bracketed there; kernels.generate says so)")
+    ap.add_argument("--arena", default="spread", choices=["spread", "hipmalloc"], help="where the resident batches lie: `spread` takes them from "
+                    "one placement pool of the library (uhdr_hip_mem_pool_*: every arena's physical chunks spaced evenly over the memory of all "
+                    "resident batches), `hipmalloc` from torch's allocator (one hipMalloc per arena: physically contiguous on a free device).  "
+                    "The other policy is measured behind `value` and reported beside it (`placement`).")
+    ap.add_argument("--no-placement-ab", action="store_true", help="skip the measurement of the other placement policy (profiling runs)")
     ap.add_argument("--no-fixed-batch", action="store_true", help="skip the fixed-batch measurement behind `value` (profiling runs: the last "
                     "K dispatches of the process are then the K timed steps of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,14 +240,26 @@ def dry_run(a, world, rank):
 class Batch:
     """`frames` 4K pairs + their maps and 1010102 outputs, all resident in this rank's HBM."""
 
-    def __init__(self, lib, frames, rank, seed_offset=0):
+    ARENAS = (W * H * 3, W * H * 3 // 2, (W // 4) * (H // 4), W * H * 4)   # bytes per frame: P010, YUV, map, output
+
+    @staticmethod
+    def arena_bytes(size, frames):
+        return (size + 255) // 256 * 256 * frames
+
+    def __init__(self, lib, frames, rank, seed_offset=0, pool=None):
         self.lib, self.n = lib, frames
         self.stats = True
         self.p010, self.yuv, self.maps, self.outs = [], [], [], []
-        # one arena per kind of buffer, frames back to back (256-byte multiples; measured: paddings between them change nothing)
+        # one arena per kind of buffer, frames back to back (256-byte multiples; measured: paddings between them change nothing --
+        # what does is WHICH physical memory the arena occupies: `pool`, DESIGN.md 6.1)
         def arena(size, fill0):
             stride = (size + 255) // 256 * 256
-            t = (torch.zeros if fill0 else torch.empty)(stride * frames, dtype=torch.uint8, device="cuda")
+            if pool is not None:
+                t = pool.tensor(stride * frames)
+                if fill0:
+                    t.zero_()
+            else:
+                t = (torch.zeros if fill0 else torch.empty)(stride * frames, dtype=torch.uint8, device="cuda")
             return [t[i * stride:i * stride + size] for i in range(frames)]
 
         self.p010, self.yuv = arena(W * H * 3, False), arena(W * H * 3 // 2, False)
@@ -646,7 +663,17 @@ def main():
     # R resident batches (R x 4.55 GB of the 288 GB): the timed steps rotate over them.  Batch 0 holds SURVEY 8(d)'s seeds
     # (1234 + global image index: what cpu_baseline cross-checks), the others the same generator 65536 seeds further on.
     R = max(1, a.rotate)
-    batches = [Batch(lib, a.frames, rank, seed_offset=65536 * r) for r in range(R)]
+    pool, placement_note = None, None
+    POOL_CHUNK = 16 << 20
+    if a.arena == "spread":
+        # one pool exactly the size of what stays resident; every arena is an allocation of its own, so its chunks are spaced evenly
+        # over the pool: the R batches interleave physically
+        need = sum((Batch.arena_bytes(sz, a.frames) + POOL_CHUNK - 1) // POOL_CHUNK * POOL_CHUNK for sz in Batch.ARENAS) * R
+        try:
+            pool = api.MemPool(dev, need, POOL_CHUNK)
+        except Exception as e:   # (a runtime without the virtual-memory calls, a device without the memory: say so and go on)
+            placement_note = "placement pool unavailable (%s): torch's allocator instead" % (str(e)[:200],)
+    batches = [Batch(lib, a.frames, rank, seed_offset=65536 * r, pool=pool) for r in range(R)]
     for bt in batches:
         bt.stats = not a.no_stats
     batch = batches[0]
@@ -725,6 +752,17 @@ def main():
         timed_steps(side_gen, side_app)
         ev_gen, gen_from_side_pass = side_gen, True
 
+    # the other placement policy, same protocol, right behind (never `value`): the batches again from torch's allocator
+    other_elapsed = None
+    if pool is not None and not a.no_placement_ab:
+        mine = list(batches)
+        batches[:] = [Batch(lib, a.frames, rank, seed_offset=65536 * r) for r in range(R)]
+        for bt in batches:
+            bt.stats = not a.no_stats
+        other_elapsed = timed_steps()
+        batches[:] = mine
+        torch.cuda.empty_cache()
+
     def avg_ms_per_launch(evs):   # every event pair brackets exactly one kernel launch of <= CHUNK frames
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
         frames = sum(m for _, _, m in evs)
@@ -796,6 +834,16 @@ def main():
                 "value": round(a.frames * world * a.steps * (W * H / 1e6) / fixed_elapsed, 1), "ms_per_step": round(fixed_elapsed / a.steps * 1e3, 4),
                 "what": "the same W + K steps over ONE batch (rounds 1-3's protocol), measured right after `value`: the next step's generate then "
                         "finds part of the chroma planes apply read in the 256 MB Infinity Cache"},
+            "placement": {
+                "policy": "spread" if pool is not None else "hipmalloc", "note": placement_note,
+                "what": "which physical device memory the resident batches occupy (same bytes, same kernels, same virtual layout).  spread: "
+                        "one uhdr_hip_mem_pool of %d MiB chunks the size of the %d resident batches, one allocation per arena, each backed by chunks "
+                        "spaced evenly over the pool, so the batches interleave physically; hipmalloc: one hipMalloc per arena (torch's allocator), "
+                        "physically contiguous on a device whose memory is free.  DESIGN.md 6.1, profiles/r04_placement.txt" % (POOL_CHUNK >> 20, R),
+                "pool_MiB": None if pool is None else pool.stats()[0] * (POOL_CHUNK >> 20),
+                "hipmalloc": None if other_elapsed is None else {
+                    "value": round(a.frames * world * a.steps * (W * H / 1e6) / other_elapsed, 1), "ms_per_step": round(other_elapsed / a.steps * 1e3, 4),
+                    "what": "the same W + K rotating steps over batches from torch's allocator, measured right behind `value` in this process"}},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 in, f32+f64 math, u8/u32 out",
             "data": "synthetic",
             "config": {"workload": workload_name(a, world),

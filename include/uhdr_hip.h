@@ -175,6 +175,30 @@ int uhdr_hip_stream_release(void* stream);
 /* last HIP error text seen by the library on this thread ("" if none) */
 const char* uhdr_hip_last_error(void);
 
+/* ---- where resident images lie in device memory (no reference counterpart: the reference's images live in malloc'ed host memory) ----
+ * Any device pointer works with every call.  But WHICH physical memory a batch of images occupies decides what the card's HBM gives
+ * the streaming kernels: a batch in one physically contiguous stretch (what hipMalloc returns on a device whose memory is mostly free)
+ * runs apply 6-7 % slower than the same batch in pieces taken from all over a region three or more times its size, whatever the
+ * virtual layout (profiles/r04_placement.txt).  A pool takes `bytes` of device memory as chunks of `chunk_bytes` through
+ * the HIP virtual-memory calls; an allocation is one contiguous range of virtual addresses backed by chunks spaced evenly over the
+ * pool's free ones -- so the images of several allocations interleave physically.  Intended use: at start-up, one pool the size of
+ * everything that stays resident (a few batches: frames, maps, renditions), one allocation per arena.
+ *   bytes        rounded up to whole chunks; fails with ERROR_INSUFFICIENT_RESOURCE when the device does not have them
+ *   chunk_bytes  0 = 16 MiB; a multiple of 2 MiB
+ * ERROR_BAD_PTR for a NULL argument, ERROR_UNSUPPORTED_FEATURE for a size of 0, a chunk size that is no multiple of 2 MiB, a device
+ * that does not exist or a pointer the pool did not hand out.
+ * alloc: ERROR_INSUFFICIENT_RESOURCE when fewer free chunks are left than the size needs; free returns the chunks to the pool (the
+ * pointer must be one alloc returned, with no work outstanding on it); trim gives the chunks no allocation uses back to the device;
+ * destroy unmaps and releases everything (allocations included).  Calls on one pool are serialised by the library. */
+typedef struct uhdr_hip_mem_pool uhdr_hip_mem_pool_t;
+int uhdr_hip_mem_pool_create(int device, size_t bytes, size_t chunk_bytes, uhdr_hip_mem_pool_t** pool);
+int uhdr_hip_mem_pool_alloc(uhdr_hip_mem_pool_t* pool, size_t bytes, void** ptr);
+int uhdr_hip_mem_pool_free(uhdr_hip_mem_pool_t* pool, void* ptr);
+int uhdr_hip_mem_pool_trim(uhdr_hip_mem_pool_t* pool);
+int uhdr_hip_mem_pool_destroy(uhdr_hip_mem_pool_t* pool);
+/* chunks the pool holds / of those, chunks no allocation uses (either pointer may be NULL) */
+int uhdr_hip_mem_pool_stats(uhdr_hip_mem_pool_t* pool, size_t* chunks, size_t* free_chunks);
+
 /* ---- single image ------------------------------------------------------------------------ */
 
 /* UltraHdr::generateGainMap (ultrahdr.cpp:185-358).  Writes the (width/4)x(height/4) u8 map into

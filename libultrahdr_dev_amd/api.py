@@ -74,6 +74,12 @@ SIGNATURES = {
     "uhdr_hip_convert_yuv_batch": (C.c_int, [C.c_int, _IP, C.c_int, C.c_int, C.c_void_p]),
     "uhdr_hip_generate_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, C.c_int, _MP, _IP, C.c_int, C.c_void_p, C.c_void_p]),
     "uhdr_hip_apply_gainmap_batch": (C.c_int, [C.c_int, _IP, _IP, _MP, C.c_int, C.c_float, _IP, C.c_int, C.c_void_p]),
+    "uhdr_hip_mem_pool_create": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "uhdr_hip_mem_pool_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "uhdr_hip_mem_pool_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "uhdr_hip_mem_pool_trim": (C.c_int, [C.c_void_p]),
+    "uhdr_hip_mem_pool_destroy": (C.c_int, [C.c_void_p]),
+    "uhdr_hip_mem_pool_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "uhdr_hip_crop": (C.c_int, [_IP, C.c_int, C.c_int, C.c_int, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_mirror": (C.c_int, [_IP, C.c_int, _IP, C.c_int, C.c_void_p]),
     "uhdr_hip_rotate": (C.c_int, [_IP, C.c_int, _IP, C.c_int, C.c_void_p]),
@@ -228,3 +234,49 @@ def image_array(images):
 
 def metadata(max_boost, min_boost=1.0, version=b"1.0"):
     return Metadata(version, float(max_boost), float(min_boost), 1.0, 0.0, 0.0, float(min_boost), float(max_boost))
+
+
+class MemPool:
+    """uhdr_hip_mem_pool_* (include/uhdr_hip.h, "where resident images lie in device memory"): device memory taken as chunks, every
+    allocation spread evenly over the pool's free chunks.  `tensor(n)` returns a torch uint8 tensor over such an allocation (the pool
+    must outlive it)."""
+
+    def __init__(self, device, nbytes, chunk_bytes=0):
+        self.lib, self.device = init(device), device
+        self.handle = C.c_void_p()
+        rc = self.lib.uhdr_hip_mem_pool_create(device, nbytes, chunk_bytes, C.byref(self.handle))
+        if rc != NO_ERROR:
+            raise MemoryError("uhdr_hip_mem_pool_create(%d bytes): status %d (%s)" % (nbytes, rc, self.lib.uhdr_hip_last_error().decode()))
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        rc = self.lib.uhdr_hip_mem_pool_alloc(self.handle, nbytes, C.byref(p))
+        if rc != NO_ERROR:
+            raise MemoryError("uhdr_hip_mem_pool_alloc(%d bytes): status %d" % (nbytes, rc))
+        return p.value
+
+    def tensor(self, nbytes):
+        import torch
+
+        class _Raw:   # (torch reads the CUDA array interface; the object keeps nothing alive: the pool owns the memory)
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(_Raw(self.alloc(nbytes), nbytes), device=torch.device("cuda", self.device))
+
+    def free(self, ptr):
+        return self.lib.uhdr_hip_mem_pool_free(self.handle, C.c_void_p(ptr))
+
+    def trim(self):
+        return self.lib.uhdr_hip_mem_pool_trim(self.handle)
+
+    def stats(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        assert self.lib.uhdr_hip_mem_pool_stats(self.handle, C.byref(a), C.byref(b)) == NO_ERROR
+        return a.value, b.value
+
+    def destroy(self):
+        if self.handle:
+            rc = self.lib.uhdr_hip_mem_pool_destroy(self.handle)
+            self.handle = C.c_void_p()
+            return rc
+        return NO_ERROR

@@ -781,6 +781,163 @@ int uhdr_hip_stream_release(void* stream) {
   return UHDR_HIP_NO_ERROR;
 }
 
+// ---- placement pools (include/uhdr_hip.h: "where resident images lie in device memory") ---------------------------------------
+// Chunks are created one after another, so on a device whose memory is mostly free they walk through it; an allocation takes chunks
+// spaced evenly over the free ones in that order, i.e. it is spread over the whole pool and interleaves with its neighbours.
+struct uhdr_hip_mem_pool {
+  int device = 0;
+  size_t chunk = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handle;
+  std::vector<uint8_t> state;   // 0 free, 1 in an allocation, 2 given back to the device (trim)
+  struct Range { void* va; size_t chunks; std::vector<size_t> member; };
+  std::vector<Range> ranges;
+  std::mutex mu;
+};
+namespace {
+struct DeviceGuard {   // the pool's device is current inside a call and the caller's again afterwards
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess); if (prev == dev) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+void pool_unmap(uhdr_hip_mem_pool* p, uhdr_hip_mem_pool::Range& r) {
+  (void)hipMemUnmap(r.va, r.chunks * p->chunk);
+  (void)hipMemAddressFree(r.va, r.chunks * p->chunk);
+  for (size_t k : r.member) p->state[k] = 0;
+}
+}  // namespace
+
+int uhdr_hip_mem_pool_create(int device, size_t bytes, size_t chunk_bytes, uhdr_hip_mem_pool_t** pool) {
+  if (pool == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  *pool = nullptr;
+  if (chunk_bytes == 0) chunk_bytes = (size_t)16 << 20;
+  if (bytes == 0 || chunk_bytes % ((size_t)2 << 20) != 0) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  if (device < 0 || device >= uhdr_hip_device_count()) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  DeviceGuard g(device);
+  if (!g.ok) { snprintf(t_err, sizeof(t_err), "uhdr_hip_mem_pool_create: cannot make device %d current", device); return UHDR_HIP_UNKNOWN_ERROR; }
+  std::unique_ptr<uhdr_hip_mem_pool> p(new (std::nothrow) uhdr_hip_mem_pool());
+  if (!p) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+  p->device = device;
+  p->chunk = chunk_bytes;
+  const size_t n = (bytes + chunk_bytes - 1) / chunk_bytes;
+  size_t dev_free = 0, dev_total = 0;
+  HIP_TRY(hipMemGetInfo(&dev_free, &dev_total));
+  if (n > dev_free / chunk_bytes) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;   // (before a single chunk is taken)
+  try { p->handle.reserve(n); p->state.reserve(n); } catch (const std::bad_alloc&) { return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE; }
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  for (size_t i = 0; i < n; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    const hipError_t e = hipMemCreate(&h, chunk_bytes, &prop, 0);
+    if (e != hipSuccess) {
+      set_err("hipMemCreate(pool chunk)", e);
+      for (auto& hh : p->handle) (void)hipMemRelease(hh);
+      return e == hipErrorOutOfMemory ? UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE : UHDR_HIP_UNKNOWN_ERROR;
+    }
+    p->handle.push_back(h);
+    p->state.push_back(0);
+  }
+  *pool = p.release();
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_mem_pool_alloc(uhdr_hip_mem_pool_t* p, size_t bytes, void** ptr) {
+  if (p == nullptr || ptr == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  *ptr = nullptr;
+  if (bytes == 0) return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+  std::lock_guard<std::mutex> lk(p->mu);
+  DeviceGuard g(p->device);
+  if (!g.ok) return UHDR_HIP_UNKNOWN_ERROR;
+  const size_t m = (bytes + p->chunk - 1) / p->chunk;
+  std::vector<size_t> freec;
+  uhdr_hip_mem_pool::Range r;
+  try {
+    for (size_t i = 0; i < p->state.size(); ++i) if (p->state[i] == 0) freec.push_back(i);
+    if (freec.size() < m) return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE;
+    // member j = the free chunk at position (j + 1/2) F / m: evenly spaced over the free ones, distinct because F >= m
+    for (size_t j = 0; j < m; ++j) r.member.push_back(freec[(size_t)(((2 * (unsigned long long)j + 1) * freec.size()) / (2 * (unsigned long long)m))]);
+    p->ranges.reserve(p->ranges.size() + 1);
+  } catch (const std::bad_alloc&) { return UHDR_HIP_ERROR_INSUFFICIENT_RESOURCE; }
+  r.chunks = m;
+  r.va = nullptr;
+  HIP_TRY(hipMemAddressReserve(&r.va, m * p->chunk, 0, nullptr, 0));
+  size_t mapped = 0;
+  hipError_t e = hipSuccess;
+  for (; mapped < m; ++mapped) {
+    e = hipMemMap(static_cast<char*>(r.va) + mapped * p->chunk, p->chunk, 0, p->handle[r.member[mapped]], 0);
+    if (e != hipSuccess) break;
+  }
+  if (e == hipSuccess) {
+    hipMemAccessDesc a = {};
+    a.location.type = hipMemLocationTypeDevice;
+    a.location.id = p->device;
+    a.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(r.va, m * p->chunk, &a, 1);
+  }
+  if (e != hipSuccess) {
+    set_err("hipMemMap / hipMemSetAccess(pool allocation)", e);
+    if (mapped) (void)hipMemUnmap(r.va, mapped * p->chunk);
+    (void)hipMemAddressFree(r.va, m * p->chunk);
+    return UHDR_HIP_UNKNOWN_ERROR;
+  }
+  for (size_t k : r.member) p->state[k] = 1;
+  *ptr = r.va;
+  p->ranges.push_back(std::move(r));
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_mem_pool_free(uhdr_hip_mem_pool_t* p, void* ptr) {
+  if (p == nullptr || ptr == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  std::lock_guard<std::mutex> lk(p->mu);
+  DeviceGuard g(p->device);
+  if (!g.ok) return UHDR_HIP_UNKNOWN_ERROR;
+  for (size_t i = 0; i < p->ranges.size(); ++i)
+    if (p->ranges[i].va == ptr) {
+      pool_unmap(p, p->ranges[i]);
+      p->ranges.erase(p->ranges.begin() + (long)i);
+      return UHDR_HIP_NO_ERROR;
+    }
+  return UHDR_HIP_ERROR_UNSUPPORTED_FEATURE;
+}
+
+int uhdr_hip_mem_pool_trim(uhdr_hip_mem_pool_t* p) {
+  if (p == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  std::lock_guard<std::mutex> lk(p->mu);
+  DeviceGuard g(p->device);
+  if (!g.ok) return UHDR_HIP_UNKNOWN_ERROR;
+  for (size_t i = 0; i < p->state.size(); ++i)
+    if (p->state[i] == 0) { (void)hipMemRelease(p->handle[i]); p->state[i] = 2; }
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_mem_pool_stats(uhdr_hip_mem_pool_t* p, size_t* chunks, size_t* free_chunks) {
+  if (p == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  std::lock_guard<std::mutex> lk(p->mu);
+  size_t held = 0, fr = 0;
+  for (uint8_t s : p->state) { held += s != 2; fr += s == 0; }
+  if (chunks) *chunks = held;
+  if (free_chunks) *free_chunks = fr;
+  return UHDR_HIP_NO_ERROR;
+}
+
+int uhdr_hip_mem_pool_destroy(uhdr_hip_mem_pool_t* p) {
+  if (p == nullptr) return UHDR_HIP_ERROR_BAD_PTR;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    DeviceGuard g(p->device);
+    if (!g.ok) return UHDR_HIP_UNKNOWN_ERROR;
+    (void)hipDeviceSynchronize();
+    for (auto& r : p->ranges) pool_unmap(p, r);
+    p->ranges.clear();
+    for (size_t i = 0; i < p->state.size(); ++i)
+      if (p->state[i] != 2) (void)hipMemRelease(p->handle[i]);
+  }
+  delete p;
+  return UHDR_HIP_NO_ERROR;
+}
+
 int uhdr_hip_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   int prev = -1;

@@ -5,7 +5,7 @@ TAG=${1:-run}
 OUT=/tmp/pmc_apply_$TAG
 rm -rf $OUT; mkdir -p $OUT $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 4 --warmup 1 --ramp-ms 0 --no-cpu-baseline --no-other-configs"
+ARGS="$R/bench.py --steps 4 --warmup 1 --ramp-ms 0 --no-fixed-batch --no-placement-ab --no-cpu-baseline --no-other-configs"
 timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1 || echo "pass a: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
 echo "pass a done $(date +%T)" >> $R/gpurun_out/pmc_apply_progress_$TAG.log
 timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT --output-format csv -d $OUT/b -- python3 $ARGS > $OUT/b.log 2>&1 || echo "pass b: timed out or failed" >> $R/gpurun_out/pmc_apply_progress_$TAG.log

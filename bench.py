@@ -76,6 +76,11 @@ def parse():
                     "one placement pool of the library (uhdr_hip_mem_pool_*: every arena's physical chunks spaced evenly over the memory of all "
                     "resident batches), `hipmalloc` from torch's allocator (one hipMalloc per arena: physically contiguous on a free device).  "
                     "The other policy is measured behind `value` and reported beside it (`placement`).")
+    ap.add_argument("--pool-gib", type=float, default=-1.0, help="--arena spread: the stretch of device memory the placement pool is drawn from, "
+                    "in GiB.  The pool is created whole, the arenas take chunks spaced evenly over it, the rest goes back to the device "
+                    "(uhdr_hip_mem_pool_trim) before anything is timed.  -1 (default) = 70 %% of the free device memory, at most 200 GiB: a pool "
+                    "only as large as what stays resident (0) is fast or not by where it happens to lie, a wide one always "
+                    "(profiles/r04_placement.txt)")
     ap.add_argument("--no-placement-ab", action="store_true", help="skip the measurement of the other placement policy (profiling runs)")
     ap.add_argument("--no-fixed-batch", action="store_true", help="skip the fixed-batch measurement behind `value` (profiling runs: the last "
                     "K dispatches of the process are then the K timed steps of `value`)")
@@ -663,17 +668,24 @@ def main():
     # R resident batches (R x 4.55 GB of the 288 GB): the timed steps rotate over them.  Batch 0 holds SURVEY 8(d)'s seeds
     # (1234 + global image index: what cpu_baseline cross-checks), the others the same generator 65536 seeds further on.
     R = max(1, a.rotate)
-    pool, placement_note = None, None
+    pool, placement_note, pool_create_ms = None, None, None
     POOL_CHUNK = 16 << 20
     if a.arena == "spread":
         # one pool exactly the size of what stays resident; every arena is an allocation of its own, so its chunks are spaced evenly
         # over the pool: the R batches interleave physically
         need = sum((Batch.arena_bytes(sz, a.frames) + POOL_CHUNK - 1) // POOL_CHUNK * POOL_CHUNK for sz in Batch.ARENAS) * R
         try:
-            pool = api.MemPool(dev, need, POOL_CHUNK)
+            span = a.pool_gib * (1 << 30) if a.pool_gib >= 0 else min(0.7 * torch.cuda.mem_get_info()[0], 200.0 * (1 << 30))
+            t_pool = time.perf_counter()
+            pool = api.MemPool(dev, max(need, int(span)), POOL_CHUNK)
+            pool_create_ms = (time.perf_counter() - t_pool) * 1e3
         except Exception as e:   # (a runtime without the virtual-memory calls, a device without the memory: say so and go on)
             placement_note = "placement pool unavailable (%s): torch's allocator instead" % (str(e)[:200],)
     batches = [Batch(lib, a.frames, rank, seed_offset=65536 * r, pool=pool) for r in range(R)]
+    pool_span_mib = None
+    if pool is not None:
+        pool_span_mib = pool.stats()[0] * (POOL_CHUNK >> 20)
+        pool.trim()
     for bt in batches:
         bt.stats = not a.no_stats
     batch = batches[0]
@@ -837,10 +849,12 @@ def main():
             "placement": {
                 "policy": "spread" if pool is not None else "hipmalloc", "note": placement_note,
                 "what": "which physical device memory the resident batches occupy (same bytes, same kernels, same virtual layout).  spread: "
-                        "one uhdr_hip_mem_pool of %d MiB chunks the size of the %d resident batches, one allocation per arena, each backed by chunks "
-                        "spaced evenly over the pool, so the batches interleave physically; hipmalloc: one hipMalloc per arena (torch's allocator), "
-                        "physically contiguous on a device whose memory is free.  DESIGN.md 6.1, profiles/r04_placement.txt" % (POOL_CHUNK >> 20, R),
-                "pool_MiB": None if pool is None else pool.stats()[0] * (POOL_CHUNK >> 20),
+                        "one uhdr_hip_mem_pool of %d MiB chunks drawn from pool_span_MiB of device memory, one allocation per arena of the %d "
+                        "resident batches, each backed by chunks spaced evenly over the pool, the unused chunks returned before anything is timed "
+                        "(pool_MiB stay); hipmalloc: one hipMalloc per arena (torch's allocator), physically contiguous on a device whose memory is "
+                        "free.  DESIGN.md 6.1, profiles/r04_placement.txt" % (POOL_CHUNK >> 20, R),
+                "pool_MiB": None if pool is None else pool.stats()[0] * (POOL_CHUNK >> 20), "pool_span_MiB": pool_span_mib,
+                "pool_create_ms": None if pool_create_ms is None else round(pool_create_ms, 1),
                 "hipmalloc": None if other_elapsed is None else {
                     "value": round(a.frames * world * a.steps * (W * H / 1e6) / other_elapsed, 1), "ms_per_step": round(other_elapsed / a.steps * 1e3, 4),
                     "what": "the same W + K rotating steps over batches from torch's allocator, measured right behind `value` in this process"}},

@@ -19,6 +19,7 @@ fmt = api.OUTPUT_HDR_HLG
 SLAB = torch.empty((14 << 30) if (len(sys.argv) < 2 or sys.argv[1] != "slabs") else (4700 << 20), dtype=torch.uint8, device="cuda")
 SIZES = (W * H * 3, W * H * 3 // 2, (W // 4) * (H // 4), W * H * 4)   # p010, yuv, map, out
 MiB = 1 << 20
+SLABS = None
 
 
 class Placed(bench.Batch):
@@ -28,6 +29,7 @@ class Placed(bench.Batch):
         self.lib, self.n, self.stats = lib, N, True
         ar = []
         for k, size in enumerate(SIZES):
+            SLAB = SLABS[k] if SLABS is not None else globals()["SLAB"]   # (vmmarenas: every arena a slab of its own)
             if isinstance(starts[k], (list, tuple)):   # every frame's own offset
                 assert all(o % 256 == 0 and o + size <= SLAB.numel() for o in starts[k])
                 ar.append([SLAB[o:o + size] for o in starts[k]])
@@ -247,6 +249,46 @@ elif mode == "vmmpool":   # a pool of chunks walking through device memory; slab
         SLAB = torch.as_tensor(raw, device="cuda")
         keep.append(raw)
         run(label, *packed(0))
+elif mode == "vmmarenas":   # every arena a slab of its own from one pool of chunks: where each arena's chunks come from, separately
+    vmm = C.CDLL(os.path.join(ROOT, "scripts", "ab", "libvmm_arena.so"))
+    vmm.vmm_pool_create.argtypes, vmm.vmm_pool_create.restype = [C.c_size_t, C.c_size_t], C.c_void_p
+    vmm.vmm_pool_chunks.argtypes, vmm.vmm_pool_chunks.restype = [C.c_void_p], C.c_size_t
+    vmm.vmm_pool_map.argtypes, vmm.vmm_pool_map.restype = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t], C.c_void_p
+
+    class Raw:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    chunk = 16 * MiB
+    pool = vmm.vmm_pool_create(200 << 30, chunk)
+    nch = vmm.vmm_pool_chunks(pool)
+    need = [(((sz + 255) // 256 * 256) * N + chunk - 1) // chunk for sz in SIZES]   # chunks per arena: 100, 50, 3, 127
+    print("pool of %d chunks; arenas take %s" % (nch, need))
+    keep = []
+
+    def arenas(label, spec):
+        """spec[k] = (first chunk, stride) of arena k"""
+        global SLABS
+        SLABS = []
+        for k in range(4):
+            va = vmm.vmm_pool_map(pool, spec[k][0], spec[k][1], need[k])
+            assert va
+            raw = Raw(va, need[k] * chunk)
+            keep.append(raw)
+            SLABS.append(torch.as_tensor(raw, device="cuda"))
+        run(label, [0, 0, 0, 0], (0, 0, 0, 0))
+
+    q = nch // 4
+    for rep in range(2):
+        o = rep * 37
+        arenas("all arenas: every k-th chunk of the whole pool", [(o + 0, nch // need[0]), (o + 1, nch // need[1]), (o + 2, nch // need[2]), (o + 3, nch // need[3])])
+        arenas("every arena contiguous, a quarter of the pool apart", [(o + 0, 1), (o + q, 1), (o + 2 * q, 1), (o + 3 * q, 1)])
+        arenas("inputs contiguous (far apart), output spread", [(o + 0, 1), (o + q, 1), (o + 2 * q, 1), (o + 3, nch // need[3])])
+        arenas("inputs spread, output contiguous", [(o + 0, nch // need[0]), (o + 1, nch // need[1]), (o + 2, nch // need[2]), (o + 3 * q, 1)])
+        arenas("every arena spread over its own quarter", [(o + 0, q // need[0]), (o + q, q // need[1]), (o + 2 * q, q // need[2]), (o + 3 * q, q // need[3])])
+        arenas("P010 over the first half, YUV over the second, output over all", [(o + 0, (nch // 2) // need[0]), (o + nch // 2, (nch // 2) // need[1]), (o + 2, nch // need[2]), (o + 3, nch // need[3])])
+        arenas("all arenas spread over the first 16 GiB", [(o + 0, 1024 // need[0]), (o + 1, 1024 // need[1]), (o + 2, 1024 // need[2]), (o + 3, 1024 // need[3])])
+        arenas("all arenas spread over the first 64 GiB", [(o + 0, 4096 // need[0]), (o + 1, 4096 // need[1]), (o + 2, 4096 // need[2]), (o + 3, 4096 // need[3])])
 elif mode == "stride":
     for p in (0, 256, 1024, 4096, 8192, 65536, 256 * 1024, 1 * MiB, 2 * MiB + 4096):
         run("%d B between frames (all arenas)" % p, *packed(0, (0, 0, 0), (p, p, p, p)))

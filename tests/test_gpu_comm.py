@@ -140,3 +140,6 @@ def test_bench_takes_the_c_library_path_with_comm_capi():
     assert c["path"].startswith("capi") and c["path_note"] is None and c["world"] == 1 and c["backend"].startswith("nccl")
     assert c["reduction_checked"] is True and c["content_minmax"][0] < c["content_minmax"][1] and c["allreduce_us"] > 0
     assert d["n_gpus"] == 1 and d["value"] > 0
+    # (the resident batches came from a placement pool -- the default --, and the line carries the other policy beside it)
+    pl = d["placement"]
+    assert pl["policy"] == "spread" and pl["note"] is None and pl["pool_MiB"] >= 2 * 4 * 71 and pl["hipmalloc"]["value"] > 0

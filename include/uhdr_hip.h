@@ -181,8 +181,9 @@ const char* uhdr_hip_last_error(void);
  * runs apply 6-7 % slower than the same batch in pieces taken from all over a region three or more times its size, whatever the
  * virtual layout (profiles/r04_placement.txt).  A pool takes `bytes` of device memory as chunks of `chunk_bytes` through
  * the HIP virtual-memory calls; an allocation is one contiguous range of virtual addresses backed by chunks spaced evenly over the
- * pool's free ones -- so the images of several allocations interleave physically.  Intended use: at start-up, one pool the size of
- * everything that stays resident (a few batches: frames, maps, renditions), one allocation per arena.
+ * pool's free ones -- so the images of several allocations interleave physically.  Intended use: at start-up, one pool over a wide
+ * stretch of the card (tens of GiB and more: a pool no larger than what it holds is fast or not by where it happens to lie), one
+ * allocation per arena of what stays resident (frames, maps, renditions), then uhdr_hip_mem_pool_trim() for the rest.
  *   bytes        rounded up to whole chunks; fails with ERROR_INSUFFICIENT_RESOURCE when the device does not have them
  *   chunk_bytes  0 = 16 MiB; a multiple of 2 MiB
  * ERROR_BAD_PTR for a NULL argument, ERROR_UNSUPPORTED_FEATURE for a size of 0, a chunk size that is no multiple of 2 MiB, a device

@@ -13,14 +13,14 @@ shutil.copytree(os.path.join(ROOT, "libultrahdr_dev_amd", "csrc"), d + "/csrc")
 shutil.copytree(os.path.join(ROOT, "include"), "/tmp/uhdr_ge1/a/include")
 p = d + "/csrc/uhdr_kernels.hip"
 s = open(p).read()
-old = "    const uint32_t ex = gen_pair<TF, LUT, FILTER, DEFER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);"
+old = "    const uint32_t ex = gen_pair<TF, LUT, FILTER, DEFER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr, (FILTER && DEFER) ? &mid : nullptr);"
 assert s.count(old) == 1
 new = """    uint32_t ex = 3u;
     if (FILTER && DEFER) {
       uint32_t x = 0u;
       for (int k = 0; k < 2; ++k) { for (int r = 0; r < 4; ++r) x ^= hy[k][r][0] ^ hy[k][r][1] ^ y8[k][r]; for (int r = 0; r < 2; ++r) x ^= huv[k][r][0] ^ huv[k][r][1] ^ u8[k][r] ^ v8[k][r]; }
       o[0] = (uint8_t)x; o[1] = (uint8_t)(x >> 8); gn[0] = gn[1] = 1.0f;
-    } else ex = gen_pair<TF, LUT, FILTER, DEFER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr);"""
+    } else ex = gen_pair<TF, LUT, FILTER, DEFER>(c, hy, huv, y8, u8, v8, o, gn, s_srgb, s_hdr, nullptr);"""
 open(p, "w").write(s.replace(old, new))
 subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-shared", "-o", os.path.join(ROOT, "scripts", "ab", "libvar_GE1.so")] + SRCS, cwd=d + "/csrc", stderr=subprocess.DEVNULL)
 print("built GE1")

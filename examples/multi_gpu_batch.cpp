@@ -76,9 +76,27 @@ int run_rank(Shared* sh, int rank, int world, int frames, int steps, int warmup)
   // this rank's slice: global image index = rank * frames + i, seed 1234 + index
   const size_t p010_bytes = W * H * 3, yuv_bytes = W * H * 3 / 2, map_bytes = (W / 4) * (H / 4), out_bytes = W * H * 4;
   std::vector<uhdr_hip_image_t> yi(frames), pi(frames), mi(frames), oi(frames);
+  // What stays resident -- four arenas, frames back to back -- comes from a placement pool (include/uhdr_hip.h): drawn
+  // from a wide stretch of the card, every arena spread evenly over it, the rest handed back.  Plain hipMalloc serves as well (6-10 %
+  // slower on a card whose memory is free) and is what a runtime without the virtual-memory calls gets.
+  const size_t sizes[4] = {p010_bytes, yuv_bytes, (map_bytes + 255) / 256 * 256, out_bytes};
+  char* arena[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t free_b = 0, total_b = 0, need = 0;
+  HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+  for (size_t sz : sizes) need += ((sz * (size_t)frames + ((size_t)16 << 20) - 1) >> 24) << 24;
+  size_t span = free_b / 10 * 7;
+  if (span > ((size_t)200 << 30)) span = (size_t)200 << 30;
+  uhdr_hip_mem_pool_t* pool = nullptr;
+  bool pooled = uhdr_hip_mem_pool_create(rank, span > need ? span : need, 0, &pool) == UHDR_HIP_NO_ERROR;
+  for (int k = 0; k < 4 && pooled; ++k) pooled = uhdr_hip_mem_pool_alloc(pool, sizes[k] * (size_t)frames, reinterpret_cast<void**>(&arena[k])) == UHDR_HIP_NO_ERROR;
+  if (pooled) {
+    CHECK(uhdr_hip_mem_pool_trim(pool));
+  } else {
+    if (pool) CHECK(uhdr_hip_mem_pool_destroy(pool));
+    for (int k = 0; k < 4; ++k) HIPCHECK(hipMalloc(&arena[k], sizes[k] * (size_t)frames));
+  }
   for (int i = 0; i < frames; ++i) {
-    char *p, *y, *m, *o;
-    HIPCHECK(hipMalloc(&p, p010_bytes)); HIPCHECK(hipMalloc(&y, yuv_bytes)); HIPCHECK(hipMalloc(&m, map_bytes)); HIPCHECK(hipMalloc(&o, out_bytes));
+    char *p = arena[0] + sizes[0] * i, *y = arena[1] + sizes[1] * i, *m = arena[2] + sizes[2] * i, *o = arena[3] + sizes[3] * i;
     CHECK(uhdr_hip_synth_lcg_frame(W, H, 1234u + (unsigned)(rank * frames + i), p, y, s));
     yi[i] = uhdr_hip_image_t{y, W, H, UHDR_HIP_CG_BT709, y + W * H, W, W / 2, UHDR_HIP_PIX_FMT_YUV420};
     pi[i] = uhdr_hip_image_t{p, W, H, UHDR_HIP_CG_BT2100, p + W * H * 2, W, W, UHDR_HIP_PIX_FMT_P010};

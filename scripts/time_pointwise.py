@@ -5,8 +5,21 @@ import torch
 from libultrahdr_dev_amd import api, synth
 lib = api.init(0)
 W, H, N = 3840, 2160, 32
-ps = [synth.lcg_frame(W, H, 10 + i)[0] for i in range(N)]
-ds = [torch.zeros(W * H * 3 // 2, dtype=torch.uint8, device="cuda") for _ in range(N)]
+# `pool` as the first argument: frames and results from a placement pool (uhdr_hip_mem_pool_*) instead of torch's allocator
+if len(sys.argv) > 1 and sys.argv[1] == "pool":
+    pool = api.MemPool(0, 200 << 30)
+    pa, ya, da_ = pool.tensor(W * H * 3 * N), pool.tensor(W * H * 3 // 2 * N), pool.tensor(W * H * 3 // 2 * N)
+    pool.trim()
+    ps = [pa[i * W * H * 3:(i + 1) * W * H * 3] for i in range(N)]
+    for i in range(N):
+        synth.lcg_frame(W, H, 10 + i, out=(ps[i], ya[i * W * H * 3 // 2:(i + 1) * W * H * 3 // 2]))
+    da_.zero_()
+    ds = [da_[i * W * H * 3 // 2:(i + 1) * W * H * 3 // 2] for i in range(N)]
+    print("frames and results from a placement pool")
+else:
+    ps = [synth.lcg_frame(W, H, 10 + i)[0] for i in range(N)]
+    ds = [torch.zeros(W * H * 3 // 2, dtype=torch.uint8, device="cuda") for _ in range(N)]
+    print("frames and results from torch's allocator")
 sa = api.image_array([api.p010_image(p.data_ptr(), W, H, api.CG_BT2100) for p in ps])
 da = api.image_array([api.yuv420_image(d.data_ptr(), W, H, api.CG_BT2100) for d in ds])
 def timed(f, it=20):
